@@ -1,0 +1,313 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by running the REAL reference on CPU.
+
+Runs only in the build container (needs /root/reference, which never travels
+to the GPU box).  Writes small ``tests/golden/*.npz`` files holding seeded
+inputs and the reference's outputs; the reference's source is only imported,
+never copied.  Usage:
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python3 /root/repo/tests/golden/make_golden.py
+
+Fixture groups follow SURVEY.md section 8(c): G1 volumes (A1/A2/A3), G2 soft-argmin
+(A4), G3 local lookups (A5/A6), G4 RAFT correlation (A8/A9/A10), G5 GRU local
+updater (A11), G6 disp_warp (A12), G7 convex upsample (A13), G8 RAFT update
+block (A14).
+"""
+import contextlib
+import io
+import os
+import sys
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+REF = os.environ.get("STEREO_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from _weights import fill_state_dict_
+
+torch.set_grad_enabled(False)
+
+
+def npy(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays")
+
+
+# ------------------------------------------------------------------ G1
+def g1_volumes():
+    from models.utils.build_cost_volume import CostVolume
+    from models.CrossAttentionCostVolume.GWC_Cost_Volume import build_gwc_volume
+
+    torch.manual_seed(101)
+    L = torch.randn(2, 16, 5, 40)
+    R = torch.randn(2, 16, 5, 40)
+    out = {"L": npy(L), "R": npy(R)}
+    for D in (1, 12, 40):
+        out[f"corr_D{D}"] = npy(CostVolume(D, "correlation")(L, R))
+    for (D, G) in ((1, 4), (12, 1), (12, 4), (12, 16), (40, 2)):
+        out[f"gwc_D{D}_G{G}"] = npy(build_gwc_volume(L, R, D, G))
+    for D in (1, 12):
+        out[f"diff_D{D}"] = npy(CostVolume(D, "difference")(L, R))
+        out[f"concat_D{D}"] = npy(CostVolume(D, "concat")(L, R))
+    # ragged width (W % 4 != 0) and D > W is not exercised by the reference
+    # (slicing [:-i] with i >= W yields empty rows) -> keep D <= W.
+    torch.manual_seed(102)
+    L2 = torch.randn(1, 6, 3, 37)
+    R2 = torch.randn(1, 6, 3, 37)
+    out["L_ragged"] = npy(L2)
+    out["R_ragged"] = npy(R2)
+    out["corr_ragged_D9"] = npy(CostVolume(9, "correlation")(L2, R2))
+    out["gwc_ragged_D9_G3"] = npy(build_gwc_volume(L2, R2, 9, 3))
+    save("g1_volumes", **out)
+
+
+# ------------------------------------------------------------------ G2
+def g2_soft_argmin():
+    from models.utils.estimation import DisparityEstimation, DisparityEstimationWithProb
+
+    torch.manual_seed(201)
+    vol = 3.0 * torch.randn(2, 12, 5, 40)
+    out = {"vol": npy(vol)}
+    out["disp_sim"] = npy(DisparityEstimation(12, True)(vol))
+    out["disp_cost"] = npy(DisparityEstimation(12, False)(vol))
+    out["disp_other_maxdisp"] = npy(DisparityEstimation(48, True)(vol))  # estimation.py:24-28 branch
+    d, p = DisparityEstimationWithProb(12, True)(vol)
+    out["disp_withprob"] = npy(d)
+    out["prob"] = npy(p)
+    # large logits (softmax stability)
+    big = 40.0 * torch.randn(1, 24, 3, 17)
+    out["vol_big"] = npy(big)
+    out["disp_big"] = npy(DisparityEstimation(24, True)(big))
+    save("g2_soft_argmin", **out)
+
+
+# ------------------------------------------------------------------ G3
+def g3_local_lookup():
+    from models.LocalCostVolume.Attempts.fixed_local_cost_volume import (
+        LocalCostVolume, build_cost_volume_from_volume)
+    from models.LocalCostVolume.Attempts.variance_local_cost_volume import Variance_Based_Local_Cost_Volume
+
+    torch.manual_seed(301)
+    D = 24
+    vol = 2.0 * torch.randn(2, D, 6, 20)
+    disp = torch.rand(2, 1, 6, 20) * (D - 1)
+    # hand-placed edge pixels
+    disp[0, 0, 0, 0] = 0.0
+    disp[0, 0, 0, 1] = 1.5          # disp < r
+    disp[0, 0, 0, 2] = D - 1.0      # top integer
+    disp[0, 0, 0, 3] = D - 2.25     # disp > D-1-r
+    disp[0, 0, 0, 4] = 7.0          # exact integer
+    disp[0, 0, 0, 5] = 2.0          # lower bound exactly 0 for r=2
+    disp[0, 0, 0, 6] = D - 3.0      # upper bound exactly D-1 for r=2
+    disp[0, 0, 0, 7] = 11.5
+    out = {"vol": npy(vol), "disp": npy(disp)}
+    for (r, S) in ((2, 20), (4, 10), (2.1, 20)):
+        for cv in (False, True):
+            key = f"fixed_r{r}_S{S}_cv{int(cv)}"
+            out[key] = npy(LocalCostVolume(radius=r, sample_points=S)(vol, disp, cv))
+    for (g, S) in ((1, 10), (0.5, 20)):
+        for cv in (False, True):
+            key = f"var_g{g}_S{S}_cv{int(cv)}"
+            out[key] = npy(Variance_Based_Local_Cost_Volume(garma=g, sample_points=S)(vol, disp, cv))
+    # raw sampler incl. out-of-range / negative candidates
+    cand = torch.rand(2, 7, 6, 20) * (D + 6) - 3.0
+    cand[0, 0, 0, 0] = 5.0
+    cand[0, 1, 0, 0] = -0.0
+    cand[0, 2, 0, 0] = D - 1.0
+    out["cand"] = npy(cand)
+    out["sampled"] = npy(build_cost_volume_from_volume(vol, cand))
+    save("g3_local_lookup", **out)
+
+
+# ------------------------------------------------------------------ G4
+def g4_raft_corr():
+    from models.IterativeLocalCostVolume.corr.corr import CorrBlock1D, PytorchAlternateCorrBlock1D
+    from models.IterativeLocalCostVolume.utils.utils import coords_grid, bilinear_sampler
+
+    torch.manual_seed(401)
+    B, C, H, W = 2, 16, 5, 24
+    f1 = torch.randn(B, C, H, W)
+    f2 = torch.randn(B, C, H, W)
+    coords = coords_grid(B, H, W) - torch.cat([torch.rand(B, 1, H, W) * 10.0, torch.zeros(B, 1, H, W)], 1)
+    coords[0, 0, 0, 0] = -3.0      # far out of range (left)
+    coords[0, 0, 0, 1] = W + 2.0   # far out of range (right)
+    coords[0, 0, 0, 2] = 5.0       # exact integer
+    coords[0, 0, 0, 3] = W - 1.0
+    out = {"f1": npy(f1), "f2": npy(f2), "coords": npy(coords)}
+    out["allpairs"] = npy(CorrBlock1D.corr(f1, f2)).reshape(B, H, W, W)
+    blk = CorrBlock1D(f1, f2, num_levels=4, radius=4)
+    for i, lv in enumerate(blk.corr_pyramid):
+        out[f"pyr{i}"] = npy(lv).reshape(B * H * W, -1)
+    out["lookup_r4_l4"] = npy(blk(coords))
+    blk2 = CorrBlock1D(f1, f2, num_levels=2, radius=3)
+    out["lookup_r3_l2"] = npy(blk2(coords))
+    alt = PytorchAlternateCorrBlock1D(f1, f2, num_levels=4, radius=4)
+    out["alt_lookup_r4_l4"] = npy(alt(coords))
+    out["coords_grid_3x4"] = npy(coords_grid(2, 3, 4))
+    # bilinear_sampler on a 2-D image (general form, mask=True)
+    img = torch.randn(2, 3, 6, 9)
+    cxy = torch.stack([torch.rand(2, 4, 5) * 11 - 1, torch.rand(2, 4, 5) * 8 - 1], dim=-1)
+    s, m = bilinear_sampler(img, cxy, mask=True)
+    out["bs_img"], out["bs_coords"], out["bs_out"], out["bs_mask"] = npy(img), npy(cxy), npy(s), npy(m)
+    save("g4_raft_corr", **out)
+
+
+# ------------------------------------------------------------------ G5
+def g5_gru_updater():
+    from models.LocalCostVolume.Attempts.update import DisparityUpdateDLCWithMask
+
+    torch.manual_seed(501)
+    D, h, w = 24, 12, 24
+    net = DisparityUpdateDLCWithMask(input_channels=D, hidden_dim=8, sample_points=20).eval()
+    fill_state_dict_(net, seed=0.5)
+    vol = torch.randn(1, D, h, w)
+    disp = torch.rand(1, 1, h, w) * (D - 1)
+    left = torch.randn(1, 3, 8 * h, 8 * w)
+    right = torch.randn(1, 3, 8 * h, 8 * w)
+    hidden = torch.zeros(1, 16, h, w)
+    out = {"vol": npy(vol), "disp0": npy(disp), "left": npy(left), "right": npy(right)}
+    for it in range(3):
+        disp, hidden, mask = net(vol, disp, left, right, hidden, True)
+        out[f"disp{it + 1}"] = npy(disp)
+        out[f"hidden{it + 1}"] = npy(hidden)
+        out[f"mask{it + 1}_sub"] = npy(mask[:, ::37])  # subsample the 576 channels (size)
+    # the guidance encoder's pointwise pieces on their own
+    from utils.disparity_warper import disp_warp
+    p = F.softmax(vol, dim=1)
+    cand = torch.arange(D).view(1, D, 1, 1).float()
+    d0 = torch.from_numpy(out["disp0"])
+    out["uncertainty0"] = npy(p * cand * (cand - d0) * (cand - d0))
+    li = F.interpolate(left, size=[h, w], mode="bilinear", align_corners=False)
+    ri = F.interpolate(right, size=[h, w], mode="bilinear", align_corners=False)
+    out["left_small"], out["right_small"] = npy(li), npy(ri)
+    out["error0"] = npy(disp_warp(ri, d0)[0] - li)
+    save("g5_gru_updater", **out)
+
+
+# ------------------------------------------------------------------ G6
+def g6_disp_warp():
+    from utils.disparity_warper import disp_warp
+
+    torch.manual_seed(601)
+    img = torch.randn(2, 3, 7, 19)
+    disp = torch.rand(2, 1, 7, 19) * 12.0
+    disp[0, 0, 0, 0] = 0.0
+    disp[0, 0, 0, 5] = 30.0   # > W
+    disp[0, 0, 3, 4] = 4.0    # integer
+    out = {"img": npy(img), "disp": npy(disp)}
+    for pm in ("border", "zeros"):
+        wimg, m = disp_warp(img, disp, padding_mode=pm)
+        out[f"warped_{pm}"] = npy(wimg)
+        out[f"mask_{pm}"] = npy(m)
+    save("g6_disp_warp", **out)
+
+
+# ------------------------------------------------------------------ G7
+def g7_upsample():
+    from models.utils.upsample import upsample_convex8, upsample_simple8
+    from models.IterativeLocalCostVolume.utils.utils import upflow8
+
+    torch.manual_seed(701)
+    disp = torch.rand(2, 1, 5, 7) * 20
+    mask8 = torch.randn(2, 576, 5, 7)
+    out = {"disp": npy(disp), "mask8": npy(mask8)}
+    out["up8"] = npy(upsample_convex8(disp, mask8))
+    out["simple8"] = npy(upsample_simple8(disp))
+    out["upflow8"] = npy(upflow8(torch.cat([disp, -disp], 1)))
+
+    # RAFT upsample_flow (factor 4, two flow channels): raft_stereo.py:110-122,
+    # evaluated through the reference method bound to a stand-in `self`.
+    with contextlib.redirect_stdout(io.StringIO()):
+        sys.argv = ["x"]
+        import types
+        t = types.ModuleType("turtle"); t.left = t.right = None; sys.modules["turtle"] = t
+        try:
+            from models.IterativeLocalCostVolume.raft_stereo import RAFT_Stereo
+            ok = True
+        except Exception as e:  # pragma: no cover - environment dependent
+            print("RAFT_Stereo import failed:", e, file=sys.stderr)
+            ok = False
+    flow = torch.randn(2, 2, 5, 7)
+    mask4 = torch.randn(2, 144, 5, 7)
+    out["flow"], out["mask4"] = npy(flow), npy(mask4)
+    if ok:
+        holder = types.SimpleNamespace(downsample=2)
+        out["upflow4"] = npy(RAFT_Stereo.upsample_flow(holder, flow, mask4))
+    save("g7_upsample", **out)
+
+
+# ------------------------------------------------------------------ G8
+def g8_raft_update():
+    from models.IterativeLocalCostVolume.update.update import BasicMultiUpdateBlock_LZH
+
+    torch.manual_seed(801)
+    hd = [16, 16, 16]
+    blk = BasicMultiUpdateBlock_LZH(4, 4, 3, 2, hd).eval()
+    fill_state_dict_(blk, seed=0.25)
+    H, W = 16, 32
+    net = [torch.tanh(torch.randn(1, 16, H >> i, W >> i)) for i in range(3)]
+    inp = [[0.3 * torch.randn(1, 16, H >> i, W >> i) for _ in range(3)] for i in range(3)]
+    corr = torch.randn(1, 36, H, W)
+    flow = torch.cat([torch.randn(1, 1, H, W), torch.zeros(1, 1, H, W)], 1)
+    out = {"corr": npy(corr), "flow": npy(flow)}
+    for i in range(3):
+        out[f"net{i}_0"] = npy(net[i])
+        for j in range(3):
+            out[f"inp{i}{j}"] = npy(inp[i][j])
+    net_l = [n.clone() for n in net]
+    for it in range(2):
+        net_l, mask, delta = blk(net_l, inp, corr, flow, iter32=True, iter16=True)
+        for i in range(3):
+            out[f"net{i}_{it + 1}"] = npy(net_l[i])
+        out[f"mask_{it + 1}"] = npy(mask[:, ::7])
+        out[f"delta_{it + 1}"] = npy(delta)
+        flow = flow + delta
+    save("g8_raft_update", **out)
+
+
+# ------------------------------------------------------------------ cfg-1 check
+def check_oracle_cfg1():
+    """Not a fixture: proves the C oracle == the reference at BASELINE
+    configs[0] (1 pair 384x768 D=64: corr -> soft-argmin -> local lookup)."""
+    sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
+    import oracle
+    from models.utils.build_cost_volume import CostVolume
+    from models.utils.estimation import DisparityEstimation
+    from models.LocalCostVolume.Attempts.fixed_local_cost_volume import LocalCostVolume
+
+    torch.manual_seed(0)
+    L = torch.randn(1, 32, 384, 768)
+    R = torch.randn(1, 32, 384, 768)
+    vol = CostVolume(64, "correlation")(L, R)
+    disp = DisparityEstimation(64)(vol)
+    d2 = LocalCostVolume(2, 20)(vol, disp.unsqueeze(1), True)
+    ovol = oracle.corr_volume(npy(L), npy(R), 64)
+    odisp = oracle.soft_argmin(ovol)
+    od2 = oracle.local_lookup(ovol, odisp[:, None], 2.0, 20, True)
+    print("cfg-1 oracle vs reference: vol %.3g disp %.3g lookup %.3g" % (
+        np.abs(ovol - npy(vol)).max(), np.abs(odisp - npy(disp)).max(), np.abs(od2 - npy(d2)).max()))
+
+
+if __name__ == "__main__":
+    CHECK = "--check" in sys.argv
+    g1_volumes()
+    g2_soft_argmin()
+    g3_local_lookup()
+    g4_raft_corr()
+    g5_gru_updater()
+    g6_disp_warp()
+    g7_upsample()
+    g8_raft_update()
+    if CHECK:
+        check_oracle_cfg1()
