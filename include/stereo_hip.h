@@ -1,0 +1,161 @@
+/*
+ * stereo_hip.h -- C ABI of libstereo_hip.so: the MI355X (gfx950) stereo
+ * cost-volume + disparity-regression hot path.
+ *
+ * The reference (Magicboomliu/StereoFormer) has no FFI for this path: every
+ * function below replaces a plain PyTorch nn.Module.forward / function, cited
+ * as file:line relative to the reference root.  The binding a maintainer
+ * would add on the reference side is in INTEGRATION.md.
+ *
+ * Conventions
+ *   - all tensors fp32, contiguous NCHW, DEVICE pointers owned by the caller;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*;
+ *     NULL = the default stream); no internal sync, no global state, no
+ *     allocation: safe to capture into a hipGraph and re-entrant;
+ *   - return value: STEREO_OK or a negative STEREO_ERR_* code; on error no
+ *     kernel has been launched;
+ *   - zero-sized problems (any extent == 0) return STEREO_OK and launch nothing.
+ */
+#ifndef STEREO_HIP_H
+#define STEREO_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STEREO_OK 0
+#define STEREO_ERR_NULL_POINTER (-1)
+#define STEREO_ERR_BAD_SHAPE (-2)   /* negative extent, C % G != 0, D > limit ... */
+#define STEREO_ERR_UNSUPPORTED (-3) /* size outside what the kernels index safely */
+#define STEREO_ERR_LAUNCH (-4)      /* hipGetLastError() after the launch */
+
+#define STEREO_MASK_ZERO 0   /* out-of-image band logits are 0.0 (A1+A4 semantics) */
+#define STEREO_MASK_NEGINF 1 /* out-of-image band entries are excluded */
+#define STEREO_SCALE_SQRT_C 0 /* 1/sqrt(C): corr.py:111 */
+#define STEREO_SCALE_MEAN 1   /* 1/C: build_cost_volume.py:44-45 */
+
+#define STEREO_MAX_LEVELS 8
+
+int stereo_abi_version(void);
+const char *stereo_strerror(int code);
+
+/* A1  CostVolume.forward 'correlation'  models/utils/build_cost_volume.py:39-47
+ *     left,right [B,C,H,W] -> vol [B,D,H,W];  vol[b,d,h,w] = mean_c L*R(w-d), 0 for w<d */
+int stereo_corr_volume_f32(const float *left, const float *right, float *vol,
+                           int B, int C, int H, int W, int D, void *stream);
+
+/* A2  'difference' (:21-28) -> [B,C,D,H,W];  'concat' (:30-37) -> [B,2C,D,H,W] */
+int stereo_diff_volume_f32(const float *left, const float *right, float *vol,
+                           int B, int C, int H, int W, int D, void *stream);
+int stereo_concat_volume_f32(const float *left, const float *right, float *vol,
+                             int B, int C, int H, int W, int D, void *stream);
+
+/* A3  build_gwc_volume  models/CrossAttentionCostVolume/GWC_Cost_Volume.py:14-24
+ *     -> vol [B,G,D,H,W]; STEREO_ERR_BAD_SHAPE when C % G != 0 (the reference asserts, :7) */
+int stereo_gwc_volume_f32(const float *left, const float *right, float *vol,
+                          int B, int C, int H, int W, int D, int G, void *stream);
+
+/* A4  DisparityEstimation(.WithProb).forward  models/utils/estimation.py:14-33,44-62
+ *     vol [B,D,H,W] -> disp [B,H,W] (+ prob [B,D,H,W] when prob != NULL) */
+int stereo_soft_argmin_f32(const float *vol, float *disp, float *prob,
+                           int B, int D, int H, int W, int match_similarity, void *stream);
+
+/* disparity_regression  models/utils/submodule.py:23-27:  x [B,D,H,W] -> out[b,h,w] = sum_d x*d */
+int stereo_disparity_regression_f32(const float *x, float *out, int B, int D, int H, int W, void *stream);
+
+/* cfg-2 chain reader: volg [B,G,D,H,W] -> group mean (torch .mean(1)) -> A4.
+ * vol_mean [B,D,H,W] is written when non-NULL. */
+int stereo_group_mean_soft_argmin_f32(const float *volg, float *vol_mean, float *disp,
+                                      int B, int G, int D, int H, int W,
+                                      int match_similarity, void *stream);
+
+/* A1+A4 fused, no volume materialised: disp = soft_argmin(corr_volume(L,R,D)) */
+int stereo_corr_soft_argmin_f32(const float *left, const float *right, float *disp,
+                                int B, int C, int H, int W, int D, int match_similarity,
+                                void *stream);
+
+/* A5  build_cost_volume_from_volume  .../Attempts/fixed_local_cost_volume.py:61-80
+ *     vol [B,D,H,W], cand [B,K,H,W] -> out [B,K,H,W] */
+int stereo_sample_volume_f32(const float *vol, const float *cand, float *out,
+                             int B, int D, int H, int W, int K, void *stream);
+
+/* A5  LocalCostVolume.forward  fixed_local_cost_volume.py:18-58
+ *     vol [B,D,H,W], disp [B,1,H,W] -> out [B,1,H,W]; S = sample_points (S+1 candidates) */
+int stereo_local_lookup_f32(const float *vol, const float *disp, float *out,
+                            int B, int D, int H, int W, float radius, int S,
+                            int consider_valid, void *stream);
+
+/* A6  Variance_Based_Local_Cost_Volume.forward  .../Attempts/variance_local_cost_volume.py:34-78 */
+int stereo_variance_lookup_f32(const float *vol, const float *disp, float *out,
+                               int B, int D, int H, int W, float gamma, int S,
+                               int consider_valid, void *stream);
+
+/* A11 sampler with learned offsets  .../Attempts/update.py:279-313
+ *     bounds [B,2,H,W] (channel 0 = lower offset, 1 = upper offset; torch.chunk order) */
+int stereo_bounds_lookup_f32(const float *vol, const float *disp, const float *bounds, float *out,
+                             int B, int D, int H, int W, int S, int consider_valid, void *stream);
+
+/* A11 uncertainty volume  .../Attempts/update.py:71-72,86:  softmax_d(vol)*d*(d-disp)^2 */
+int stereo_uncertainty_volume_f32(const float *vol, const float *disp, float *out,
+                                  int B, int D, int H, int W, void *stream);
+
+/* A8  CorrBlock1D.__init__ + .corr  models/IterativeLocalCostVolume/corr/corr.py:55-76,103-111
+ *     fmap1 [B,C,H,W1], fmap2 [B,C,H,W2] -> levels[i] [B*H*W1, W2>>i], i = 0..num_levels
+ *     (levels = HOST array of num_levels+1 device pointers; the reference builds
+ *     num_levels+1 pyramid entries) */
+int stereo_allpairs_pyramid_f32(const float *fmap1, const float *fmap2, float *const *levels,
+                                int B, int C, int H, int W1, int W2, int num_levels, void *stream);
+
+/* A9  CorrBlock1D.__call__ + bilinear_sampler  corr.py:78-101, .../utils/utils.py:59-76
+ *     coords [B,2,H,W1] (x = channel 0) -> out [B, num_levels*(2r+1), H, W1] */
+int stereo_corr_lookup_f32(const float *const *levels, const float *coords, float *out,
+                           int B, int H, int W1, int W2, int num_levels, int radius, void *stream);
+
+/* A10 PytorchAlternateCorrBlock1D.__call__  corr.py:8-51 (no all-pairs volume).
+ *     workspace: (B*C*H*(W/2 + W/4 + ...)) floats for the pooled fmap2 copies */
+int stereo_alt_corr_lookup_f32(const float *fmap1, const float *fmap2, const float *coords,
+                               float *out, float *workspace,
+                               int B, int C, int H, int W, int num_levels, int radius, void *stream);
+long long stereo_alt_corr_workspace_floats(int B, int C, int H, int W, int num_levels);
+
+/* bilinear_sampler(img, coords, mask)  .../utils/utils.py:59-76 (general 2-D form)
+ *     img [N,C,H,W], coords [N,Ho,Wo,2] pixel units -> out [N,C,Ho,Wo], mask [N,Ho,Wo,1] or NULL */
+int stereo_bilinear_sampler_f32(const float *img, const float *coords, float *out, float *mask,
+                                int N, int C, int H, int W, int Ho, int Wo, void *stream);
+
+/* A12 disp_warp  utils/disparity_warper.py:83-106;  img [B,Ci,H,W], disp [B,1,H,W]
+ *     -> warped [B,Ci,H,W], mask [B,Ci,H,W] (or NULL); padding_border: 1 'border', 0 'zeros' */
+int stereo_disp_warp_f32(const float *img, const float *disp, float *warped, float *mask,
+                         int B, int Ci, int H, int W, int padding_border, void *stream);
+
+/* A13 upsample_convex8  models/utils/upsample.py:22-38 (f=8) and RAFT_Stereo.upsample_flow
+ *     models/IterativeLocalCostVolume/raft_stereo.py:110-122 (f = 2^downsample)
+ *     disp [N,Cd,H,W], mask [N,9*f*f,H,W] -> out [N,Cd,f*H,f*W] */
+int stereo_upsample_convex_f32(const float *disp, const float *mask, float *out,
+                               int N, int Cd, int H, int W, int f, void *stream);
+
+/* F.interpolate(bilinear) to (Ho,Wo): upsample_simple8 / upflow8 / interp / the 1/8 image
+ * resize (upsample.py:41-43, utils.py:85-87, update/update.py:125-127, Attempts/update.py:73-77);
+ * out = scale * interp(in) */
+int stereo_resize_bilinear_f32(const float *in, float *out, int NC, int Hi, int Wi, int Ho, int Wo,
+                               int align_corners, float scale, void *stream);
+
+/* A7  epipolar cross-attention (build-defined; reference file is empty:
+ *     models/CrossAttentionCostVolume/cross_attention_cost_volume.py)
+ *     left,right [B,C,H,W], value [B,Cv,H,W] -> out [B,Cv,H,W] (or NULL), disp [B,H,W] (or NULL) */
+int stereo_cross_attention_f32(const float *left, const float *right, const float *value,
+                               float *out, float *disp, int B, int C, int Cv, int H, int W, int D,
+                               int mask_mode, int scale_mode, void *stream);
+
+/* A11/A14 ConvGRU gate math around the (host-framework) convolutions
+ *     Attempts/update.py:41-48, update/update.py:28-32; bias pointers may be NULL
+ *     reset: out = sigmoid(rc + cr) * h;  blend: out = (1-z)*h + z*tanh(qc+cq), z = sigmoid(zc+cz) */
+int stereo_gru_reset_f32(const float *h, const float *rc, const float *cr, float *out,
+                         long long n, void *stream);
+int stereo_gru_blend_f32(const float *h, const float *zc, const float *qc, const float *cz,
+                         const float *cq, float *out, long long n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STEREO_HIP_H */

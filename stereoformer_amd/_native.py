@@ -1,0 +1,121 @@
+"""ctypes binding of libstereo_hip.so (include/stereo_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream;
+every op is a direct C-ABI call with raw device pointers.  There is NO CPU or
+eager fallback: if the library is missing or a tensor is not on the GPU the
+call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstereo_hip.so")
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_ll = ctypes.c_longlong
+
+# name -> argtypes (return type is int unless listed in _RESTYPE)
+SIGNATURES = {
+    "stereo_abi_version": [],
+    "stereo_strerror": [_i],
+    "stereo_corr_volume_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "stereo_diff_volume_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "stereo_concat_volume_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "stereo_gwc_volume_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_soft_argmin_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "stereo_disparity_regression_f32": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "stereo_group_mean_soft_argmin_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_corr_soft_argmin_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_sample_volume_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "stereo_local_lookup_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "stereo_variance_lookup_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "stereo_bounds_lookup_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_uncertainty_volume_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "stereo_allpairs_pyramid_f32": [_vp, _vp, ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_corr_lookup_f32": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_alt_corr_lookup_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_alt_corr_workspace_floats": [_i, _i, _i, _i, _i],
+    "stereo_bilinear_sampler_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_disp_warp_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "stereo_upsample_convex_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "stereo_resize_bilinear_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "stereo_cross_attention_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_gru_reset_f32": [_vp, _vp, _vp, _vp, _ll, _vp],
+    "stereo_gru_blend_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp],
+}
+_RESTYPE = {"stereo_strerror": ctypes.c_char_p, "stereo_alt_corr_workspace_floats": _ll}
+
+_lib = None
+
+
+class StereoHipError(RuntimeError):
+    """Raised when a libstereo_hip.so entry point returns a STEREO_ERR_* code."""
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the in-tree library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). stereoformer_amd has no CPU/eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    missing = [name for name in SIGNATURES if not hasattr(lib, name)]
+    if missing:  # header/library mismatch: fail loudly, never degrade
+        raise RuntimeError(f"{LIB_PATH} lacks symbols {missing}; rebuild it (stereoformer_amd/build.py)")
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, _i)
+    _lib = lib
+    return lib
+
+
+def check(rc: int, name: str) -> None:
+    if rc != 0:
+        msg = load().stereo_strerror(rc).decode()
+        raise StereoHipError(f"{name} failed: {msg} (code {rc})")
+
+
+def call(name: str, *args) -> None:
+    check(getattr(load(), name)(*args), name)
+
+
+def stream_ptr(device: torch.device | None = None) -> ctypes.c_void_p:
+    return _vp(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t: torch.Tensor | None) -> ctypes.c_void_p:
+    return _vp(0) if t is None else _vp(t.data_ptr())
+
+
+def dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    """Validate an op input: HIP device, fp32; returns it contiguous."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name}: tensor is on {t.device}; stereoformer_amd runs only on an MI355X HIP device "
+            "(no CPU fallback - the CPU restatement lives in oracle/ and is test-only)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype} (the path computes in f32)")
+    if torch.is_grad_enabled() and t.requires_grad:
+        raise RuntimeError(
+            f"{name}: the HIP path is forward-only this round (SURVEY 8(f) N3); call under torch.no_grad()")
+    return t.contiguous()
+
+
+def same_device(*ts: torch.Tensor) -> torch.device:
+    dev = ts[0].device
+    for t in ts[1:]:
+        if t is not None and t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev

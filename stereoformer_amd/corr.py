@@ -1,0 +1,152 @@
+"""RAFT-style epipolar correlation (A8/A9/A10) behind the reference's surfaces:
+``models/IterativeLocalCostVolume/corr/corr.py`` and
+``models/IterativeLocalCostVolume/utils/utils.py``."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import _native as N
+
+
+def _level_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+class CorrBlock1D:
+    """``CorrBlock1D(fmap1, fmap2, num_levels=4, radius=4)`` (corr.py:54-111).
+
+    ``corr_pyramid`` holds num_levels+1 tensors [B*H*W1,1,1,W2>>i] like the
+    reference (:66-76); ``__call__(coords)`` returns [B, num_levels*(2r+1), H, W1]."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        self.num_levels = num_levels
+        self.radius = radius
+        fmap1 = N.dev_f32(fmap1, "CorrBlock1D: fmap1")
+        fmap2 = N.dev_f32(fmap2, "CorrBlock1D: fmap2")
+        B, C, H, W1 = fmap1.shape
+        W2 = fmap2.shape[3]
+        if fmap2.shape[:3] != fmap1.shape[:3]:
+            raise ValueError("CorrBlock1D: fmap1/fmap2 must share B, C, H")
+        N.same_device(fmap1, fmap2)
+        self._shape = (B, H, W1, W2)
+        rows = B * H * W1
+        widths = [W2 >> i for i in range(num_levels + 1)]
+        self.corr_pyramid = [torch.empty((rows, 1, 1, w), device=fmap1.device, dtype=torch.float32) for w in widths]
+        with torch.cuda.device(fmap1.device):
+            N.call("stereo_allpairs_pyramid_f32", N.ptr(fmap1), N.ptr(fmap2), _level_array(self.corr_pyramid),
+                   B, C, H, W1, W2, num_levels, N.stream_ptr(fmap1.device))
+
+    def __call__(self, coords):
+        coords = N.dev_f32(coords, "CorrBlock1D: coords")
+        B, H, W1, W2 = self._shape
+        if coords.dim() != 4 or coords.shape[0] != B or coords.shape[1] < 1 or tuple(coords.shape[2:]) != (H, W1):
+            raise ValueError(f"CorrBlock1D: coords must be [B,2,H,W1] = [{B},2,{H},{W1}]")
+        if coords.shape[1] != 2:  # the reference only reads channel 0 (corr.py:80)
+            coords = torch.cat([coords[:, :1], torch.zeros_like(coords[:, :1])], 1).contiguous()
+        T = 2 * self.radius + 1
+        out = torch.empty((B, self.num_levels * T, H, W1), device=coords.device, dtype=torch.float32)
+        with torch.cuda.device(coords.device):
+            N.call("stereo_corr_lookup_f32", _level_array(self.corr_pyramid[:self.num_levels]), N.ptr(coords),
+                   N.ptr(out), B, H, W1, W2, self.num_levels, self.radius, N.stream_ptr(coords.device))
+        return out
+
+    @staticmethod
+    def corr(fmap1, fmap2):
+        """All-pairs ``einsum('aijk,aijh->ajkh')/sqrt(C)`` -> [B,H,W1,1,W2] (corr.py:103-111)."""
+        fmap1 = N.dev_f32(fmap1, "CorrBlock1D.corr: fmap1")
+        fmap2 = N.dev_f32(fmap2, "CorrBlock1D.corr: fmap2")
+        B, C, H, W1 = fmap1.shape
+        W2 = fmap2.shape[3]
+        out = torch.empty((B, H, W1, 1, W2), device=fmap1.device, dtype=torch.float32)
+        with torch.cuda.device(fmap1.device):
+            N.call("stereo_allpairs_pyramid_f32", N.ptr(fmap1), N.ptr(fmap2), _level_array([out]), B, C, H, W1, W2, 0,
+                   N.stream_ptr(fmap1.device))
+        return out
+
+
+class PytorchAlternateCorrBlock1D:
+    """``PytorchAlternateCorrBlock1D`` (corr.py:8-51): the memory-saving variant that never
+    builds the all-pairs volume."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        self.num_levels = num_levels
+        self.radius = radius
+        self.corr_pyramid = []
+        self.fmap1 = N.dev_f32(fmap1, "PytorchAlternateCorrBlock1D: fmap1")
+        self.fmap2 = N.dev_f32(fmap2, "PytorchAlternateCorrBlock1D: fmap2")
+        if self.fmap1.shape != self.fmap2.shape:
+            raise ValueError("PytorchAlternateCorrBlock1D: fmap shapes differ")
+
+    def __call__(self, coords):
+        coords = N.dev_f32(coords, "PytorchAlternateCorrBlock1D: coords")
+        B, C, H, W = self.fmap1.shape
+        if tuple(coords.shape) != (B, 2, H, W):
+            raise ValueError("PytorchAlternateCorrBlock1D: coords must be [B,2,H,W]")
+        T = 2 * self.radius + 1
+        out = torch.empty((B, self.num_levels * T, H, W), device=coords.device, dtype=torch.float32)
+        nws = int(N.load().stereo_alt_corr_workspace_floats(B, C, H, W, self.num_levels))
+        ws = torch.empty((max(nws, 1),), device=coords.device, dtype=torch.float32)
+        with torch.cuda.device(coords.device):
+            N.call("stereo_alt_corr_lookup_f32", N.ptr(self.fmap1), N.ptr(self.fmap2), N.ptr(coords), N.ptr(out),
+                   N.ptr(ws), B, C, H, W, self.num_levels, self.radius, N.stream_ptr(coords.device))
+        return out
+
+
+class AlternateCorrBlock:
+    """The reference's CUDA-extension variant is a stub that raises (corr.py:114-116)."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        raise NotImplementedError
+
+
+def bilinear_sampler(img, coords, mode="bilinear", mask=False):
+    """``bilinear_sampler`` (utils/utils.py:59-76): pixel coordinates, align_corners=True, zeros
+    padding.  img [N,C,H,W], coords [N,Ho,Wo,2]."""
+    if mode != "bilinear":
+        raise NotImplementedError("bilinear_sampler: only mode='bilinear' (the reference passes it to grid_sample)")
+    img = N.dev_f32(img, "bilinear_sampler: img")
+    coords = N.dev_f32(coords, "bilinear_sampler: coords")
+    n, c, h, w = img.shape
+    if coords.dim() != 4 or coords.shape[0] != n or coords.shape[-1] != 2:
+        raise ValueError("bilinear_sampler: coords must be [N,Ho,Wo,2]")
+    ho, wo = coords.shape[1:3]
+    out = torch.empty((n, c, ho, wo), device=img.device, dtype=torch.float32)
+    m = torch.empty((n, ho, wo, 1), device=img.device, dtype=torch.float32) if mask else None
+    with torch.cuda.device(img.device):
+        N.call("stereo_bilinear_sampler_f32", N.ptr(img), N.ptr(coords), N.ptr(out), N.ptr(m), n, c, h, w, ho, wo,
+               N.stream_ptr(img.device))
+    return (out, m) if mask else out
+
+
+def coords_grid(batch, ht, wd, device=None):
+    """``coords_grid`` (utils/utils.py:79-82): [B,2,H,W], channel 0 = x, channel 1 = y."""
+    ys, xs = torch.meshgrid(torch.arange(ht, device=device), torch.arange(wd, device=device), indexing="ij")
+    coords = torch.stack([xs, ys], dim=0).float()
+    return coords[None].repeat(batch, 1, 1, 1)
+
+
+class InputPadder:
+    """``InputPadder`` (utils/utils.py:7-26): replicate-pads to a multiple of ``divis_by``."""
+
+    def __init__(self, dims, mode="sintel", divis_by=8):
+        self.ht, self.wd = dims[-2:]
+        pad_ht = (((self.ht // divis_by) + 1) * divis_by - self.ht) % divis_by
+        pad_wd = (((self.wd // divis_by) + 1) * divis_by - self.wd) % divis_by
+        if mode == "sintel":
+            self._pad = [pad_wd // 2, pad_wd - pad_wd // 2, pad_ht // 2, pad_ht - pad_ht // 2]
+        else:
+            self._pad = [pad_wd // 2, pad_wd - pad_wd // 2, 0, pad_ht]
+
+    def pad(self, *inputs):
+        assert all((x.ndim == 4) for x in inputs)
+        return [F.pad(x, self._pad, mode="replicate") for x in inputs]
+
+    def unpad(self, x):
+        assert x.ndim == 4
+        ht, wd = x.shape[-2:]
+        c = [self._pad[2], ht - self._pad[3], self._pad[0], wd - self._pad[1]]
+        return x[..., c[0]:c[1], c[2]:c[3]]

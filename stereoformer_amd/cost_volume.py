@@ -1,0 +1,97 @@
+"""Cost-volume builders behind the reference's module surfaces (A1/A2/A3).
+
+Mirrors ``models/utils/build_cost_volume.py:5-54`` (twin ``models/utils/cost.py``),
+``models/CrossAttentionCostVolume/GWC_Cost_Volume.py:5-24`` and
+``models/utils/submodule.py:30-41`` -- same names, arguments, output layouts
+and error behaviour -- with the body replaced by one HIP launch.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _native as N
+
+
+def _pair(left, right, who):
+    left = N.dev_f32(left, f"{who}: left_feature")
+    right = N.dev_f32(right, f"{who}: right_feature")
+    if left.dim() != 4 or left.shape != right.shape:
+        raise ValueError(f"{who}: expected two [B,C,H,W] tensors of one shape, got {tuple(left.shape)} "
+                         f"and {tuple(right.shape)}")
+    N.same_device(left, right)
+    return left, right
+
+
+class CostVolume(nn.Module):
+    """``CostVolume(max_disp, feature_similarity)`` (build_cost_volume.py:5-54).
+
+    'correlation' -> [B,D,H,W]; 'difference' -> [B,C,D,H,W]; 'concat' ->
+    [B,2C,D,H,W]; anything else raises NotImplementedError (:49-50)."""
+
+    def __init__(self, max_disp, feature_similarity="correlation"):
+        super().__init__()
+        self.max_disp = max_disp
+        self.feature_similarity = feature_similarity
+
+    def forward(self, left_feature, right_feature):
+        if self.feature_similarity not in ("difference", "concat", "correlation"):
+            raise NotImplementedError
+        L, R = _pair(left_feature, right_feature, "CostVolume")
+        b, c, h, w = L.shape
+        D = int(self.max_disp)
+        st = N.stream_ptr(L.device)
+        with torch.cuda.device(L.device):
+            if self.feature_similarity == "correlation":
+                vol = torch.empty((b, D, h, w), device=L.device, dtype=torch.float32)
+                N.call("stereo_corr_volume_f32", N.ptr(L), N.ptr(R), N.ptr(vol), b, c, h, w, D, st)
+            elif self.feature_similarity == "difference":
+                vol = torch.empty((b, c, D, h, w), device=L.device, dtype=torch.float32)
+                N.call("stereo_diff_volume_f32", N.ptr(L), N.ptr(R), N.ptr(vol), b, c, h, w, D, st)
+            else:
+                vol = torch.empty((b, 2 * c, D, h, w), device=L.device, dtype=torch.float32)
+                N.call("stereo_concat_volume_f32", N.ptr(L), N.ptr(R), N.ptr(vol), b, c, h, w, D, st)
+        return vol
+
+
+class CostVolumePyramid(nn.Module):
+    """``CostVolumePyramid`` (models/utils/cost.py:56-72): scale s uses max_disp // 2**s."""
+
+    def __init__(self, max_disp, feature_similarity="correlation"):
+        super().__init__()
+        self.max_disp = max_disp
+        self.feature_similarity = feature_similarity
+
+    def forward(self, left_feature_pyramid, right_feature_pyramid):
+        out = []
+        for s in range(len(left_feature_pyramid)):
+            cv = CostVolume(self.max_disp // (2 ** s), self.feature_similarity)
+            out.append(cv(left_feature_pyramid[s], right_feature_pyramid[s]))
+        return out
+
+
+def build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups):
+    """``build_gwc_volume`` (GWC_Cost_Volume.py:14-24) -> [B,G,D,H,W]."""
+    L, R = _pair(refimg_fea, targetimg_fea, "build_gwc_volume")
+    B, C, H, W = L.shape
+    assert C % num_groups == 0  # GWC_Cost_Volume.py:7
+    vol = torch.empty((B, num_groups, maxdisp, H, W), device=L.device, dtype=torch.float32)
+    with torch.cuda.device(L.device):
+        N.call("stereo_gwc_volume_f32", N.ptr(L), N.ptr(R), N.ptr(vol), B, C, H, W, int(maxdisp), int(num_groups),
+               N.stream_ptr(L.device))
+    return vol
+
+
+def groupwise_correlation(fea1, fea2, num_groups):
+    """``groupwise_correlation`` (GWC_Cost_Volume.py:5-11) -> [B,G,H,W] (= the D=1 slice)."""
+    L, R = _pair(fea1, fea2, "groupwise_correlation")
+    B, C, H, W = L.shape
+    assert C % num_groups == 0
+    cost = build_gwc_volume(L, R, 1, num_groups).view(B, num_groups, H, W)
+    assert cost.shape == (B, num_groups, H, W)
+    return cost
+
+
+def build_concat_volume(refimg_fea, targetimg_fea, maxdisp):
+    """``build_concat_volume`` (models/utils/submodule.py:30-41) == CostVolume(maxdisp,'concat')."""
+    return CostVolume(maxdisp, "concat")(refimg_fea, targetimg_fea)

@@ -1,0 +1,52 @@
+// Shared helpers for the gfx950 kernels behind include/stereo_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/stereo_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define STEREO_REQUIRE_PTR(p) \
+    do {                      \
+        if ((p) == nullptr) return STEREO_ERR_NULL_POINTER; \
+    } while (0)
+
+#define STEREO_LAUNCH_CHECK()                                        \
+    do {                                                             \
+        if (hipGetLastError() != hipSuccess) return STEREO_ERR_LAUNCH; \
+    } while (0)
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// grid.y / grid.z are limited to 65535
+static inline bool fits_grid_yz(long long v) { return v >= 1 && v <= 65535; }
+
+__device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+
+// v_exp_f32 based exp: |rel err| ~1e-6 on the softmax range; far inside the 1e-3 disparity bar
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
+// ste_ceil / ste_floor forward values (fixed_local_cost_volume.py:5-9):
+// ceil(x) - x + x evaluated left to right in fp32 (no contraction: these are
+// plain adds, and the library is built without fast-math).
+__device__ __forceinline__ float ste_ceil_f(float x) { return (ceilf(x) - x) + x; }
+__device__ __forceinline__ float ste_floor_f(float x) { return (floorf(x) - x) + x; }
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// One interpolated tap of build_cost_volume_from_volume
+// (fixed_local_cost_volume.py:61-80).  v -> vol[b,0,h,w], stride = H*W.
+__device__ __forceinline__ float sample_tap(const float *__restrict__ v, size_t stride, int D, float c)
+{
+    const float cc = clampf(ste_ceil_f(c), 0.0f, (float)(D - 1));
+    const float cf = clampf(ste_floor_f(c), 0.0f, (float)(D - 1));
+    const int ic = (int)cc, ifl = (int)cf;  // .long() truncates toward zero
+    const float floor_rate = (float)ic - c;
+    const float ceil_rate = 1.0f - floor_rate;
+    return v[(size_t)ifl * stride] * floor_rate + v[(size_t)ic * stride] * ceil_rate;
+}

@@ -1,0 +1,211 @@
+// Local cost-volume re-sampling (A5 fixed radius, A6 variance based, A11
+// learned bounds), the raw sampler, and the A11 uncertainty volume.
+//
+// One lane = one pixel (consecutive lanes = consecutive w, so every volume tap
+// of a wave touches at most a few 128-B lines per D plane).  The S+1
+// candidates are produced, tapped (two clamped planes + lerp) and folded into
+// an online softmax-expectation in registers; nothing but the final disparity
+// is written.
+#include "common.h"
+
+namespace {
+
+struct Softmax1 {
+    float m, s;
+    __device__ __forceinline__ void init() { m = -INFINITY, s = 0.0f; }
+    __device__ __forceinline__ float push(float x)  // returns the rescale applied to earlier terms
+    {
+        const float cm = fmaxf(m, x);
+        const float sc = (m == cm) ? 1.0f : fast_exp(m - cm);
+        s = s * sc + fast_exp(x - cm);
+        m = cm;
+        return sc;
+    }
+};
+
+// candidates -> taps -> softmax -> expectation
+// (fixed_local_cost_volume.py:33-56 == variance_local_cost_volume.py:56-72 == Attempts/update.py:297-313)
+// invalid: -1 = consider_valid off, 0/1 = the pixel's invalid mask
+__device__ __forceinline__ float lookup_pixel(const float *__restrict__ v, size_t HW, int D, float cur, float lower,
+                                              float upper, int S, int invalid)
+{
+    const float interval = __fdiv_rn(__fmul_rn(__fsub_rn(upper, lower), 1.0f), (float)S);
+    const float inv = invalid > 0 ? 1.0f : 0.0f;
+    float m = -INFINITY, s = 0.0f, e = 0.0f;
+    for (int k = 0; k <= S; ++k) {
+        float c = __fadd_rn(lower, __fmul_rn((float)k, interval));
+        if (invalid >= 0) c = __fadd_rn(__fmul_rn(c, 1.0f - inv), __fmul_rn(inv, cur));  // update.py:304
+        const float val = sample_tap(v, HW, D, c);
+        const float cm = fmaxf(m, val);
+        const float sc = (m == cm) ? 1.0f : fast_exp(m - cm);
+        const float p = fast_exp(val - cm);
+        s = s * sc + p;
+        e = e * sc + p * c;
+        m = cm;
+    }
+    return e / s;
+}
+
+enum { MODE_FIXED = 0, MODE_VARIANCE = 1, MODE_BOUNDS = 2 };
+
+template <int MODE>
+__global__ __launch_bounds__(256) void lookup_kernel(const float *__restrict__ vol, const float *__restrict__ disp,
+                                                     const float *__restrict__ bounds, float *__restrict__ out, int D,
+                                                     int W, long long HW, long long npix, float param, int S,
+                                                     int consider_valid)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npix;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long b = t / HW, p = t - b * HW;
+        const float *v = vol + (size_t)b * D * HW + p;
+        const float cur = disp[t];
+        float lower, upper;
+        int invalid = -1;
+        if (MODE == MODE_FIXED) {
+            lower = cur - param;
+            upper = cur + param;
+        } else if (MODE == MODE_BOUNDS) {
+            lower = cur - bounds[(size_t)b * 2 * HW + p];
+            upper = cur + bounds[(size_t)b * 2 * HW + HW + p];
+        } else {
+            // GetVarince (variance_local_cost_volume.py:12-25): sigma of softmax(vol) around cur
+            float m = -INFINITY, s = 0.0f, var = 0.0f;
+            for (int d = 0; d < D; ++d) {
+                const float x = v[(size_t)d * HW];
+                const float cm = fmaxf(m, x);
+                const float sc = (m == cm) ? 1.0f : fast_exp(m - cm);
+                const float pe = fast_exp(x - cm);
+                const float err = (float)d - cur;
+                s = s * sc + pe;
+                var = var * sc + pe * (err * err);
+                m = cm;
+            }
+            const float sigma = sqrtf(var / s);
+            lower = cur - param * sigma;
+            upper = cur + param * sigma;
+        }
+        if (consider_valid) {
+            invalid = (lower < 0.0f) || (upper >= (float)(D - 1));
+            if (MODE == MODE_VARIANCE) invalid = invalid || (upper > (float)(p % W));  // :44,48
+        } else if (MODE == MODE_VARIANCE) {
+            lower = clampf(lower, 0.0f, (float)(D - 1));  // :52-53
+            upper = clampf(upper, 0.0f, (float)(D - 1));
+        } else {
+            lower = lower < 0.0f ? 0.0f : lower;       // fixed_local_cost_volume.py:29
+            upper = clampf(upper, 0.0f, (float)D);     // :30 (max = D)
+        }
+        out[t] = lookup_pixel(v, (size_t)HW, D, cur, lower, upper, S, invalid);
+    }
+}
+
+__global__ __launch_bounds__(256) void sample_volume_kernel(const float *__restrict__ vol,
+                                                            const float *__restrict__ cand, float *__restrict__ out,
+                                                            int D, int K, long long HW, long long n)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long p = t % HW, b = t / (HW * K);
+        out[t] = sample_tap(vol + (size_t)b * D * HW + p, (size_t)HW, D, cand[t]);
+    }
+}
+
+// U[b,d,p] = softmax_d(vol)[d] * d * (d - disp)^2   (Attempts/update.py:71-72,86)
+__global__ __launch_bounds__(256) void uncertainty_kernel(const float *__restrict__ vol,
+                                                          const float *__restrict__ disp, float *__restrict__ out,
+                                                          int D, long long HW, long long npix)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npix;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long b = t / HW, p = t - b * HW;
+        const float *v = vol + (size_t)b * D * HW + p;
+        float *o = out + (size_t)b * D * HW + p;
+        const float cur = disp[t];
+        Softmax1 sm;
+        sm.init();
+        for (int d = 0; d < D; ++d) sm.push(v[(size_t)d * HW]);
+        const float inv = 1.0f / sm.s;
+        for (int d = 0; d < D; ++d) {
+            const float pd = fast_exp(v[(size_t)d * HW] - sm.m) * inv;
+            const float e = (float)d - cur;
+            o[(size_t)d * HW] = pd * (float)d * e * e;
+        }
+    }
+}
+
+inline unsigned grid_for(long long nthreads)
+{
+    long long blocks = (nthreads + 255) / 256;
+    const long long cap = 256LL * 32;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+template <int MODE>
+int lookup_dispatch(const float *vol, const float *disp, const float *bounds, float *out, int B, int D, int H, int W,
+                    float param, int S, int consider_valid, void *stream)
+{
+    STEREO_REQUIRE_PTR(vol);
+    STEREO_REQUIRE_PTR(disp);
+    STEREO_REQUIRE_PTR(out);
+    if (MODE == MODE_BOUNDS) STEREO_REQUIRE_PTR(bounds);
+    if (B < 0 || D < 0 || H < 0 || W < 0 || S <= 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0) return STEREO_OK;
+    if (D == 0) return STEREO_ERR_BAD_SHAPE;
+    const long long HW = (long long)H * W, n = (long long)B * HW;
+    hipLaunchKernelGGL(lookup_kernel<MODE>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), vol, disp, bounds, out,
+                       D, W, HW, n, param, S, consider_valid);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+}  // namespace
+
+extern "C" int stereo_local_lookup_f32(const float *vol, const float *disp, float *out, int B, int D, int H, int W,
+                                       float radius, int S, int consider_valid, void *stream)
+{
+    return lookup_dispatch<MODE_FIXED>(vol, disp, nullptr, out, B, D, H, W, radius, S, consider_valid, stream);
+}
+
+extern "C" int stereo_variance_lookup_f32(const float *vol, const float *disp, float *out, int B, int D, int H, int W,
+                                          float gamma, int S, int consider_valid, void *stream)
+{
+    return lookup_dispatch<MODE_VARIANCE>(vol, disp, nullptr, out, B, D, H, W, gamma, S, consider_valid, stream);
+}
+
+extern "C" int stereo_bounds_lookup_f32(const float *vol, const float *disp, const float *bounds, float *out, int B,
+                                        int D, int H, int W, int S, int consider_valid, void *stream)
+{
+    return lookup_dispatch<MODE_BOUNDS>(vol, disp, bounds, out, B, D, H, W, 0.0f, S, consider_valid, stream);
+}
+
+extern "C" int stereo_sample_volume_f32(const float *vol, const float *cand, float *out, int B, int D, int H, int W,
+                                        int K, void *stream)
+{
+    STEREO_REQUIRE_PTR(vol);
+    STEREO_REQUIRE_PTR(cand);
+    STEREO_REQUIRE_PTR(out);
+    if (B < 0 || D < 0 || H < 0 || W < 0 || K < 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0 || K == 0) return STEREO_OK;
+    if (D == 0) return STEREO_ERR_BAD_SHAPE;
+    const long long HW = (long long)H * W, n = (long long)B * K * HW;
+    hipLaunchKernelGGL(sample_volume_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), vol, cand, out, D, K,
+                       HW, n);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+extern "C" int stereo_uncertainty_volume_f32(const float *vol, const float *disp, float *out, int B, int D, int H,
+                                             int W, void *stream)
+{
+    STEREO_REQUIRE_PTR(vol);
+    STEREO_REQUIRE_PTR(disp);
+    STEREO_REQUIRE_PTR(out);
+    if (B < 0 || D < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0 || D == 0) return STEREO_OK;
+    const long long HW = (long long)H * W, n = (long long)B * HW;
+    hipLaunchKernelGGL(uncertainty_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), vol, disp, out, D, HW,
+                       n);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}

@@ -1,0 +1,89 @@
+// ConvGRU gate math (A11/A14) around the host framework's convolutions.
+// Attempts/update.py:41-48 and update/update.py:28-32: pure streaming
+// elementwise kernels, 16 B/lane when the element count allows.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int V>
+__global__ __launch_bounds__(256) void gru_reset_kernel(const float *__restrict__ h, const float *__restrict__ rc,
+                                                        const float *__restrict__ cr, float *__restrict__ out,
+                                                        long long nvec)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nvec;
+         t += (long long)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const long long e = t * V + i;
+            const float r = sigmoidf_(rc[e] + (cr ? cr[e] : 0.0f));
+            out[e] = r * h[e];
+        }
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict__ h, const float *__restrict__ zc,
+                                                        const float *__restrict__ qc, const float *__restrict__ cz,
+                                                        const float *__restrict__ cq, float *__restrict__ out,
+                                                        long long nvec)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nvec;
+         t += (long long)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const long long e = t * V + i;
+            const float z = sigmoidf_(zc[e] + (cz ? cz[e] : 0.0f));
+            const float q = tanhf(qc[e] + (cq ? cq[e] : 0.0f));
+            out[e] = (1.0f - z) * h[e] + z * q;
+        }
+    }
+}
+
+inline unsigned grid_for(long long nthreads)
+{
+    long long blocks = (nthreads + 255) / 256;
+    const long long cap = 256LL * 32;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+}  // namespace
+
+extern "C" int stereo_gru_reset_f32(const float *h, const float *rc, const float *cr, float *out, long long n,
+                                    void *stream)
+{
+    STEREO_REQUIRE_PTR(h);
+    STEREO_REQUIRE_PTR(rc);
+    STEREO_REQUIRE_PTR(out);
+    if (n < 0) return STEREO_ERR_BAD_SHAPE;
+    if (n == 0) return STEREO_OK;
+    if (n % 4 == 0)
+        hipLaunchKernelGGL(gru_reset_kernel<4>, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(stream), h, rc, cr, out,
+                           n / 4);
+    else
+        hipLaunchKernelGGL(gru_reset_kernel<1>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), h, rc, cr, out, n);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+extern "C" int stereo_gru_blend_f32(const float *h, const float *zc, const float *qc, const float *cz, const float *cq,
+                                    float *out, long long n, void *stream)
+{
+    STEREO_REQUIRE_PTR(h);
+    STEREO_REQUIRE_PTR(zc);
+    STEREO_REQUIRE_PTR(qc);
+    STEREO_REQUIRE_PTR(out);
+    if (n < 0) return STEREO_ERR_BAD_SHAPE;
+    if (n == 0) return STEREO_OK;
+    if (n % 4 == 0)
+        hipLaunchKernelGGL(gru_blend_kernel<4>, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(stream), h, zc, qc, cz,
+                           cq, out, n / 4);
+    else
+        hipLaunchKernelGGL(gru_blend_kernel<1>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), h, zc, qc, cz, cq,
+                           out, n);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}

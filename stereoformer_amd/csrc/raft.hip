@@ -1,0 +1,273 @@
+// RAFT-style epipolar correlation (A8 all-pairs + pyramid, A9 lookup, A10
+// on-the-fly alternative).
+//
+// All-pairs: per image row (b,h) the volume is the dense product
+//   out[w1,w2] = sum_c f1[c,w1] * f2[c,w2] / sqrt(C)
+// computed on the matrix cores with the exact-f32 MFMA (v_mfma_f32_32x32x2_f32:
+// bitwise an fmaf chain, so the 1e-3 disparity bar holds without any
+// low-precision split).  A <-> fmap1 (rows = w1), B <-> fmap2 (cols = w2): both
+// operands are read straight from the [C][W] layout, 32 consecutive pixels per
+// half-wave, and every accumulator register stores a 128-B row segment.
+#include "common.h"
+
+namespace {
+
+inline unsigned grid_for(long long nthreads)
+{
+    long long blocks = (nthreads + 255) / 256;
+    const long long cap = 256LL * 32;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+// block = 4 waves (2 x 2), wave tile = 64 (w1) x 64 (w2) = 2 x 2 MFMA tiles
+__global__ __launch_bounds__(256) void allpairs_kernel(const float *__restrict__ f1, const float *__restrict__ f2,
+                                                       float *__restrict__ out, int C, int H, int W1, int W2,
+                                                       float sqrt_c)
+{
+    const int bh = blockIdx.z;
+    const int b = bh / H, h = bh - b * H;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int m0 = blockIdx.y * 128 + (wave >> 1) * 64;  // w1 origin of this wave
+    const int n0 = blockIdx.x * 128 + (wave & 1) * 64;   // w2 origin
+    if (m0 >= W1 || n0 >= W2) return;                    // wave-uniform
+
+    const size_t HW1 = (size_t)H * W1, HW2 = (size_t)H * W2;
+    const float *a_base = f1 + (size_t)b * C * HW1 + (size_t)h * W1;
+    const float *b_base = f2 + (size_t)b * C * HW2 + (size_t)h * W2;
+    const int ia0 = m0 + l31, ia1 = m0 + 32 + l31;
+    const int jb0 = n0 + l31, jb1 = n0 + 32 + l31;
+    const bool va0 = ia0 < W1, va1 = ia1 < W1, vb0 = jb0 < W2, vb1 = jb1 < W2;
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    for (int c0 = 0; c0 < C; c0 += 2) {
+        const int c = c0 + half;
+        const bool vc = c < C;
+        const float a0 = (vc && va0) ? a_base[(size_t)c * HW1 + ia0] : 0.0f;
+        const float a1 = (vc && va1) ? a_base[(size_t)c * HW1 + ia1] : 0.0f;
+        const float b0 = (vc && vb0) ? b_base[(size_t)c * HW2 + jb0] : 0.0f;
+        const float b1 = (vc && vb1) ? b_base[(size_t)c * HW2 + jb1] : 0.0f;
+        acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+        acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+        acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+        acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+    }
+    float *obase = out + (size_t)bh * W1 * W2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int w1a = m0 + row, w1b = m0 + 32 + row;
+        if (w1a < W1) {
+            if (vb0) obase[(size_t)w1a * W2 + jb0] = acc00[r] / sqrt_c;
+            if (vb1) obase[(size_t)w1a * W2 + jb1] = acc01[r] / sqrt_c;
+        }
+        if (w1b < W1) {
+            if (vb0) obase[(size_t)w1b * W2 + jb0] = acc10[r] / sqrt_c;
+            if (vb1) obase[(size_t)w1b * W2 + jb1] = acc11[r] / sqrt_c;
+        }
+    }
+}
+
+// F.avg_pool2d(x,[1,2],stride=[1,2]) on rows: Win -> Win/2 (floor), corr.py:70-76
+__global__ __launch_bounds__(256) void avgpool_w2_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                         int Win, int Wout, long long nout)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nout;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long r = t / Wout;
+        const int x = (int)(t - r * Wout);
+        const float *p = in + (size_t)r * Win + 2 * x;
+        out[t] = (p[0] + p[1]) * 0.5f;
+    }
+}
+
+struct LevelPtrs {
+    const float *p[STEREO_MAX_LEVELS];
+    int w[STEREO_MAX_LEVELS];
+};
+
+// 1-D linear tap, zeros padding, through bilinear_sampler's normalise
+// (utils/utils.py:64-66) and grid_sample's align_corners=True un-normalise.
+__device__ __forceinline__ float lerp_zero_pad_ac(const float *__restrict__ row, int Wl, float x)
+{
+    const float xg = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, x), (float)(Wl - 1)), 1.0f);
+    const float ix = __fmul_rn(__fdiv_rn(__fadd_rn(xg, 1.0f), 2.0f), (float)(Wl - 1));
+    const float fx = floorf(ix);
+    const float w1 = ix - fx, w0 = 1.0f - w1;
+    float acc = 0.0f;
+    if (fx >= 0.0f && fx <= (float)(Wl - 1)) acc += row[(int)fx] * w0;
+    if (fx + 1.0f >= 0.0f && fx + 1.0f <= (float)(Wl - 1)) acc += row[(int)fx + 1] * w1;
+    return acc;
+}
+
+// A9: CorrBlock1D.__call__ (corr.py:78-101)
+__global__ __launch_bounds__(256) void corr_lookup_kernel(LevelPtrs lv, const float *__restrict__ coords,
+                                                          float *__restrict__ out, int L, int r, long long HW,
+                                                          long long npix)
+{
+    const int T = 2 * r + 1;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npix;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long b = t / HW, p = t - b * HW;
+        const float x = coords[(size_t)b * 2 * HW + p];
+        float *o = out + (size_t)b * (size_t)(L * T) * HW + p;
+        for (int i = 0; i < L; ++i) {
+            const float *row = lv.p[i] + (size_t)t * lv.w[i];
+            const float xl = x / (float)(1 << i);
+            for (int k = 0; k < T; ++k)
+                o[(size_t)(i * T + k) * HW] = lerp_zero_pad_ac(row, lv.w[i], __fadd_rn((float)(k - r), xl));
+        }
+    }
+}
+
+// A10: PytorchAlternateCorrBlock1D.__call__ (corr.py:8-51).  One thread per
+// (b, level*tap, h, w); loops over channels.  lv.p[i] = fmap2 pooled i times.
+__global__ __launch_bounds__(256) void alt_corr_lookup_kernel(const float *__restrict__ f1, LevelPtrs lv,
+                                                              const float *__restrict__ coords,
+                                                              float *__restrict__ out, int C, int H, int W, int L, int r,
+                                                              float sqrt_c, long long nout)
+{
+    const int T = 2 * r + 1;
+    const long long HW = (long long)H * W;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nout;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long p = t % HW;
+        long long q = t / HW;
+        const int lt = (int)(q % (L * T));
+        const long long b = q / (L * T);
+        const int i = lt / T, k = lt - i * T;
+        const int Wl = lv.w[i];
+        const float x = coords[(size_t)b * 2 * HW + p], y = coords[(size_t)b * 2 * HW + HW + p];
+        const float px = __fadd_rn(x / (float)(1 << i), (float)(k - r));
+        const float xg = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, px), (float)(Wl - 1)), 1.0f);
+        const float yg = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, y), (float)(H - 1)), 1.0f);
+        const float ix = __fmul_rn(__fdiv_rn(__fadd_rn(xg, 1.0f), 2.0f), (float)(Wl - 1));
+        const float iy = __fmul_rn(__fdiv_rn(__fadd_rn(yg, 1.0f), 2.0f), (float)(H - 1));
+        const float fx = floorf(ix), fy = floorf(iy);
+        const float ax = ix - fx, ay = iy - fy;
+        const int x0 = (int)fx, y0 = (int)fy;
+        const bool vx0 = fx >= 0.0f && fx <= (float)(Wl - 1), vx1 = fx + 1.0f >= 0.0f && fx + 1.0f <= (float)(Wl - 1);
+        const bool vy0 = fy >= 0.0f && fy <= (float)(H - 1), vy1 = fy + 1.0f >= 0.0f && fy + 1.0f <= (float)(H - 1);
+        const float w00 = (1.0f - ax) * (1.0f - ay), w01 = ax * (1.0f - ay), w10 = (1.0f - ax) * ay, w11 = ax * ay;
+        const float *img = lv.p[i] + (size_t)b * C * H * (size_t)Wl;
+        const float *q1 = f1 + (size_t)b * C * HW + p;
+        float dot = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            const float *im = img + (size_t)c * H * (size_t)Wl;
+            float s = 0.0f;
+            if (vy0 && vx0) s += im[(size_t)y0 * Wl + x0] * w00;
+            if (vy0 && vx1) s += im[(size_t)y0 * Wl + x0 + 1] * w01;
+            if (vy1 && vx0) s += im[(size_t)(y0 + 1) * Wl + x0] * w10;
+            if (vy1 && vx1) s += im[(size_t)(y0 + 1) * Wl + x0 + 1] * w11;
+            dot = fmaf(s, q1[(size_t)c * HW], dot);
+        }
+        out[t] = dot / sqrt_c;
+    }
+}
+
+}  // namespace
+
+extern "C" int stereo_allpairs_pyramid_f32(const float *fmap1, const float *fmap2, float *const *levels, int B, int C,
+                                           int H, int W1, int W2, int num_levels, void *stream)
+{
+    STEREO_REQUIRE_PTR(fmap1);
+    STEREO_REQUIRE_PTR(fmap2);
+    STEREO_REQUIRE_PTR(levels);
+    if (B < 0 || C < 0 || H < 0 || W1 < 0 || W2 < 0 || num_levels < 0) return STEREO_ERR_BAD_SHAPE;
+    if (num_levels + 1 > STEREO_MAX_LEVELS) return STEREO_ERR_UNSUPPORTED;
+    if (B == 0 || H == 0 || W1 == 0 || W2 == 0) return STEREO_OK;
+    for (int i = 0, w = W2; i <= num_levels; ++i, w /= 2)
+        if (w > 0) STEREO_REQUIRE_PTR(levels[i]);
+    if (!fits_grid_yz((long long)B * H) || !fits_grid_yz((W1 + 127) / 128)) return STEREO_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    dim3 grid((W2 + 127) / 128, (W1 + 127) / 128, (unsigned)(B * H));
+    hipLaunchKernelGGL(allpairs_kernel, grid, dim3(256), 0, st, fmap1, fmap2, levels[0], C, H, W1, W2,
+                       sqrtf((float)C));
+    STEREO_LAUNCH_CHECK();
+    const long long rows = (long long)B * H * W1;
+    for (int i = 1, w = W2; i <= num_levels; ++i) {
+        const int wo = w / 2;
+        if (wo == 0) break;
+        const long long nout = rows * wo;
+        hipLaunchKernelGGL(avgpool_w2_kernel, dim3(grid_for(nout)), dim3(256), 0, st, levels[i - 1], levels[i], w, wo,
+                           nout);
+        STEREO_LAUNCH_CHECK();
+        w = wo;
+    }
+    return STEREO_OK;
+}
+
+extern "C" int stereo_corr_lookup_f32(const float *const *levels, const float *coords, float *out, int B, int H, int W1,
+                                      int W2, int num_levels, int radius, void *stream)
+{
+    STEREO_REQUIRE_PTR(levels);
+    STEREO_REQUIRE_PTR(coords);
+    STEREO_REQUIRE_PTR(out);
+    if (B < 0 || H < 0 || W1 < 0 || W2 < 0 || num_levels < 0 || radius < 0) return STEREO_ERR_BAD_SHAPE;
+    if (num_levels > STEREO_MAX_LEVELS) return STEREO_ERR_UNSUPPORTED;
+    if (B == 0 || H == 0 || W1 == 0 || num_levels == 0) return STEREO_OK;
+    LevelPtrs lv;
+    for (int i = 0, w = W2; i < num_levels; ++i, w /= 2) {
+        if (w < 2) return STEREO_ERR_UNSUPPORTED;  // 2x/(W-1) is undefined (reference yields NaN/inf)
+        STEREO_REQUIRE_PTR(levels[i]);
+        lv.p[i] = levels[i];
+        lv.w[i] = w;
+    }
+    const long long HW = (long long)H * W1, n = (long long)B * HW;
+    hipLaunchKernelGGL(corr_lookup_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), lv, coords, out,
+                       num_levels, radius, HW, n);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+extern "C" long long stereo_alt_corr_workspace_floats(int B, int C, int H, int W, int num_levels)
+{
+    long long total = 0;
+    for (int i = 1, w = W; i < num_levels; ++i) {
+        w /= 2;
+        total += (long long)B * C * H * w;
+    }
+    return total;
+}
+
+extern "C" int stereo_alt_corr_lookup_f32(const float *fmap1, const float *fmap2, const float *coords, float *out,
+                                          float *workspace, int B, int C, int H, int W, int num_levels, int radius,
+                                          void *stream)
+{
+    STEREO_REQUIRE_PTR(fmap1);
+    STEREO_REQUIRE_PTR(fmap2);
+    STEREO_REQUIRE_PTR(coords);
+    STEREO_REQUIRE_PTR(out);
+    if (B < 0 || C < 0 || H < 0 || W < 0 || num_levels < 0 || radius < 0) return STEREO_ERR_BAD_SHAPE;
+    if (num_levels > STEREO_MAX_LEVELS) return STEREO_ERR_UNSUPPORTED;
+    if (B == 0 || H == 0 || W == 0 || num_levels == 0) return STEREO_OK;
+    if (num_levels > 1 && stereo_alt_corr_workspace_floats(B, C, H, W, num_levels) > 0) STEREO_REQUIRE_PTR(workspace);
+    hipStream_t st = as_stream(stream);
+    LevelPtrs lv;
+    lv.p[0] = fmap2;
+    lv.w[0] = W;
+    float *ws = workspace;
+    const long long rows = (long long)B * C * H;
+    for (int i = 1; i < num_levels; ++i) {
+        const int wo = lv.w[i - 1] / 2;
+        if (wo < 2) return STEREO_ERR_UNSUPPORTED;
+        const long long nout = rows * wo;
+        if (nout > 0) {
+            hipLaunchKernelGGL(avgpool_w2_kernel, dim3(grid_for(nout)), dim3(256), 0, st, lv.p[i - 1], ws, lv.w[i - 1],
+                               wo, nout);
+            STEREO_LAUNCH_CHECK();
+        }
+        lv.p[i] = ws;
+        lv.w[i] = wo;
+        ws += nout;
+    }
+    if (W < 2 || H < 2) return STEREO_ERR_UNSUPPORTED;  // corr.py:20-21 divides by (W-1),(H-1)
+    const int T = 2 * radius + 1;
+    const long long nout = (long long)B * num_levels * T * H * W;
+    hipLaunchKernelGGL(alt_corr_lookup_kernel, dim3(grid_for(nout)), dim3(256), 0, st, fmap1, lv, coords, out, C, H, W,
+                       num_levels, radius, sqrtf((float)C), nout);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}

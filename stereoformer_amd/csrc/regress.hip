@@ -1,0 +1,287 @@
+// Soft-argmin disparity regression (A4) and its fused readers.
+//
+// One lane owns V (=4 when H*W % 4 == 0) consecutive pixels and walks the D
+// planes of the volume with 16-byte loads (one wave load = 1 KiB contiguous
+// along W), keeping an online-softmax state (running max, sum, d-weighted sum)
+// per pixel: the volume is read exactly once.  The with-prob variant re-reads
+// the (then L2/MALL-warm) column to write the normalised probabilities.
+#include "common.h"
+
+namespace {
+
+template <int V>
+struct Vec;
+template <>
+struct Vec<4> {
+    typedef f32x4 T;
+    static __device__ __forceinline__ T load(const float *p) { return ld4(p); }
+    static __device__ __forceinline__ void store(float *p, T v) { st4(p, v); }
+};
+template <>
+struct Vec<1> {
+    typedef float T __attribute__((ext_vector_type(1)));
+    static __device__ __forceinline__ T load(const float *p) { return (T){*p}; }
+    static __device__ __forceinline__ void store(float *p, T v) { *p = v[0]; }
+};
+
+// Online softmax-expectation state for V pixels.
+template <int V>
+struct Online {
+    float m[V], s[V], e[V];
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            m[i] = -INFINITY;
+            s[i] = 0.0f;
+            e[i] = 0.0f;
+        }
+    }
+    // absorb U planes x[u][i] with candidate value d0+u
+    template <int U>
+    __device__ __forceinline__ void absorb(const float (&x)[U][V], int d0, int nvalid)
+    {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            float cm = m[i];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (u < nvalid) cm = fmaxf(cm, x[u][i]);
+            const float sc = (m[i] == cm) ? 1.0f : fast_exp(m[i] - cm);  // m=-inf,cm finite -> 0
+            float ss = s[i] * sc, ee = e[i] * sc;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (u < nvalid) {
+                    const float p = fast_exp(x[u][i] - cm);
+                    ss += p;
+                    ee = fmaf(p, (float)(d0 + u), ee);
+                }
+            m[i] = cm;
+            s[i] = ss;
+            e[i] = ee;
+        }
+    }
+};
+
+// vol [B, D, HW] -> disp [B, HW] (+ prob)
+template <int V, int U, bool PROB>
+__global__ __launch_bounds__(256) void soft_argmin_kernel(const float *__restrict__ vol, float *__restrict__ disp,
+                                                          float *__restrict__ prob, int D, long long HW,
+                                                          long long ncols, float sgn)
+{
+    const long long HWv = HW / V;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < ncols;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long b = t / HWv, p = (t - b * HWv) * V;
+        const float *v = vol + (size_t)b * D * HW + p;
+        Online<V> st;
+        st.init();
+        for (int d0 = 0; d0 < D; d0 += U) {
+            float x[U][V];
+            const int nv = (D - d0) < U ? (D - d0) : U;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (u < nv) {
+                    const typename Vec<V>::T r = Vec<V>::load(v + (size_t)(d0 + u) * HW);
+#pragma unroll
+                    for (int i = 0; i < V; ++i) x[u][i] = sgn * r[i];
+                }
+            }
+            st.template absorb<U>(x, d0, nv);
+        }
+        typename Vec<V>::T o;
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[i] = st.e[i] / st.s[i];
+        Vec<V>::store(disp + (size_t)b * HW + p, o);
+        if (PROB) {
+            float inv[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) inv[i] = 1.0f / st.s[i];
+            float *pr = prob + (size_t)b * D * HW + p;
+            for (int d = 0; d < D; ++d) {
+                const typename Vec<V>::T r = Vec<V>::load(v + (size_t)d * HW);
+                typename Vec<V>::T q;
+#pragma unroll
+                for (int i = 0; i < V; ++i) q[i] = fast_exp(sgn * r[i] - st.m[i]) * inv[i];
+                Vec<V>::store(pr + (size_t)d * HW, q);
+            }
+        }
+    }
+}
+
+// volg [B, G, D, HW] -> mean over G -> (vol_mean [B, D, HW]) -> disp [B, HW]
+template <int V, int U, bool WRITE_MEAN>
+__global__ __launch_bounds__(256) void group_mean_soft_argmin_kernel(const float *__restrict__ volg,
+                                                                     float *__restrict__ vol_mean,
+                                                                     float *__restrict__ disp, int G, int D,
+                                                                     long long HW, long long ncols, float sgn,
+                                                                     float inv_g, int exact_div)
+{
+    const long long HWv = HW / V;
+    const size_t gstride = (size_t)D * HW;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < ncols;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long b = t / HWv, p = (t - b * HWv) * V;
+        const float *v = volg + (size_t)b * G * gstride + p;
+        Online<V> st;
+        st.init();
+        for (int d0 = 0; d0 < D; d0 += U) {
+            float x[U][V];
+            const int nv = (D - d0) < U ? (D - d0) : U;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < V; ++i) x[u][i] = 0.0f;
+#pragma unroll 4
+            for (int g = 0; g < G; ++g) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (u < nv) {
+                        const typename Vec<V>::T r = Vec<V>::load(v + (size_t)g * gstride + (size_t)(d0 + u) * HW);
+#pragma unroll
+                        for (int i = 0; i < V; ++i) x[u][i] += r[i];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (u < nv) {
+                    typename Vec<V>::T mv;
+#pragma unroll
+                    for (int i = 0; i < V; ++i) {
+                        mv[i] = exact_div ? x[u][i] / (float)G : x[u][i] * inv_g;
+                        x[u][i] = sgn * mv[i];
+                    }
+                    if (WRITE_MEAN) Vec<V>::store(vol_mean + (size_t)b * gstride + (size_t)(d0 + u) * HW + p, mv);
+                }
+            }
+            st.template absorb<U>(x, d0, nv);
+        }
+        typename Vec<V>::T o;
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[i] = st.e[i] / st.s[i];
+        Vec<V>::store(disp + (size_t)b * HW + p, o);
+    }
+}
+
+// disparity_regression (models/utils/submodule.py:23-27): out[b,p] = sum_d x[b,d,p] * d
+template <int V>
+__global__ __launch_bounds__(256) void disparity_regression_kernel(const float *__restrict__ x,
+                                                                   float *__restrict__ out, int D, long long HW,
+                                                                   long long ncols)
+{
+    const long long HWv = HW / V;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < ncols;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long b = t / HWv, p = (t - b * HWv) * V;
+        const float *v = x + (size_t)b * D * HW + p;
+        typename Vec<V>::T acc;
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] = 0.0f;
+#pragma unroll 8
+        for (int d = 0; d < D; ++d) {
+            const typename Vec<V>::T r = Vec<V>::load(v + (size_t)d * HW);
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[i] = fmaf(r[i], (float)d, acc[i]);
+        }
+        Vec<V>::store(out + (size_t)b * HW + p, acc);
+    }
+}
+
+inline unsigned grid_for(long long nthreads)
+{
+    long long blocks = (nthreads + 255) / 256;
+    const long long cap = 256LL * 32;  // grid-stride above this
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+}  // namespace
+
+extern "C" int stereo_soft_argmin_f32(const float *vol, float *disp, float *prob, int B, int D, int H, int W,
+                                      int match_similarity, void *stream)
+{
+    STEREO_REQUIRE_PTR(vol);
+    STEREO_REQUIRE_PTR(disp);
+    if (B < 0 || D < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0) return STEREO_OK;
+    if (D == 0) return STEREO_ERR_BAD_SHAPE;  // softmax over an empty axis
+    const long long HW = (long long)H * W;
+    const float sgn = match_similarity ? 1.0f : -1.0f;
+    hipStream_t st = as_stream(stream);
+    const bool vec = (HW % 4 == 0) && aligned16(vol) && aligned16(disp) && (prob == nullptr || aligned16(prob));
+    if (vec) {
+        const long long n = (long long)B * (HW / 4);
+        if (prob)
+            hipLaunchKernelGGL((soft_argmin_kernel<4, 8, true>), dim3(grid_for(n)), dim3(256), 0, st, vol, disp, prob, D,
+                               HW, n, sgn);
+        else
+            hipLaunchKernelGGL((soft_argmin_kernel<4, 8, false>), dim3(grid_for(n)), dim3(256), 0, st, vol, disp, prob,
+                               D, HW, n, sgn);
+    } else {
+        const long long n = (long long)B * HW;
+        if (prob)
+            hipLaunchKernelGGL((soft_argmin_kernel<1, 8, true>), dim3(grid_for(n)), dim3(256), 0, st, vol, disp, prob, D,
+                               HW, n, sgn);
+        else
+            hipLaunchKernelGGL((soft_argmin_kernel<1, 8, false>), dim3(grid_for(n)), dim3(256), 0, st, vol, disp, prob,
+                               D, HW, n, sgn);
+    }
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+extern "C" int stereo_group_mean_soft_argmin_f32(const float *volg, float *vol_mean, float *disp, int B, int G, int D,
+                                                 int H, int W, int match_similarity, void *stream)
+{
+    STEREO_REQUIRE_PTR(volg);
+    STEREO_REQUIRE_PTR(disp);
+    if (B < 0 || G <= 0 || D < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0) return STEREO_OK;
+    if (D == 0) return STEREO_ERR_BAD_SHAPE;
+    const long long HW = (long long)H * W;
+    const float sgn = match_similarity ? 1.0f : -1.0f;
+    const bool pow2 = (G & (G - 1)) == 0;
+    hipStream_t st = as_stream(stream);
+    const bool vec =
+        (HW % 4 == 0) && aligned16(volg) && aligned16(disp) && (vol_mean == nullptr || aligned16(vol_mean));
+#define GM_LAUNCH(V, U, WM)                                                                                           \
+    hipLaunchKernelGGL((group_mean_soft_argmin_kernel<V, U, WM>), dim3(grid_for(n)), dim3(256), 0, st, volg, vol_mean, \
+                       disp, G, D, HW, n, sgn, 1.0f / (float)G, pow2 ? 0 : 1)
+    if (vec) {
+        const long long n = (long long)B * (HW / 4);
+        if (vol_mean)
+            GM_LAUNCH(4, 2, true);
+        else
+            GM_LAUNCH(4, 2, false);
+    } else {
+        const long long n = (long long)B * HW;
+        if (vol_mean)
+            GM_LAUNCH(1, 4, true);
+        else
+            GM_LAUNCH(1, 4, false);
+    }
+#undef GM_LAUNCH
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+extern "C" int stereo_disparity_regression_f32(const float *x, float *out, int B, int D, int H, int W, void *stream)
+{
+    STEREO_REQUIRE_PTR(x);
+    STEREO_REQUIRE_PTR(out);
+    if (B < 0 || D < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0) return STEREO_OK;
+    const long long HW = (long long)H * W;
+    hipStream_t st = as_stream(stream);
+    if ((HW % 4 == 0) && aligned16(x) && aligned16(out)) {
+        const long long n = (long long)B * (HW / 4);
+        hipLaunchKernelGGL(disparity_regression_kernel<4>, dim3(grid_for(n)), dim3(256), 0, st, x, out, D, HW, n);
+    } else {
+        const long long n = (long long)B * HW;
+        hipLaunchKernelGGL(disparity_regression_kernel<1>, dim3(grid_for(n)), dim3(256), 0, st, x, out, D, HW, n);
+    }
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}

@@ -1,0 +1,326 @@
+// Cost-volume builders (A1 correlation, A2 difference/concat, A3 group-wise).
+//
+// Correlation / group-wise volume:   vol[b,g,d,h,w] = mean_{c in g} L[b,c,h,w] * R[b,c,h,w-d]
+// (0.0 for w < d).  One workgroup = one image row segment of TW=256 pixels of
+// one (batch, group): the left tile [CC][TW] and the right tile with its
+// disparity halo [CC][TW+Dpad] are staged in LDS with coalesced 16-byte loads
+// along W; each of the 8 waves owns one chunk of DC disparities and keeps a
+// DC x 4 accumulator block in registers (lane = 4 consecutive pixels), reading
+// the right tile as a sliding window of ds_read_b128.  Every store is a full
+// 1-KiB W-contiguous wave store (16 B/lane); the w<d zeros are written by the
+// same kernel (the reference's new_zeros pass does not exist here).
+#include "common.h"
+
+namespace {
+
+constexpr int TW = 256;  // pixels per tile: 64 lanes x 4
+constexpr int NW = 8;    // waves per workgroup
+constexpr int NT = NW * 64;
+constexpr int CCMAX = 8;  // channels staged per LDS round
+
+// EPI_STORE: write the volume.  EPI_ARGMIN: fold every disparity plane into an
+// online softmax-expectation instead (A1+A4 fused; `vol` is then disp [B,H,W]
+// and G must be 1): each wave keeps (max, sum, d-weighted sum) for its own
+// disparity chunks, the 8 partial states meet in LDS at the end.
+enum { EPI_STORE = 0, EPI_ARGMIN = 1 };
+
+template <int DC, bool VEC, int EPI>
+__global__ __launch_bounds__(NT) void gwc_volume_kernel(const float *__restrict__ L, const float *__restrict__ R,
+                                                        float *__restrict__ vol, int C, int H, int W, int D, int G,
+                                                        int CPG, int Dpad, int CC, float inv_cpg, int exact_div,
+                                                        float sgn)
+{
+    extern __shared__ f32x4 smem4[];
+    float *Rs = reinterpret_cast<float *>(smem4);  // [CC][RS]
+    const int RS = TW + Dpad;
+    float *Ls = Rs + CC * RS;  // [CC][TW]
+
+    const int w0 = blockIdx.x * TW;
+    const int h = blockIdx.y;
+    const int b = blockIdx.z / G, g = blockIdx.z % G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wl = lane * 4;
+
+    const size_t HW = (size_t)H * W;
+    const float *Lrow = L + ((size_t)b * C + (size_t)g * CPG) * HW + (size_t)h * W;
+    const float *Rrow = R + ((size_t)b * C + (size_t)g * CPG) * HW + (size_t)h * W;
+    float *vbase = vol + (((size_t)b * G + g) * D) * HW + (size_t)h * W;
+
+    float sm_m[4], sm_s[4], sm_e[4];  // EPI_ARGMIN state
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sm_m[i] = -INFINITY, sm_s[i] = 0.0f, sm_e[i] = 0.0f;
+
+    const int npass = (D + NW * DC - 1) / (NW * DC);
+    for (int pass = 0; pass < npass; ++pass) {
+        const int d0 = (pass * NW + wave) * DC;
+        const bool active = d0 < D;  // wave-uniform
+
+        f32x4 acc[DC];
+#pragma unroll
+        for (int i = 0; i < DC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int c0 = 0; c0 < CPG; c0 += CC) {
+            const int ncc = (CPG - c0) < CC ? (CPG - c0) : CC;
+            __syncthreads();  // previous round's readers are done
+            // ---- stage right tile (with halo) and left tile
+            const int rq = RS / 4;
+            for (int idx = tid; idx < ncc * rq; idx += NT) {
+                const int c = idx / rq, x = (idx - c * rq) * 4;
+                const int w = w0 - Dpad + x;
+                const float *src = Rrow + (size_t)(c0 + c) * HW;
+                f32x4 v;
+                if (VEC && w >= 0 && w + 3 < W) {
+                    v = ld4(src + w);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = (w + i >= 0 && w + i < W) ? src[w + i] : 0.0f;
+                }
+                *reinterpret_cast<f32x4 *>(Rs + c * RS + x) = v;
+            }
+            const int lq = TW / 4;
+            for (int idx = tid; idx < ncc * lq; idx += NT) {
+                const int c = idx / lq, x = (idx - c * lq) * 4;
+                const int w = w0 + x;
+                const float *src = Lrow + (size_t)(c0 + c) * HW;
+                f32x4 v;
+                if (VEC && w + 3 < W) {
+                    v = ld4(src + w);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = (w + i < W) ? src[w + i] : 0.0f;
+                }
+                *reinterpret_cast<f32x4 *>(Ls + c * TW + x) = v;
+            }
+            __syncthreads();
+            if (active) {
+                // window start in the right tile: x = Dpad + wl - d0 - DC  (>= 0, multiple of 4)
+                const float *rwin = Rs + (Dpad + wl - d0 - DC);
+                for (int c = 0; c < ncc; ++c) {
+                    const f32x4 lv = *reinterpret_cast<const f32x4 *>(Ls + c * TW + wl);
+                    float win[DC + 4];
+#pragma unroll
+                    for (int q = 0; q < DC / 4 + 1; ++q) {
+                        const f32x4 t = *reinterpret_cast<const f32x4 *>(rwin + c * RS + 4 * q);
+                        win[4 * q + 0] = t[0];
+                        win[4 * q + 1] = t[1];
+                        win[4 * q + 2] = t[2];
+                        win[4 * q + 3] = t[3];
+                    }
+#pragma unroll
+                    for (int dd = 0; dd < DC; ++dd) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[dd][i] = fmaf(lv[i], win[DC + i - dd], acc[dd][i]);
+                    }
+                }
+            }
+        }
+        if (active && EPI == EPI_ARGMIN) {
+            const int w = w0 + wl;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float x[DC];
+                float cm = sm_m[i];
+#pragma unroll
+                for (int dd = 0; dd < DC; ++dd) {
+                    const float m = exact_div ? acc[dd][i] / (float)CPG : acc[dd][i] * inv_cpg;
+                    x[dd] = (w + i >= d0 + dd) ? sgn * m : sgn * 0.0f;  // zero-filled logits take part (estimation.py:20)
+                    if (d0 + dd < D) cm = fmaxf(cm, x[dd]);
+                }
+                const float sc = (sm_m[i] == cm) ? 1.0f : fast_exp(sm_m[i] - cm);
+                float ss = sm_s[i] * sc, ee = sm_e[i] * sc;
+#pragma unroll
+                for (int dd = 0; dd < DC; ++dd)
+                    if (d0 + dd < D) {
+                        const float p = fast_exp(x[dd] - cm);
+                        ss += p;
+                        ee = fmaf(p, (float)(d0 + dd), ee);
+                    }
+                sm_m[i] = cm, sm_s[i] = ss, sm_e[i] = ee;
+            }
+        }
+        if (active && EPI == EPI_STORE) {
+            const int w = w0 + wl;
+#pragma unroll
+            for (int dd = 0; dd < DC; ++dd) {
+                const int d = d0 + dd;
+                if (d < D) {
+                    f32x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float m = exact_div ? acc[dd][i] / (float)CPG : acc[dd][i] * inv_cpg;
+                        o[i] = (w + i >= d) ? m : 0.0f;
+                    }
+                    float *dst = vbase + (size_t)d * HW + w;
+                    if (VEC && w + 3 < W) {
+                        st4(dst, o);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (w + i < W) dst[i] = o[i];
+                    }
+                }
+            }
+        }
+    }
+    if (EPI == EPI_ARGMIN) {
+        __syncthreads();
+        float *stt = reinterpret_cast<float *>(smem4);  // [3][NW][TW]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            stt[(0 * NW + wave) * TW + wl + i] = sm_m[i];
+            stt[(1 * NW + wave) * TW + wl + i] = sm_s[i];
+            stt[(2 * NW + wave) * TW + wl + i] = sm_e[i];
+        }
+        __syncthreads();
+        if (tid < TW && w0 + tid < W) {
+            float M = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) M = fmaxf(M, stt[(0 * NW + k) * TW + tid]);
+            float S = 0.0f, E = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                const float mk = stt[(0 * NW + k) * TW + tid];
+                const float sc = (mk == -INFINITY) ? 0.0f : fast_exp(mk - M);
+                S = fmaf(stt[(1 * NW + k) * TW + tid], sc, S);
+                E = fmaf(stt[(2 * NW + k) * TW + tid], sc, E);
+            }
+            vol[((size_t)b * H + h) * W + w0 + tid] = E / S;
+        }
+    }
+}
+
+template <int DC, int EPI>
+int launch_gwc(const float *L, const float *R, float *vol, int B, int C, int H, int W, int D, int G, float sgn,
+               hipStream_t st)
+{
+    const int CPG = C / G;
+    const int Dpad = ((D + DC - 1) / DC) * DC;
+    const int CC = CPG < CCMAX ? CPG : CCMAX;
+    size_t lds = (size_t)CC * (size_t)(TW + Dpad + TW) * sizeof(float);
+    if (EPI == EPI_ARGMIN && lds < (size_t)3 * NW * TW * sizeof(float)) lds = (size_t)3 * NW * TW * sizeof(float);
+    if (lds > 160 * 1024) return STEREO_ERR_UNSUPPORTED;
+    const bool pow2 = (CPG & (CPG - 1)) == 0;
+    const bool vec = (W % 4 == 0) && aligned16(L) && aligned16(R) && aligned16(vol);
+    dim3 grid((W + TW - 1) / TW, H, (unsigned)(B * G));
+    auto kern = vec ? gwc_volume_kernel<DC, true, EPI> : gwc_volume_kernel<DC, false, EPI>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return STEREO_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, L, R, vol, C, H, W, D, G, CPG, Dpad, CC, 1.0f / (float)CPG,
+                       pow2 ? 0 : 1, sgn);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+template <int EPI>
+int gwc_dispatch(const float *L, const float *R, float *vol, int B, int C, int H, int W, int D, int G, float sgn,
+                 void *stream)
+{
+    STEREO_REQUIRE_PTR(L);
+    STEREO_REQUIRE_PTR(R);
+    STEREO_REQUIRE_PTR(vol);
+    if (B < 0 || C < 0 || H < 0 || W < 0 || D < 0 || G <= 0) return STEREO_ERR_BAD_SHAPE;
+    if (C % G != 0) return STEREO_ERR_BAD_SHAPE;  // GWC_Cost_Volume.py:7
+    if (B == 0 || C == 0 || H == 0 || W == 0 || D == 0) {
+        // C == 0 with D > 0: mean over nothing; the reference would give NaN.  Not a use case.
+        return C == 0 && B && H && W && D ? STEREO_ERR_BAD_SHAPE : STEREO_OK;
+    }
+    if (!fits_grid_yz(H) || !fits_grid_yz((long long)B * G)) return STEREO_ERR_UNSUPPORTED;
+    if (D > 4096) return STEREO_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    if (D <= NW * 8) return launch_gwc<8, EPI>(L, R, vol, B, C, H, W, D, G, sgn, st);
+    if (D <= NW * 16) return launch_gwc<16, EPI>(L, R, vol, B, C, H, W, D, G, sgn, st);
+    return launch_gwc<24, EPI>(L, R, vol, B, C, H, W, D, G, sgn, st);
+}
+
+// ---------------------------------------------------------------- A2 (copy-bound volumes)
+// out[b, c, d, h, w]: one thread per 4 consecutive w of one (b,c,d,h) row.
+template <bool CONCAT>
+__global__ __launch_bounds__(256) void shift_volume_kernel(const float *__restrict__ L, const float *__restrict__ R,
+                                                           float *__restrict__ vol, int C, int H, int W, int D,
+                                                           long long nquads)
+{
+    const int Wq = (W + 3) / 4;
+    const int Cout = CONCAT ? 2 * C : C;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads;
+         q += (long long)gridDim.x * blockDim.x) {
+        const int wq = (int)(q % Wq);
+        long long r = q / Wq;
+        const int h = (int)(r % H);
+        r /= H;
+        const int d = (int)(r % D);
+        r /= D;
+        const int c = (int)(r % Cout);
+        const int b = (int)(r / Cout);
+        const int w = wq * 4;
+        float *dst = vol + ((((size_t)b * Cout + c) * D + d) * H + h) * (size_t)W + w;
+        const int cs = (CONCAT && c >= C) ? c - C : c;
+        const float *lrow = L + (((size_t)b * C + cs) * H + h) * (size_t)W;
+        const float *rrow = R + (((size_t)b * C + cs) * H + h) * (size_t)W;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (w + i < W) {
+                float v = 0.0f;
+                if (w + i >= d) {
+                    if (CONCAT)
+                        v = (c < C) ? lrow[w + i] : rrow[w + i - d];
+                    else
+                        v = lrow[w + i] - rrow[w + i - d];
+                }
+                dst[i] = v;
+            }
+        }
+    }
+}
+
+template <bool CONCAT>
+int shift_dispatch(const float *L, const float *R, float *vol, int B, int C, int H, int W, int D, void *stream)
+{
+    STEREO_REQUIRE_PTR(L);
+    STEREO_REQUIRE_PTR(R);
+    STEREO_REQUIRE_PTR(vol);
+    if (B < 0 || C < 0 || H < 0 || W < 0 || D < 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || C == 0 || H == 0 || W == 0 || D == 0) return STEREO_OK;
+    const long long nquads = (long long)B * (CONCAT ? 2 * C : C) * D * H * ((W + 3) / 4);
+    long long blocks = (nquads + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(shift_volume_kernel<CONCAT>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), L, R, vol,
+                       C, H, W, D, nquads);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+}  // namespace
+
+extern "C" int stereo_corr_volume_f32(const float *left, const float *right, float *vol, int B, int C, int H, int W,
+                                      int D, void *stream)
+{
+    return gwc_dispatch<EPI_STORE>(left, right, vol, B, C, H, W, D, 1, 1.0f, stream);
+}
+
+extern "C" int stereo_gwc_volume_f32(const float *left, const float *right, float *vol, int B, int C, int H, int W,
+                                     int D, int G, void *stream)
+{
+    return gwc_dispatch<EPI_STORE>(left, right, vol, B, C, H, W, D, G, 1.0f, stream);
+}
+
+extern "C" int stereo_diff_volume_f32(const float *left, const float *right, float *vol, int B, int C, int H, int W,
+                                      int D, void *stream)
+{
+    return shift_dispatch<false>(left, right, vol, B, C, H, W, D, stream);
+}
+
+extern "C" int stereo_concat_volume_f32(const float *left, const float *right, float *vol, int B, int C, int H, int W,
+                                        int D, void *stream)
+{
+    return shift_dispatch<true>(left, right, vol, B, C, H, W, D, stream);
+}
+
+extern "C" int stereo_corr_soft_argmin_f32(const float *left, const float *right, float *disp, int B, int C, int H,
+                                           int W, int D, int match_similarity, void *stream)
+{
+    if (D == 0 && B > 0 && H > 0 && W > 0) return STEREO_ERR_BAD_SHAPE;  // softmax over an empty axis
+    return gwc_dispatch<EPI_ARGMIN>(left, right, disp, B, C, H, W, D, 1, match_similarity ? 1.0f : -1.0f, stream);
+}

@@ -1,0 +1,99 @@
+"""Local cost-volume re-sampling (A5/A6) behind the reference's surfaces:
+``models/LocalCostVolume/Attempts/fixed_local_cost_volume.py:13-80`` and
+``models/LocalCostVolume/Attempts/variance_local_cost_volume.py:12-99``."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _native as N
+
+
+def _vol_disp(old_cost_volume, cur_disparity, who):
+    vol = N.dev_f32(old_cost_volume, f"{who}: old_cost_volume")
+    disp = N.dev_f32(cur_disparity, f"{who}: cur_disparity")
+    if vol.dim() != 4:
+        raise ValueError(f"{who}: old_cost_volume must be [B,D,H,W]")
+    B, D, H, W = vol.shape
+    if tuple(disp.shape) != (B, 1, H, W):
+        raise ValueError(f"{who}: cur_disparity must be [B,1,H,W] = {(B, 1, H, W)}, got {tuple(disp.shape)}")
+    N.same_device(vol, disp)
+    return vol, disp
+
+
+class LocalCostVolume(nn.Module):
+    """``LocalCostVolume(radius=4, sample_points=10)`` (fixed_local_cost_volume.py:13-58)."""
+
+    def __init__(self, radius=4, sample_points=10) -> None:
+        super().__init__()
+        self.radius = radius
+        self.sample_points = sample_points
+
+    def forward(self, old_cost_volume, cur_disparity, consider_valid=False):
+        vol, disp = _vol_disp(old_cost_volume, cur_disparity, "LocalCostVolume")
+        B, D, H, W = vol.shape
+        out = torch.empty((B, 1, H, W), device=vol.device, dtype=torch.float32)
+        with torch.cuda.device(vol.device):
+            N.call("stereo_local_lookup_f32", N.ptr(vol), N.ptr(disp), N.ptr(out), B, D, H, W, float(self.radius),
+                   int(self.sample_points), 1 if consider_valid else 0, N.stream_ptr(vol.device))
+        return out
+
+
+class Variance_Based_Local_Cost_Volume(nn.Module):
+    """``Variance_Based_Local_Cost_Volume(garma=1, sample_points=10)``
+    (variance_local_cost_volume.py:28-78)."""
+
+    def __init__(self, garma=1, sample_points=10):
+        super().__init__()
+        self.sample_points = sample_points
+        self.garma = garma
+
+    def forward(self, old_cost_volume, cur_disparity, consider_valid=False):
+        vol, disp = _vol_disp(old_cost_volume, cur_disparity, "Variance_Based_Local_Cost_Volume")
+        B, D, H, W = vol.shape
+        out = torch.empty((B, 1, H, W), device=vol.device, dtype=torch.float32)
+        with torch.cuda.device(vol.device):
+            N.call("stereo_variance_lookup_f32", N.ptr(vol), N.ptr(disp), N.ptr(out), B, D, H, W, float(self.garma),
+                   int(self.sample_points), 1 if consider_valid else 0, N.stream_ptr(vol.device))
+        return out
+
+
+def build_cost_volume_from_volume(old_volume, sampling_candidates):
+    """``build_cost_volume_from_volume`` (fixed_local_cost_volume.py:61-80):
+    [B,D,H,W] x candidates [B,K,H,W] -> [B,K,H,W]."""
+    vol = N.dev_f32(old_volume, "build_cost_volume_from_volume: old_volume")
+    cand = N.dev_f32(sampling_candidates, "build_cost_volume_from_volume: sampling_candidates")
+    B, D, H, W = vol.shape
+    if cand.dim() != 4 or cand.shape[0] != B or tuple(cand.shape[2:]) != (H, W):
+        raise ValueError("build_cost_volume_from_volume: candidates must be [B,K,H,W]")
+    out = torch.empty_like(cand)
+    with torch.cuda.device(vol.device):
+        N.call("stereo_sample_volume_f32", N.ptr(vol), N.ptr(cand), N.ptr(out), B, D, H, W, int(cand.shape[1]),
+               N.stream_ptr(vol.device))
+    return out
+
+
+def bounds_lookup(old_cost_volume, cur_disp, bounds, sample_points, consider_valid=True):
+    """The A11 sampler (``Attempts/update.py:279-313``): ``bounds`` [B,2,H,W] are the
+    non-negative (lower, upper) offsets predicted by OffsetPredictionHead."""
+    vol, disp = _vol_disp(old_cost_volume, cur_disp, "bounds_lookup")
+    bounds = N.dev_f32(bounds, "bounds_lookup: bounds")
+    B, D, H, W = vol.shape
+    if tuple(bounds.shape) != (B, 2, H, W):
+        raise ValueError("bounds_lookup: bounds must be [B,2,H,W]")
+    out = torch.empty((B, 1, H, W), device=vol.device, dtype=torch.float32)
+    with torch.cuda.device(vol.device):
+        N.call("stereo_bounds_lookup_f32", N.ptr(vol), N.ptr(disp), N.ptr(bounds), N.ptr(out), B, D, H, W,
+               int(sample_points), 1 if consider_valid else 0, N.stream_ptr(vol.device))
+    return out
+
+
+def uncertainty_volume(old_cost_volume, cur_disp):
+    """``softmax(vol,1) * d * (d-disp)^2`` (``Attempts/update.py:71-72,86``) in one kernel."""
+    vol, disp = _vol_disp(old_cost_volume, cur_disp, "uncertainty_volume")
+    B, D, H, W = vol.shape
+    out = torch.empty_like(vol)
+    with torch.cuda.device(vol.device):
+        N.call("stereo_uncertainty_volume_f32", N.ptr(vol), N.ptr(disp), N.ptr(out), B, D, H, W,
+               N.stream_ptr(vol.device))
+    return out

@@ -1,0 +1,79 @@
+"""Convex / bilinear upsampling (A13) behind ``models/utils/upsample.py``,
+``RAFT_Stereo.upsample_flow`` (raft_stereo.py:110-122) and ``upflow8`` (utils/utils.py:85-87)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _native as N
+
+
+class ConvAffinityUpsample(nn.Module):
+    """``ConvAffinityUpsample`` (upsample.py:6-19): the 0.25-scaled 576-channel mask head.
+    The two convolutions stay with the host framework (MIOpen)."""
+
+    def __init__(self, input_channels, hidden_channels=128):
+        super().__init__()
+        self.upsample_mask = nn.Sequential(
+            nn.Conv2d(in_channels=input_channels, out_channels=hidden_channels, kernel_size=3, padding=1),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(hidden_channels, 8 * 8 * 9, 1, padding=0))
+
+    def forward(self, feature):
+        return .25 * self.upsample_mask(feature)
+
+
+def upsample_convex(disp, mask, factor):
+    """Convex-combination upsampling by ``factor``: disp [N,Cd,H,W], mask [N,9*f*f,H,W]."""
+    disp = N.dev_f32(disp, "upsample_convex: disp")
+    mask = N.dev_f32(mask, "upsample_convex: mask")
+    n, cd, h, w = disp.shape
+    if tuple(mask.shape) != (n, 9 * factor * factor, h, w):
+        raise RuntimeError(f"upsample_convex: mask shape {tuple(mask.shape)} is not "
+                           f"[{n},{9 * factor * factor},{h},{w}]")  # the reference's .view would fail
+    out = torch.empty((n, cd, factor * h, factor * w), device=disp.device, dtype=torch.float32)
+    with torch.cuda.device(disp.device):
+        N.call("stereo_upsample_convex_f32", N.ptr(disp), N.ptr(mask), N.ptr(out), n, cd, h, w, int(factor),
+               N.stream_ptr(disp.device))
+    return out
+
+
+def upsample_convex8(disp, mask):
+    """``upsample_convex8`` (upsample.py:22-38): [N,1,H,W] x [N,576,H,W] -> [N,1,8H,8W]."""
+    if disp.shape[1] != 1:
+        raise RuntimeError("upsample_convex8: disp must have one channel")
+    return upsample_convex(disp, mask, 8)
+
+
+def upsample_flow(flow, mask, downsample=2):
+    """``RAFT_Stereo.upsample_flow`` (raft_stereo.py:110-122) with factor 2**downsample."""
+    return upsample_convex(flow, mask, 2 ** downsample)
+
+
+def resize_bilinear(x, size, align_corners, scale=1.0):
+    """``scale * F.interpolate(x, size, mode='bilinear', align_corners=...)`` in one kernel."""
+    x = N.dev_f32(x, "resize_bilinear: x")
+    n, c, hi, wi = x.shape
+    ho, wo = int(size[0]), int(size[1])
+    out = torch.empty((n, c, ho, wo), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        N.call("stereo_resize_bilinear_f32", N.ptr(x), N.ptr(out), n * c, hi, wi, ho, wo,
+               1 if align_corners else 0, float(scale), N.stream_ptr(x.device))
+    return out
+
+
+def upsample_simple8(disp, mode="bilinear"):
+    """``upsample_simple8`` (upsample.py:41-43): 8 * bilinear x8, align_corners=True."""
+    if mode != "bilinear":
+        raise NotImplementedError
+    return resize_bilinear(disp, (8 * disp.shape[2], 8 * disp.shape[3]), True, 8.0)
+
+
+def upflow8(flow, mode="bilinear"):
+    """``upflow8`` (utils/utils.py:85-87)."""
+    return upsample_simple8(flow, mode)
+
+
+def interp(x, dest):
+    """``interp`` (update/update.py:125-127): bilinear, align_corners=True, to dest's size."""
+    return resize_bilinear(x, dest.shape[2:], True)

@@ -1,0 +1,344 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on seeded inputs,
+against the golden fixtures generated from the real reference, and -- at BASELINE.json's
+full sizes -- through size-independent identities.
+
+Tolerances (fp32 path; BASELINE north_star: disparity within 1e-3 of the reference):
+  volumes / features : 2e-5 abs     disparities : 1e-4 abs (10x inside the 1e-3 bar)
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+VOL_TOL = dict(rtol=1e-5, atol=2e-5)
+DISP_TOL = dict(rtol=0, atol=1e-4)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def close(a, b, **tol):
+    np.testing.assert_allclose(host(a) if isinstance(a, torch.Tensor) else a, b, **tol)
+
+
+@pytest.fixture(scope="module")
+def S():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    import stereoformer_amd as s
+    s._native.load()
+    return s
+
+
+# ------------------------------------------------------------------ volumes (A1/A2/A3)
+def test_volumes_golden(S, golden):
+    g = golden("g1_volumes")
+    L, R = dev(g["L"]), dev(g["R"])
+    for D in (1, 12, 40):
+        close(S.CostVolume(D, "correlation")(L, R), g[f"corr_D{D}"], **VOL_TOL)
+    for (D, G) in ((1, 4), (12, 1), (12, 4), (12, 16), (40, 2)):
+        close(S.build_gwc_volume(L, R, D, G), g[f"gwc_D{D}_G{G}"], **VOL_TOL)
+    for D in (1, 12):
+        close(S.CostVolume(D, "difference")(L, R), g[f"diff_D{D}"], rtol=0, atol=0)
+        close(S.CostVolume(D, "concat")(L, R), g[f"concat_D{D}"], rtol=0, atol=0)
+        close(S.build_concat_volume(L, R, D), g[f"concat_D{D}"], rtol=0, atol=0)
+    Lr, Rr = dev(g["L_ragged"]), dev(g["R_ragged"])
+    close(S.CostVolume(9, "correlation")(Lr, Rr), g["corr_ragged_D9"], **VOL_TOL)
+    close(S.build_gwc_volume(Lr, Rr, 9, 3), g["gwc_ragged_D9_G3"], **VOL_TOL)
+    close(S.groupwise_correlation(L, R, 4), g["gwc_D1_G4"][:, :, 0], **VOL_TOL)
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 32, 7, 300, 64, 8),     # W spans two tiles, partial second tile
+    (1, 32, 3, 960, 192, 8),    # cfg-2 row geometry
+    (1, 256, 4, 96, 24, 1),     # reference-native: 256 channels at 1/8 scale, D=24
+    (1, 6, 5, 37, 9, 3),        # ragged W (scalar path), channels/group = 2
+    (2, 12, 3, 520, 200, 4),    # D not a multiple of the chunk, multi-tile
+    (1, 8, 2, 16, 16, 2),       # D == W
+    (1, 5, 2, 33, 130, 5),      # D > W, channels/group = 1, two passes (D > 8*16)
+])
+def test_volumes_vs_oracle(S, oracle, shape):
+    B, C, H, W, D, G = shape
+    rng = np.random.default_rng(hash(shape) % 2**32)
+    L = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    R = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    close(S.CostVolume(D, "correlation")(dev(L), dev(R)), oracle.corr_volume(L, R, D), **VOL_TOL)
+    close(S.build_gwc_volume(dev(L), dev(R), D, G), oracle.gwc_volume(L, R, D, G), **VOL_TOL)
+
+
+def test_volume_errors_and_edges(S):
+    L = torch.randn(1, 6, 3, 8, device="cuda")
+    with pytest.raises(NotImplementedError):
+        S.CostVolume(4, "concated")(L, L)            # build_cost_volume.py:49-50
+    with pytest.raises(AssertionError):
+        S.build_gwc_volume(L, L, 4, 4)               # GWC_Cost_Volume.py:7
+    with pytest.raises(RuntimeError):
+        S.CostVolume(4)(L.cpu(), L.cpu())            # no CPU fallback
+    with pytest.raises(TypeError):
+        S.CostVolume(4)(L.double(), L.double())
+    e = torch.empty(0, 6, 3, 8, device="cuda")
+    assert S.CostVolume(4)(e, e).shape == (0, 4, 3, 8)
+    assert S.build_gwc_volume(e, e, 4, 2).shape == (0, 2, 4, 3, 8)
+    # non-contiguous inputs are accepted like in the reference
+    Lt = torch.randn(1, 3, 8, 6, device="cuda").permute(0, 3, 1, 2)
+    v = S.CostVolume(2)(Lt, Lt)
+    v2 = S.CostVolume(2)(Lt.contiguous(), Lt.contiguous())
+    assert torch.equal(v, v2)
+
+
+# ------------------------------------------------------------------ soft-argmin (A4)
+def test_soft_argmin_golden(S, golden):
+    g = golden("g2_soft_argmin")
+    vol = dev(g["vol"])
+    close(S.DisparityEstimation(12, True)(vol), g["disp_sim"], **DISP_TOL)
+    close(S.DisparityEstimation(12, False)(vol), g["disp_cost"], **DISP_TOL)
+    close(S.DisparityEstimation(48, True)(vol), g["disp_other_maxdisp"], **DISP_TOL)
+    d, p = S.DisparityEstimationWithProb(12, True)(vol)
+    close(d, g["disp_withprob"], **DISP_TOL)
+    close(p, g["prob"], rtol=0, atol=2e-6)
+    close(S.DisparityEstimation(24, True)(dev(g["vol_big"])), g["disp_big"], **DISP_TOL)
+    close(S.disparity_regression(dev(g["prob"]), 12), g["disp_withprob"], **DISP_TOL)
+    with pytest.raises(AssertionError):
+        S.DisparityEstimation(12)(vol[0])            # estimation.py:15
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 9, 40), (1, 192, 5, 37), (3, 7, 1, 5), (1, 1, 4, 4)])
+def test_soft_argmin_vs_oracle(S, oracle, shape):
+    rng = np.random.default_rng(7)
+    vol = (4.0 * rng.standard_normal(shape)).astype(np.float32)
+    for sim in (True, False):
+        close(S.DisparityEstimation(shape[1], sim)(dev(vol)), oracle.soft_argmin(vol, sim), **DISP_TOL)
+    d, p = S.DisparityEstimationWithProb(shape[1])(dev(vol))
+    od, op = oracle.soft_argmin(vol, True, with_prob=True)
+    close(d, od, **DISP_TOL)
+    close(p, op, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 24, 5, 40), (1, 3, 10, 3, 37), (1, 4, 192, 2, 64)])
+def test_group_mean_soft_argmin(S, oracle, shape):
+    rng = np.random.default_rng(11)
+    vg = (3.0 * rng.standard_normal(shape)).astype(np.float32)
+    mean = oracle.group_mean(vg)
+    d, m = S.group_mean_soft_argmin(dev(vg), return_mean=True)
+    close(m, mean, **VOL_TOL)
+    close(d, oracle.soft_argmin(mean), **DISP_TOL)
+    close(S.group_mean_soft_argmin(dev(vg), match_similarity=False), oracle.soft_argmin(mean, False), **DISP_TOL)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 5, 300, 64), (1, 32, 2, 960, 192), (1, 6, 3, 37, 9), (1, 8, 2, 40, 200)])
+def test_fused_corr_soft_argmin(S, oracle, shape):
+    B, C, H, W, D = shape
+    rng = np.random.default_rng(13)
+    L = rng.standard_normal((B, C, H, W), dtype=np.float32) * 2
+    R = rng.standard_normal((B, C, H, W), dtype=np.float32) * 2
+    ref = oracle.soft_argmin(oracle.corr_volume(L, R, D))
+    close(S.corr_soft_argmin(dev(L), dev(R), D), ref, **DISP_TOL)
+    two_step = S.DisparityEstimation(D)(S.CostVolume(D)(dev(L), dev(R)))
+    close(S.corr_soft_argmin(dev(L), dev(R), D), host(two_step), **DISP_TOL)
+    refc = oracle.soft_argmin(oracle.corr_volume(L, R, D), False)
+    close(S.corr_soft_argmin(dev(L), dev(R), D, match_similarity=False), refc, **DISP_TOL)
+
+
+# ------------------------------------------------------------------ local lookups (A5/A6/A11 sampler)
+def test_local_lookup_golden(S, golden):
+    g = golden("g3_local_lookup")
+    vol, disp = dev(g["vol"]), dev(g["disp"])
+    for (r, s) in ((2, 20), (4, 10), (2.1, 20)):
+        for cv in (False, True):
+            close(S.LocalCostVolume(r, s)(vol, disp, cv), g[f"fixed_r{r}_S{s}_cv{int(cv)}"], **DISP_TOL)
+    for (gm, s) in ((1, 10), (0.5, 20)):
+        for cv in (False, True):
+            close(S.Variance_Based_Local_Cost_Volume(gm, s)(vol, disp, cv), g[f"var_g{gm}_S{s}_cv{int(cv)}"],
+                  rtol=0, atol=2e-4)
+    close(S.build_cost_volume_from_volume(vol, dev(g["cand"])), g["sampled"], **VOL_TOL)
+
+
+def test_local_lookup_vs_oracle(S, oracle):
+    rng = np.random.default_rng(17)
+    B, D, H, W = 2, 64, 11, 53
+    vol = (2.0 * rng.standard_normal((B, D, H, W))).astype(np.float32)
+    disp = (rng.random((B, 1, H, W)) * (D - 1)).astype(np.float32)
+    for cv in (False, True):
+        close(S.LocalCostVolume(2, 20)(dev(vol), dev(disp), cv), oracle.local_lookup(vol, disp, 2.0, 20, cv),
+              **DISP_TOL)
+        close(S.Variance_Based_Local_Cost_Volume(1, 10)(dev(vol), dev(disp), cv),
+              oracle.variance_lookup(vol, disp, 1.0, 10, cv), rtol=0, atol=2e-4)
+        lo = rng.random((B, 1, H, W)).astype(np.float32) * 3
+        up = rng.random((B, 1, H, W)).astype(np.float32) * 3
+        bounds = np.concatenate([lo, up], 1)
+        close(S.bounds_lookup(dev(vol), dev(disp), dev(bounds), 20, cv),
+              oracle.bounds_lookup(vol, disp, lo, up, 20, cv), **DISP_TOL)
+    close(S.uncertainty_volume(dev(vol), dev(disp)), oracle.uncertainty_volume(vol, disp), rtol=1e-4, atol=2e-4)
+
+
+def test_identity_i5_invalid_pixels_return_input(S):
+    D = 24
+    vol = torch.randn(1, D, 8, 16, device="cuda")
+    disp = torch.rand(1, 1, 8, 16, device="cuda") * (D - 1)
+    out = S.LocalCostVolume(2, 20)(vol, disp, True)
+    invalid = (disp - 2 < 0) | (disp + 2 >= D - 1)
+    assert invalid.any()
+    assert (out[invalid] - disp[invalid]).abs().max().item() < 1e-5
+
+
+# ------------------------------------------------------------------ RAFT correlation (A8/A9/A10)
+def test_raft_corr_golden(S, golden):
+    g = golden("g4_raft_corr")
+    f1, f2, coords = dev(g["f1"]), dev(g["f2"]), dev(g["coords"])
+    B, C, H, W = g["f1"].shape
+    close(S.CorrBlock1D.corr(f1, f2).reshape(B, H, W, W), g["allpairs"], **VOL_TOL)
+    blk = S.CorrBlock1D(f1, f2, num_levels=4, radius=4)
+    assert len(blk.corr_pyramid) == 5
+    for i, lv in enumerate(blk.corr_pyramid):
+        close(lv.reshape(B * H * W, -1), g[f"pyr{i}"], **VOL_TOL)
+    close(blk(coords), g["lookup_r4_l4"], **VOL_TOL)
+    close(S.CorrBlock1D(f1, f2, num_levels=2, radius=3)(coords), g["lookup_r3_l2"], **VOL_TOL)
+    close(S.PytorchAlternateCorrBlock1D(f1, f2, 4, 4)(coords), g["alt_lookup_r4_l4"], rtol=1e-4, atol=1e-4)
+    close(S.coords_grid(2, 3, 4, device="cuda"), g["coords_grid_3x4"], rtol=0, atol=0)
+    s, m = S.bilinear_sampler(dev(g["bs_img"]), dev(g["bs_coords"]), mask=True)
+    close(s, g["bs_out"], **VOL_TOL)
+    close(m, g["bs_mask"], rtol=0, atol=0)
+    with pytest.raises(NotImplementedError):
+        S.AlternateCorrBlock(f1, f2)
+
+
+@pytest.mark.parametrize("shape", [(1, 256, 3, 240), (2, 31, 2, 150), (1, 64, 1, 33)])
+def test_allpairs_vs_oracle(S, oracle, shape):
+    B, C, H, W = shape
+    rng = np.random.default_rng(19)
+    f1 = rng.standard_normal(shape, dtype=np.float32)
+    f2 = rng.standard_normal(shape, dtype=np.float32)
+    ap = oracle.allpairs_corr(f1, f2)
+    blk = S.CorrBlock1D(dev(f1), dev(f2), num_levels=4, radius=4)
+    pyr = oracle.corr_pyramid(ap, 4)
+    for i in range(5):
+        close(blk.corr_pyramid[i].reshape(pyr[i].shape), pyr[i], rtol=1e-5, atol=5e-5)
+    if W >> 3 >= 2:
+        coords = np.stack([np.tile(np.arange(W, dtype=np.float32), (H, 1)) - rng.random((H, W)).astype(np.float32) * 20,
+                           np.zeros((H, W), np.float32)], 0)[None].repeat(B, 0)
+        close(blk(dev(coords)), oracle.corr_lookup(pyr, coords, 4, 4), rtol=1e-5, atol=5e-5)
+
+
+# ------------------------------------------------------------------ warp / upsample (A12/A13)
+def test_disp_warp_golden(S, golden):
+    g = golden("g6_disp_warp")
+    for pm in ("border", "zeros"):
+        w, m = S.disp_warp(dev(g["img"]), dev(g["disp"]), pm)
+        close(w, g[f"warped_{pm}"], **VOL_TOL)
+        assert (host(m) != g[f"mask_{pm}"]).mean() < 0.01
+
+
+def test_upsample_golden(S, golden, oracle):
+    g = golden("g7_upsample")
+    close(S.upsample_convex8(dev(g["disp"]), dev(g["mask8"])), g["up8"], **VOL_TOL)
+    close(S.upsample_flow(dev(g["flow"]), dev(g["mask4"]), 2), g["upflow4"], **VOL_TOL)
+    close(S.upsample_simple8(dev(g["disp"])), g["simple8"], **VOL_TOL)
+    close(S.upflow8(dev(np.concatenate([g["disp"], -g["disp"]], 1))), g["upflow8"], **VOL_TOL)
+    # wider than one 64-pixel tile, two channels, factor 8 and a generic factor
+    rng = np.random.default_rng(23)
+    d = rng.random((1, 2, 3, 150)).astype(np.float32) * 30
+    for f in (8, 4, 3):
+        mk = rng.standard_normal((1, 9 * f * f, 3, 150)).astype(np.float32)
+        close(S.upsample_convex(dev(d), dev(mk), f), oracle.upsample_convex(d, mk, f), **VOL_TOL)
+
+
+def test_resize_vs_oracle(S, oracle, golden):
+    g = golden("g5_gru_updater")
+    h, w = g["disp0"].shape[2:]
+    close(S.resize_bilinear(dev(g["left"]), (h, w), False), g["left_small"], **VOL_TOL)
+    x = np.random.default_rng(5).standard_normal((2, 3, 9, 14)).astype(np.float32)
+    close(S.resize_bilinear(dev(x), (18, 28), True), oracle.resize_bilinear(x, (18, 28), True), **VOL_TOL)
+    close(S.resize_bilinear(dev(x), (5, 9), False), oracle.resize_bilinear(x, (5, 9), False), **VOL_TOL)
+
+
+# ------------------------------------------------------------------ cross-attention (A7, build-defined)
+@pytest.mark.parametrize("cfg", [(2, 16, 5, 40, 12), (1, 32, 3, 200, 192), (1, 48, 2, 70, 33)])
+def test_cross_attention(S, oracle, cfg):
+    B, C, H, W, D = cfg
+    rng = np.random.default_rng(29)
+    L = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    R = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    V = rng.standard_normal((B, 20, H, W), dtype=np.float32)
+    for mask in ("zero", "neginf"):
+        for scale in ("sqrt_c", "mean"):
+            o, d = S.CrossAttentionCostVolume(D, mask, scale)(dev(L), dev(R), dev(V))
+            oo, od = oracle.cross_attention(L, R, V, D, mask, scale)
+            close(o, oo, rtol=1e-4, atol=5e-5)
+            close(d, od, **DISP_TOL)
+    # I3: mask='zero', scale='mean' reproduces CostVolume + DisparityEstimation of the HIP path itself
+    _, d = S.CrossAttentionCostVolume(D, "zero", "mean")(dev(L), dev(R), need_out=False)
+    close(d, host(S.DisparityEstimation(D)(S.CostVolume(D)(dev(L), dev(R)))), **DISP_TOL)
+
+
+# ------------------------------------------------------------------ GRU gate math
+def test_gru_pointwise(S, oracle):
+    from stereoformer_amd import _native as N
+    rng = np.random.default_rng(31)
+    for n in (1000, 1023):
+        a = [rng.standard_normal(n).astype(np.float32) * 2 for _ in range(5)]
+        h, zc, qc, cz, cq = [dev(x) for x in a]
+        out = torch.empty_like(h)
+        N.call("stereo_gru_blend_f32", N.ptr(h), N.ptr(zc), N.ptr(qc), N.ptr(cz), N.ptr(cq), N.ptr(out), n,
+               N.stream_ptr())
+        close(out, oracle.gru_blend(*a), rtol=1e-5, atol=2e-6)
+        N.call("stereo_gru_blend_f32", N.ptr(h), N.ptr(zc), N.ptr(qc), N.ptr(None), N.ptr(None), N.ptr(out), n,
+               N.stream_ptr())
+        close(out, oracle.gru_blend(a[0], a[1], a[2]), rtol=1e-5, atol=2e-6)
+        N.call("stereo_gru_reset_f32", N.ptr(h), N.ptr(zc), N.ptr(cz), N.ptr(out), n, N.stream_ptr())
+        close(out, oracle.gru_reset(a[0], a[1], a[3]), rtol=1e-5, atol=2e-6)
+
+
+# ------------------------------------------------------------------ BASELINE configs
+def test_cfg1_chain_vs_oracle(S, oracle):
+    """configs[0]: 1 pair 384x768 D=64: corr -> soft-argmin -> LocalCostVolume(r=2,S=20,consider_valid)."""
+    g = torch.Generator().manual_seed(0)
+    L = torch.randn(1, 32, 384, 768, generator=g)
+    R = torch.randn(1, 32, 384, 768, generator=g)
+    vol = S.CostVolume(64)(L.cuda(), R.cuda())
+    disp = S.DisparityEstimation(64)(vol)
+    d2 = S.LocalCostVolume(2, 20)(vol, disp.unsqueeze(1), True)
+    ovol = oracle.corr_volume(L.numpy(), R.numpy(), 64)
+    odisp = oracle.soft_argmin(ovol)
+    od2 = oracle.local_lookup(ovol, odisp[:, None], 2.0, 20, True)
+    close(vol, ovol, **VOL_TOL)
+    close(disp, odisp, rtol=0, atol=1e-3)   # the north-star bar; measured ~1e-4
+    assert np.abs(host(disp) - odisp).mean() < 1e-4
+    close(d2, od2, rtol=0, atol=1e-3)
+
+
+def test_cfg2_full_size_identities(S, oracle):
+    """configs[1] at full size (B=8, 960x540, D=192, G=8): the 25.5 GB group-wise volume is
+    checked through identities (I1 group-mean == correlation volume, fused == two-step) and
+    against the oracle on three full rows."""
+    B, C, H, W, D, G = 8, 32, 540, 960, 192, 8
+    g = torch.Generator(device="cuda").manual_seed(1)
+    L = torch.randn(B, C, H, W, device="cuda", generator=g)
+    R = torch.randn(B, C, H, W, device="cuda", generator=g)
+    volg = S.build_gwc_volume(L, R, D, G)
+    assert volg.shape == (B, G, D, H, W)
+    disp_g, mean = S.group_mean_soft_argmin(volg, return_mean=True)
+    rows = [0, 269, 539]
+    for b in (0, 7):
+        Ls, Rs = host(L[b:b + 1, :, rows]), host(R[b:b + 1, :, rows])
+        close(volg[b:b + 1, :, :, rows], oracle.gwc_volume(Ls, Rs, D, G), **VOL_TOL)
+        close(disp_g[b:b + 1, rows], oracle.soft_argmin(oracle.corr_volume(Ls, Rs, D)), rtol=0, atol=1e-3)
+    del volg
+    corr = S.CostVolume(D)(L, R)
+    assert (corr - mean).abs().max().item() < 2e-5          # I1
+    del mean
+    # zero fill where w < d
+    assert corr[:, 100, :, :100].abs().max().item() == 0.0
+    disp = S.DisparityEstimation(D)(corr)
+    assert (disp - disp_g).abs().max().item() < 1e-3
+    fused = S.corr_soft_argmin(L, R, D)
+    assert (fused - disp).abs().max().item() < 1e-3
+    assert (fused - disp).abs().mean().item() < 1e-4
+    d2 = S.LocalCostVolume(2, 20)(corr, disp.unsqueeze(1), True)
+    assert torch.isfinite(d2).all()
+    close(d2[0:1, :, rows], oracle.local_lookup(host(corr[0:1, :, rows]), host(disp[0:1, None, rows]), 2.0, 20, True),
+          **DISP_TOL)
