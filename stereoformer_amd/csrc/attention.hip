@@ -103,13 +103,13 @@ extern "C" int stereo_cross_attention_f32(const float *left, const float *right,
                                           float *disp, int B, int C, int Cv, int H, int W, int D, int mask_mode,
                                           int scale_mode, void *stream)
 {
-    STEREO_REQUIRE_PTR(left);
-    STEREO_REQUIRE_PTR(right);
-    if (out) STEREO_REQUIRE_PTR(value);
     if (B < 0 || C < 0 || Cv < 0 || H < 0 || W < 0 || D < 0) return STEREO_ERR_BAD_SHAPE;
     if (mask_mode != STEREO_MASK_ZERO && mask_mode != STEREO_MASK_NEGINF) return STEREO_ERR_BAD_SHAPE;
     if (scale_mode != STEREO_SCALE_SQRT_C && scale_mode != STEREO_SCALE_MEAN) return STEREO_ERR_BAD_SHAPE;
     if (B == 0 || H == 0 || W == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(left);
+    STEREO_REQUIRE_PTR(right);
+    if (out) STEREO_REQUIRE_PTR(value);
     if (D == 0 || C == 0) return STEREO_ERR_BAD_SHAPE;
     if (!fits_grid_yz(H) || !fits_grid_yz(B)) return STEREO_ERR_UNSUPPORTED;
     const int Dpad = (D + 3) / 4 * 4;

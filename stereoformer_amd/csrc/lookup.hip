@@ -145,12 +145,12 @@ template <int MODE>
 int lookup_dispatch(const float *vol, const float *disp, const float *bounds, float *out, int B, int D, int H, int W,
                     float param, int S, int consider_valid, void *stream)
 {
+    if (B < 0 || D < 0 || H < 0 || W < 0 || S <= 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0) return STEREO_OK;
     STEREO_REQUIRE_PTR(vol);
     STEREO_REQUIRE_PTR(disp);
     STEREO_REQUIRE_PTR(out);
     if (MODE == MODE_BOUNDS) STEREO_REQUIRE_PTR(bounds);
-    if (B < 0 || D < 0 || H < 0 || W < 0 || S <= 0) return STEREO_ERR_BAD_SHAPE;
-    if (B == 0 || H == 0 || W == 0) return STEREO_OK;
     if (D == 0) return STEREO_ERR_BAD_SHAPE;
     const long long HW = (long long)H * W, n = (long long)B * HW;
     hipLaunchKernelGGL(lookup_kernel<MODE>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), vol, disp, bounds, out,
@@ -182,11 +182,11 @@ extern "C" int stereo_bounds_lookup_f32(const float *vol, const float *disp, con
 extern "C" int stereo_sample_volume_f32(const float *vol, const float *cand, float *out, int B, int D, int H, int W,
                                         int K, void *stream)
 {
+    if (B < 0 || D < 0 || H < 0 || W < 0 || K < 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0 || K == 0) return STEREO_OK;
     STEREO_REQUIRE_PTR(vol);
     STEREO_REQUIRE_PTR(cand);
     STEREO_REQUIRE_PTR(out);
-    if (B < 0 || D < 0 || H < 0 || W < 0 || K < 0) return STEREO_ERR_BAD_SHAPE;
-    if (B == 0 || H == 0 || W == 0 || K == 0) return STEREO_OK;
     if (D == 0) return STEREO_ERR_BAD_SHAPE;
     const long long HW = (long long)H * W, n = (long long)B * K * HW;
     hipLaunchKernelGGL(sample_volume_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), vol, cand, out, D, K,
@@ -198,11 +198,11 @@ extern "C" int stereo_sample_volume_f32(const float *vol, const float *cand, flo
 extern "C" int stereo_uncertainty_volume_f32(const float *vol, const float *disp, float *out, int B, int D, int H,
                                              int W, void *stream)
 {
+    if (B < 0 || D < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0 || D == 0) return STEREO_OK;
     STEREO_REQUIRE_PTR(vol);
     STEREO_REQUIRE_PTR(disp);
     STEREO_REQUIRE_PTR(out);
-    if (B < 0 || D < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
-    if (B == 0 || H == 0 || W == 0 || D == 0) return STEREO_OK;
     const long long HW = (long long)H * W, n = (long long)B * HW;
     hipLaunchKernelGGL(uncertainty_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), vol, disp, out, D, HW,
                        n);

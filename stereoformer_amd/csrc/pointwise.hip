@@ -55,11 +55,11 @@ inline unsigned grid_for(long long nthreads)
 extern "C" int stereo_gru_reset_f32(const float *h, const float *rc, const float *cr, float *out, long long n,
                                     void *stream)
 {
+    if (n < 0) return STEREO_ERR_BAD_SHAPE;
+    if (n == 0) return STEREO_OK;
     STEREO_REQUIRE_PTR(h);
     STEREO_REQUIRE_PTR(rc);
     STEREO_REQUIRE_PTR(out);
-    if (n < 0) return STEREO_ERR_BAD_SHAPE;
-    if (n == 0) return STEREO_OK;
     if (n % 4 == 0)
         hipLaunchKernelGGL(gru_reset_kernel<4>, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(stream), h, rc, cr, out,
                            n / 4);
@@ -72,12 +72,12 @@ extern "C" int stereo_gru_reset_f32(const float *h, const float *rc, const float
 extern "C" int stereo_gru_blend_f32(const float *h, const float *zc, const float *qc, const float *cz, const float *cq,
                                     float *out, long long n, void *stream)
 {
+    if (n < 0) return STEREO_ERR_BAD_SHAPE;
+    if (n == 0) return STEREO_OK;
     STEREO_REQUIRE_PTR(h);
     STEREO_REQUIRE_PTR(zc);
     STEREO_REQUIRE_PTR(qc);
     STEREO_REQUIRE_PTR(out);
-    if (n < 0) return STEREO_ERR_BAD_SHAPE;
-    if (n == 0) return STEREO_OK;
     if (n % 4 == 0)
         hipLaunchKernelGGL(gru_blend_kernel<4>, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(stream), h, zc, qc, cz,
                            cq, out, n / 4);

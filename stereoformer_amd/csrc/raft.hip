@@ -172,12 +172,12 @@ __global__ __launch_bounds__(256) void alt_corr_lookup_kernel(const float *__res
 extern "C" int stereo_allpairs_pyramid_f32(const float *fmap1, const float *fmap2, float *const *levels, int B, int C,
                                            int H, int W1, int W2, int num_levels, void *stream)
 {
-    STEREO_REQUIRE_PTR(fmap1);
-    STEREO_REQUIRE_PTR(fmap2);
-    STEREO_REQUIRE_PTR(levels);
     if (B < 0 || C < 0 || H < 0 || W1 < 0 || W2 < 0 || num_levels < 0) return STEREO_ERR_BAD_SHAPE;
     if (num_levels + 1 > STEREO_MAX_LEVELS) return STEREO_ERR_UNSUPPORTED;
     if (B == 0 || H == 0 || W1 == 0 || W2 == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(fmap1);
+    STEREO_REQUIRE_PTR(fmap2);
+    STEREO_REQUIRE_PTR(levels);
     for (int i = 0, w = W2; i <= num_levels; ++i, w /= 2)
         if (w > 0) STEREO_REQUIRE_PTR(levels[i]);
     if (!fits_grid_yz((long long)B * H) || !fits_grid_yz((W1 + 127) / 128)) return STEREO_ERR_UNSUPPORTED;
@@ -202,12 +202,12 @@ extern "C" int stereo_allpairs_pyramid_f32(const float *fmap1, const float *fmap
 extern "C" int stereo_corr_lookup_f32(const float *const *levels, const float *coords, float *out, int B, int H, int W1,
                                       int W2, int num_levels, int radius, void *stream)
 {
-    STEREO_REQUIRE_PTR(levels);
-    STEREO_REQUIRE_PTR(coords);
-    STEREO_REQUIRE_PTR(out);
     if (B < 0 || H < 0 || W1 < 0 || W2 < 0 || num_levels < 0 || radius < 0) return STEREO_ERR_BAD_SHAPE;
     if (num_levels > STEREO_MAX_LEVELS) return STEREO_ERR_UNSUPPORTED;
     if (B == 0 || H == 0 || W1 == 0 || num_levels == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(levels);
+    STEREO_REQUIRE_PTR(coords);
+    STEREO_REQUIRE_PTR(out);
     LevelPtrs lv;
     for (int i = 0, w = W2; i < num_levels; ++i, w /= 2) {
         if (w < 2) return STEREO_ERR_UNSUPPORTED;  // 2x/(W-1) is undefined (reference yields NaN/inf)
@@ -236,13 +236,13 @@ extern "C" int stereo_alt_corr_lookup_f32(const float *fmap1, const float *fmap2
                                           float *workspace, int B, int C, int H, int W, int num_levels, int radius,
                                           void *stream)
 {
+    if (B < 0 || C < 0 || H < 0 || W < 0 || num_levels < 0 || radius < 0) return STEREO_ERR_BAD_SHAPE;
+    if (num_levels > STEREO_MAX_LEVELS) return STEREO_ERR_UNSUPPORTED;
+    if (B == 0 || H == 0 || W == 0 || num_levels == 0) return STEREO_OK;
     STEREO_REQUIRE_PTR(fmap1);
     STEREO_REQUIRE_PTR(fmap2);
     STEREO_REQUIRE_PTR(coords);
     STEREO_REQUIRE_PTR(out);
-    if (B < 0 || C < 0 || H < 0 || W < 0 || num_levels < 0 || radius < 0) return STEREO_ERR_BAD_SHAPE;
-    if (num_levels > STEREO_MAX_LEVELS) return STEREO_ERR_UNSUPPORTED;
-    if (B == 0 || H == 0 || W == 0 || num_levels == 0) return STEREO_OK;
     if (num_levels > 1 && stereo_alt_corr_workspace_floats(B, C, H, W, num_levels) > 0) STEREO_REQUIRE_PTR(workspace);
     hipStream_t st = as_stream(stream);
     LevelPtrs lv;

@@ -202,10 +202,10 @@ inline unsigned grid_for(long long nthreads)
 extern "C" int stereo_soft_argmin_f32(const float *vol, float *disp, float *prob, int B, int D, int H, int W,
                                       int match_similarity, void *stream)
 {
-    STEREO_REQUIRE_PTR(vol);
-    STEREO_REQUIRE_PTR(disp);
     if (B < 0 || D < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
     if (B == 0 || H == 0 || W == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(vol);
+    STEREO_REQUIRE_PTR(disp);
     if (D == 0) return STEREO_ERR_BAD_SHAPE;  // softmax over an empty axis
     const long long HW = (long long)H * W;
     const float sgn = match_similarity ? 1.0f : -1.0f;
@@ -235,10 +235,10 @@ extern "C" int stereo_soft_argmin_f32(const float *vol, float *disp, float *prob
 extern "C" int stereo_group_mean_soft_argmin_f32(const float *volg, float *vol_mean, float *disp, int B, int G, int D,
                                                  int H, int W, int match_similarity, void *stream)
 {
-    STEREO_REQUIRE_PTR(volg);
-    STEREO_REQUIRE_PTR(disp);
     if (B < 0 || G <= 0 || D < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
     if (B == 0 || H == 0 || W == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(volg);
+    STEREO_REQUIRE_PTR(disp);
     if (D == 0) return STEREO_ERR_BAD_SHAPE;
     const long long HW = (long long)H * W;
     const float sgn = match_similarity ? 1.0f : -1.0f;
@@ -269,10 +269,10 @@ extern "C" int stereo_group_mean_soft_argmin_f32(const float *volg, float *vol_m
 
 extern "C" int stereo_disparity_regression_f32(const float *x, float *out, int B, int D, int H, int W, void *stream)
 {
-    STEREO_REQUIRE_PTR(x);
-    STEREO_REQUIRE_PTR(out);
     if (B < 0 || D < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
     if (B == 0 || H == 0 || W == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(x);
+    STEREO_REQUIRE_PTR(out);
     const long long HW = (long long)H * W;
     hipStream_t st = as_stream(stream);
     if ((HW % 4 == 0) && aligned16(x) && aligned16(out)) {

@@ -218,15 +218,15 @@ template <int EPI>
 int gwc_dispatch(const float *L, const float *R, float *vol, int B, int C, int H, int W, int D, int G, float sgn,
                  void *stream)
 {
-    STEREO_REQUIRE_PTR(L);
-    STEREO_REQUIRE_PTR(R);
-    STEREO_REQUIRE_PTR(vol);
     if (B < 0 || C < 0 || H < 0 || W < 0 || D < 0 || G <= 0) return STEREO_ERR_BAD_SHAPE;
     if (C % G != 0) return STEREO_ERR_BAD_SHAPE;  // GWC_Cost_Volume.py:7
     if (B == 0 || C == 0 || H == 0 || W == 0 || D == 0) {
         // C == 0 with D > 0: mean over nothing; the reference would give NaN.  Not a use case.
         return C == 0 && B && H && W && D ? STEREO_ERR_BAD_SHAPE : STEREO_OK;
     }
+    STEREO_REQUIRE_PTR(L);
+    STEREO_REQUIRE_PTR(R);
+    STEREO_REQUIRE_PTR(vol);
     if (!fits_grid_yz(H) || !fits_grid_yz((long long)B * G)) return STEREO_ERR_UNSUPPORTED;
     if (D > 4096) return STEREO_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);
@@ -278,11 +278,11 @@ __global__ __launch_bounds__(256) void shift_volume_kernel(const float *__restri
 template <bool CONCAT>
 int shift_dispatch(const float *L, const float *R, float *vol, int B, int C, int H, int W, int D, void *stream)
 {
+    if (B < 0 || C < 0 || H < 0 || W < 0 || D < 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || C == 0 || H == 0 || W == 0 || D == 0) return STEREO_OK;
     STEREO_REQUIRE_PTR(L);
     STEREO_REQUIRE_PTR(R);
     STEREO_REQUIRE_PTR(vol);
-    if (B < 0 || C < 0 || H < 0 || W < 0 || D < 0) return STEREO_ERR_BAD_SHAPE;
-    if (B == 0 || C == 0 || H == 0 || W == 0 || D == 0) return STEREO_OK;
     const long long nquads = (long long)B * (CONCAT ? 2 * C : C) * D * H * ((W + 3) / 4);
     long long blocks = (nquads + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;

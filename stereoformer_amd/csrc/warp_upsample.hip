@@ -265,11 +265,11 @@ __global__ __launch_bounds__(256) void bilinear_sampler_kernel(const float *__re
 extern "C" int stereo_disp_warp_f32(const float *img, const float *disp, float *warped, float *mask, int B, int Ci,
                                     int H, int W, int padding_border, void *stream)
 {
+    if (B < 0 || Ci < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || Ci == 0 || H == 0 || W == 0) return STEREO_OK;
     STEREO_REQUIRE_PTR(img);
     STEREO_REQUIRE_PTR(disp);
     STEREO_REQUIRE_PTR(warped);
-    if (B < 0 || Ci < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
-    if (B == 0 || Ci == 0 || H == 0 || W == 0) return STEREO_OK;
     const long long n = (long long)B * H * W;
     hipLaunchKernelGGL(disp_warp_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), img, disp, warped, mask,
                        Ci, H, W, n, padding_border);
@@ -280,11 +280,11 @@ extern "C" int stereo_disp_warp_f32(const float *img, const float *disp, float *
 extern "C" int stereo_upsample_convex_f32(const float *disp, const float *mask, float *out, int N, int Cd, int H, int W,
                                           int f, void *stream)
 {
+    if (N < 0 || Cd < 0 || H < 0 || W < 0 || f <= 0) return STEREO_ERR_BAD_SHAPE;
+    if (N == 0 || Cd == 0 || H == 0 || W == 0) return STEREO_OK;
     STEREO_REQUIRE_PTR(disp);
     STEREO_REQUIRE_PTR(mask);
     STEREO_REQUIRE_PTR(out);
-    if (N < 0 || Cd < 0 || H < 0 || W < 0 || f <= 0) return STEREO_ERR_BAD_SHAPE;
-    if (N == 0 || Cd == 0 || H == 0 || W == 0) return STEREO_OK;
     hipStream_t st = as_stream(stream);
     const bool tiled = fits_grid_yz(H) && fits_grid_yz(N);
     dim3 grid((W + XT - 1) / XT, H, N);
@@ -308,10 +308,10 @@ extern "C" int stereo_upsample_convex_f32(const float *disp, const float *mask, 
 extern "C" int stereo_resize_bilinear_f32(const float *in, float *out, int NC, int Hi, int Wi, int Ho, int Wo,
                                           int align_corners, float scale, void *stream)
 {
-    STEREO_REQUIRE_PTR(in);
-    STEREO_REQUIRE_PTR(out);
     if (NC < 0 || Hi < 0 || Wi < 0 || Ho < 0 || Wo < 0) return STEREO_ERR_BAD_SHAPE;
     if (NC == 0 || Ho == 0 || Wo == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(in);
+    STEREO_REQUIRE_PTR(out);
     if (Hi == 0 || Wi == 0) return STEREO_ERR_BAD_SHAPE;
     float rh, rw;
     if (align_corners) {
@@ -331,11 +331,11 @@ extern "C" int stereo_resize_bilinear_f32(const float *in, float *out, int NC, i
 extern "C" int stereo_bilinear_sampler_f32(const float *img, const float *coords, float *out, float *mask, int N, int C,
                                            int H, int W, int Ho, int Wo, void *stream)
 {
+    if (N < 0 || C < 0 || H < 0 || W < 0 || Ho < 0 || Wo < 0) return STEREO_ERR_BAD_SHAPE;
+    if (N == 0 || Ho == 0 || Wo == 0) return STEREO_OK;
     STEREO_REQUIRE_PTR(img);
     STEREO_REQUIRE_PTR(coords);
     STEREO_REQUIRE_PTR(out);
-    if (N < 0 || C < 0 || H < 0 || W < 0 || Ho < 0 || Wo < 0) return STEREO_ERR_BAD_SHAPE;
-    if (N == 0 || Ho == 0 || Wo == 0) return STEREO_OK;
     if (H == 0 || W == 0) return STEREO_ERR_BAD_SHAPE;
     const long long npts = (long long)N * Ho * Wo;
     hipLaunchKernelGGL(bilinear_sampler_kernel, dim3(grid_for(npts)), dim3(256), 0, as_stream(stream), img, coords, out,
