@@ -117,6 +117,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     import stereoformer_amd as S
+    from stereoformer_amd import shard
 
     S._native.load()
     lookup = S.LocalCostVolume(radius=2, sample_points=20)
@@ -151,20 +152,15 @@ def main():
         out = step(i)
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(elapsed, device=device)
 
     build_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     read_ms = sum(a.elapsed_time(b) for a, b in ev_read) / args.steps
 
     # one RCCL gather of the disparity shards (the only data collective; outside the timed region)
-    checksum = float(out.double().sum().item())
-    if world > 1:
-        shards = [torch.empty_like(out) for _ in range(world)]
-        dist.all_gather(shards, out)
-        checksum = float(sum(s.double().sum().item() for s in shards))
+    gathered = shard.gather_pairs(out, world * B_PER_GPU)
+    assert gathered.shape[0] == world * B_PER_GPU
+    checksum = float(gathered.double().sum().item())
 
     # secondary, untimed-in-`value` numbers: the fused no-materialisation path
     fused_ms = None
@@ -182,6 +178,12 @@ def main():
     if rank == 0:
         n_pix = B_PER_GPU * H * W
         gwc_bytes = 2 * n_pix * C * 4 + n_pix * G * D * 4  # 26.54 GB
+        traffic = None  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+            traffic = pmc["kernels"]["gwc_volume_kernel<24, true, 0>"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         achieved = gwc_bytes / (build_ms * 1e-3) / 1e9
         pairs = world * B_PER_GPU * args.steps
         res = {
@@ -203,7 +205,7 @@ def main():
                        "pairs_per_gpu": B_PER_GPU, "parallelism": f"pairs sharded over {world} GPU(s), no data collective"},
             "roofline": {"bound": "hbm", "kernel": "gwc_volume_kernel (A3 build)", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "algorithmic_bytes": gwc_bytes, "avg_launch_ms": round(build_ms, 4)},
+                         "traffic": traffic, "algorithmic_bytes": gwc_bytes, "avg_launch_ms": round(build_ms, 4)},
             "kernels_ms": {"gwc_build": round(build_ms, 4), "group_mean_soft_argmin": round(read_ms, 4),
                            "fused_corr_soft_argmin_no_volume": None if fused_ms is None else round(fused_ms, 4)},
             "checksum": checksum,
