@@ -149,11 +149,12 @@ int stereo_cross_attention_f32(const float *left, const float *right, const floa
 
 /* A11/A14 ConvGRU gate math around the (host-framework) convolutions
  *     Attempts/update.py:41-48, update/update.py:28-32; bias pointers may be NULL
- *     reset: out = sigmoid(rc + cr) * h;  blend: out = (1-z)*h + z*tanh(qc+cq), z = sigmoid(zc+cz) */
+ *     reset: out = sigmoid(rc + cr) * h;  blend: out = (1-z)*h + z*act(qc+cq), z = sigmoid(zc+cz),
+ *     act = tanh, or x/(1+|x|) when softsign != 0 (ConvGRU(softsign=True), Attempts/update.py:31-34) */
 int stereo_gru_reset_f32(const float *h, const float *rc, const float *cr, float *out,
                          long long n, void *stream);
 int stereo_gru_blend_f32(const float *h, const float *zc, const float *qc, const float *cz,
-                         const float *cq, float *out, long long n, void *stream);
+                         const float *cq, float *out, long long n, int softsign, void *stream);
 
 #ifdef __cplusplus
 }

@@ -258,13 +258,13 @@ def cross_attention(L, R, V, D, mask="zero", scale="sqrt_c", lib=None):
 
 
 # --------------------------------------------------------------- GRU pointwise
-def gru_blend(h, zc, qc, cz=None, cq=None):
+def gru_blend(h, zc, qc, cz=None, cq=None, softsign=False):
     h, zc, qc = _c(h), _c(zc), _c(qc)
     cz = None if cz is None else _c(cz)
     cq = None if cq is None else _c(cq)
     out = np.empty_like(h)
     load().oracle_gru_blend(_p(h), _p(zc), _p(qc), _p(cz) if cz is not None else None,
-                            _p(cq) if cq is not None else None, _p(out), _ll(h.size))
+                            _p(cq) if cq is not None else None, _p(out), _ll(h.size), _i(int(softsign)))
     return out
 
 

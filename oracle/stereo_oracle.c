@@ -697,12 +697,13 @@ void oracle_cross_attention(const float *L, const float *R, const float *V, floa
  * update/update.py:28-32:     z=sigmoid(zc+cz), q=tanh(qc+cq); same blend.
  * bias pointers may be NULL. */
 void oracle_gru_blend(const float *h, const float *zc, const float *qc, const float *cz,
-                      const float *cq, float *out, long long n)
+                      const float *cq, float *out, long long n, int softsign)
 {
 #pragma omp parallel for schedule(static)
     for (long long i = 0; i < n; ++i) {
         const float z = 1.0f / (1.0f + expf(-(zc[i] + (cz ? cz[i] : 0.0f))));
-        const float q = tanhf(qc[i] + (cq ? cq[i] : 0.0f));
+        const float qx = qc[i] + (cq ? cq[i] : 0.0f);
+        const float q = softsign ? qx / (1.0f + fabsf(qx)) : tanhf(qx); /* nn.Softsign, Attempts/update.py:34 */
         out[i] = (1.0f - z) * h[i] + z * q;
     }
 }

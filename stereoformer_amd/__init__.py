@@ -17,10 +17,16 @@ from .corr import (AlternateCorrBlock, CorrBlock1D, InputPadder, PytorchAlternat
                    coords_grid)
 from .cross_attention import CrossAttentionCostVolume
 from .disparity_warper import disp_warp
+from .update_dlc import (BasicGuidanceNet, DisparityUpdateDLC, DisparityUpdateDLCWithMask,
+                         DisparityUpdateDLCWithMaskV2, OffsetPredictionHead, gru_blend, gru_reset)
+from .update_raft import BasicMotionEncoder_LZH, BasicMultiUpdateBlock_LZH, FlowHead, SepConvGRU, pool2x, pool4x
 from .upsample import (ConvAffinityUpsample, interp, resize_bilinear, upflow8, upsample_convex, upsample_convex8,
                        upsample_flow, upsample_simple8)
 
 __all__ = [
+    "BasicGuidanceNet", "DisparityUpdateDLC", "DisparityUpdateDLCWithMask", "DisparityUpdateDLCWithMaskV2",
+    "OffsetPredictionHead", "gru_blend", "gru_reset", "BasicMotionEncoder_LZH", "BasicMultiUpdateBlock_LZH",
+    "FlowHead", "SepConvGRU", "pool2x", "pool4x",
     "AlternateCorrBlock", "CorrBlock1D", "InputPadder", "PytorchAlternateCorrBlock1D", "bilinear_sampler",
     "coords_grid", "CrossAttentionCostVolume", "disp_warp", "ConvAffinityUpsample", "interp", "resize_bilinear",
     "upflow8", "upsample_convex", "upsample_convex8", "upsample_flow", "upsample_simple8",

@@ -47,7 +47,7 @@ SIGNATURES = {
     "stereo_resize_bilinear_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "stereo_cross_attention_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_gru_reset_f32": [_vp, _vp, _vp, _vp, _ll, _vp],
-    "stereo_gru_blend_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp],
+    "stereo_gru_blend_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp],
 }
 _RESTYPE = {"stereo_strerror": ctypes.c_char_p, "stereo_alt_corr_workspace_floats": _ll}
 

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void gru_reset_kernel(const float *__restrict_
     }
 }
 
-template <int V>
+template <int V, bool SOFTSIGN>
 __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict__ h, const float *__restrict__ zc,
                                                         const float *__restrict__ qc, const float *__restrict__ cz,
                                                         const float *__restrict__ cq, float *__restrict__ out,
@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict_
         for (int i = 0; i < V; ++i) {
             const long long e = t * V + i;
             const float z = sigmoidf_(zc[e] + (cz ? cz[e] : 0.0f));
-            const float q = tanhf(qc[e] + (cq ? cq[e] : 0.0f));
+            const float qx = qc[e] + (cq ? cq[e] : 0.0f);
+            const float q = SOFTSIGN ? qx / (1.0f + fabsf(qx)) : tanhf(qx);
             out[e] = (1.0f - z) * h[e] + z * q;
         }
     }
@@ -70,7 +71,7 @@ extern "C" int stereo_gru_reset_f32(const float *h, const float *rc, const float
 }
 
 extern "C" int stereo_gru_blend_f32(const float *h, const float *zc, const float *qc, const float *cz, const float *cq,
-                                    float *out, long long n, void *stream)
+                                    float *out, long long n, int softsign, void *stream)
 {
     if (n < 0) return STEREO_ERR_BAD_SHAPE;
     if (n == 0) return STEREO_OK;
@@ -78,12 +79,15 @@ extern "C" int stereo_gru_blend_f32(const float *h, const float *zc, const float
     STEREO_REQUIRE_PTR(zc);
     STEREO_REQUIRE_PTR(qc);
     STEREO_REQUIRE_PTR(out);
-    if (n % 4 == 0)
-        hipLaunchKernelGGL(gru_blend_kernel<4>, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(stream), h, zc, qc, cz,
-                           cq, out, n / 4);
-    else
-        hipLaunchKernelGGL(gru_blend_kernel<1>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), h, zc, qc, cz, cq,
-                           out, n);
+    hipStream_t st = as_stream(stream);
+    const bool v4 = n % 4 == 0;
+    const long long nv = v4 ? n / 4 : n;
+#define BLEND(V, S) hipLaunchKernelGGL((gru_blend_kernel<V, S>), dim3(grid_for(nv)), dim3(256), 0, st, h, zc, qc, cz, cq, out, nv)
+    if (v4 && softsign) BLEND(4, true);
+    else if (v4) BLEND(4, false);
+    else if (softsign) BLEND(1, true);
+    else BLEND(1, false);
+#undef BLEND
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }

@@ -1,0 +1,202 @@
+"""GRU-iterated local cost-volume updater (A11) behind
+``models/LocalCostVolume/Attempts/update.py`` (and ``updatev2.py``).
+
+The 3x3 convolutions / BatchNorm stay with the host framework (MIOpen); everything
+else on the iteration path is a HIP kernel: image resize, ``disp_warp``, the uncertainty
+volume (softmax * d * (d-disp)^2 in one pass), the GRU gate math, and the learned-bounds
+sampler.  Parameter names (including the reference's aliased ``conv_zz.0`` etc.) match the
+reference so its ``state_dict``s load unchanged.  No host sync inside ``forward``.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _native as N
+from .disparity_warper import disp_warp
+from .local_cost_volume import bounds_lookup, uncertainty_volume
+from .upsample import resize_bilinear
+
+
+def gru_reset(h, rc, cr=None):
+    """``sigmoid(rc + cr) * h`` in one kernel."""
+    h = N.dev_f32(h, "gru_reset: h")
+    rc = N.dev_f32(rc, "gru_reset: rc")
+    cr = None if cr is None else N.dev_f32(cr, "gru_reset: cr")
+    if rc.shape != h.shape or (cr is not None and cr.shape != h.shape):
+        raise ValueError("gru_reset: shape mismatch")
+    out = torch.empty_like(h)
+    with torch.cuda.device(h.device):
+        N.call("stereo_gru_reset_f32", N.ptr(h), N.ptr(rc), N.ptr(cr), N.ptr(out), h.numel(), N.stream_ptr(h.device))
+    return out
+
+
+def gru_blend(h, zc, qc, cz=None, cq=None, softsign=False):
+    """``(1-z)*h + z*act(qc+cq)`` with ``z = sigmoid(zc+cz)`` in one kernel."""
+    h = N.dev_f32(h, "gru_blend: h")
+    zc = N.dev_f32(zc, "gru_blend: zc")
+    qc = N.dev_f32(qc, "gru_blend: qc")
+    cz = None if cz is None else N.dev_f32(cz, "gru_blend: cz")
+    cq = None if cq is None else N.dev_f32(cq, "gru_blend: cq")
+    for t in (zc, qc, cz, cq):
+        if t is not None and t.shape != h.shape:
+            raise ValueError("gru_blend: shape mismatch")
+    out = torch.empty_like(h)
+    with torch.cuda.device(h.device):
+        N.call("stereo_gru_blend_f32", N.ptr(h), N.ptr(zc), N.ptr(qc), N.ptr(cz), N.ptr(cq), N.ptr(out), h.numel(),
+               1 if softsign else 0, N.stream_ptr(h.device))
+    return out
+
+
+class ConvGRU(nn.Module):
+    """``ConvGRU(nb_channel, softsign)`` (Attempts/update.py:17-49)."""
+
+    def __init__(self, nb_channel, softsign):
+        super().__init__()
+        self.conv_z = nn.Conv2d(nb_channel * 2, nb_channel, 3, 1, 1)
+        self.conv_b = nn.Conv2d(nb_channel * 2, nb_channel, 3, 1, 1)
+        self.conv_g = nn.Conv2d(nb_channel * 2, nb_channel, 3, 1, 1)
+        nn.init.orthogonal_(self.conv_z.weight)
+        nn.init.orthogonal_(self.conv_b.weight)
+        nn.init.orthogonal_(self.conv_g.weight)
+        nn.init.constant_(self.conv_z.bias, 0.)
+        nn.init.constant_(self.conv_b.bias, 0.)
+        nn.init.constant_(self.conv_g.bias, 0.)
+        # same aliased containers as the reference so state_dict keys line up (:29-34)
+        self.conv_zz = nn.Sequential(self.conv_z, nn.Sigmoid())
+        self.conv_bb = nn.Sequential(self.conv_b, nn.Sigmoid())
+        self.conv_gg = nn.Sequential(self.conv_g, nn.Softsign() if softsign else nn.Tanh())
+        self.softsign = bool(softsign)
+        self.nb_channel = nb_channel
+
+    def forward(self, input, prev_h):
+        if prev_h is None:  # the reference hard-codes .cuda() here (:38-39)
+            prev_h = torch.zeros(input.size(0), self.nb_channel, input.size(2), input.size(3), device=input.device,
+                                 dtype=input.dtype)
+        x1 = torch.cat((input, prev_h), 1)
+        zc = self.conv_z(x1)
+        bc = self.conv_b(x1)
+        s = gru_reset(prev_h, bc)                       # b * prev_h
+        gc = self.conv_g(torch.cat((s, input), 1))
+        return gru_blend(prev_h, zc, gc, softsign=self.softsign)
+
+
+class BasicGuidanceNet(nn.Module):
+    """``BasicGuidanceNet`` (Attempts/update.py:52-92)."""
+
+    def __init__(self, input_channels, hidden_layer=32):
+        super().__init__()
+        self.input_channels = input_channels
+        self.hidden_layers = hidden_layer
+        self.uncertain_encoder = nn.Sequential(
+            nn.Conv2d(self.input_channels, self.hidden_layers, kernel_size=3, stride=1, padding=1, bias=False),
+            nn.BatchNorm2d(self.hidden_layers), nn.ReLU(inplace=True))
+        self.disparity_error_encoder = nn.Sequential(
+            nn.Conv2d(3, self.hidden_layers, kernel_size=3, stride=1, padding=1, bias=False),
+            nn.BatchNorm2d(self.hidden_layers), nn.ReLU(inplace=True))
+
+    def forward(self, old_cost_volume, cur_disp, left_image, right_image):
+        if cur_disp.size(-1) != left_image.size(-1):
+            size = (cur_disp.size(-2), cur_disp.size(-1))
+            cur_left_image = resize_bilinear(left_image, size, align_corners=False)
+            cur_right_image = resize_bilinear(right_image, size, align_corners=False)
+        else:
+            cur_left_image, cur_right_image = left_image, right_image
+        warped_left, _ = disp_warp(cur_right_image, cur_disp)
+        error_map = warped_left - cur_left_image
+        uncertainity_volume = uncertainty_volume(old_cost_volume, cur_disp)
+        error_feature = self.disparity_error_encoder(error_map)
+        uncertainity_feature = self.uncertain_encoder(uncertainity_volume)
+        return torch.cat([error_feature, uncertainity_feature], dim=1)
+
+
+class OffsetPredictionHead(nn.Module):
+    """``OffsetPredictionHead`` (Attempts/update.py:96-105): two non-negative offsets."""
+
+    def __init__(self, input_dim, hidden_dim):
+        super().__init__()
+        self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = nn.Conv2d(hidden_dim, 2, 3, padding=1)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.relu2 = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return self.relu2(self.conv2(self.relu1(self.conv1(x))))
+
+
+class DisparityUpdateDLC(nn.Module):
+    """``DisparityUpdateDLC`` (Attempts/update.py:178-242, the definition that survives):
+    as ...WithMask but without the mask head; its offset head takes 32 channels, i.e. it
+    only works with hidden_dim == 16 (a reference quirk kept as is)."""
+
+    def __init__(self, input_channels, hidden_dim, sample_points=10):
+        super().__init__()
+        self.sample_points = sample_points
+        self.hidden_dim = hidden_dim
+        self.encoder = BasicGuidanceNet(input_channels=input_channels, hidden_layer=self.hidden_dim)
+        self.gru = ConvGRU(nb_channel=self.hidden_dim * 2, softsign=False)
+        self.offset = OffsetPredictionHead(input_dim=32, hidden_dim=64)
+
+    def forward(self, old_cost_volume, cur_disp, left_image, right_image, hidden_state=None, consider_valid=True):
+        with torch.no_grad():
+            offset_features = self.encoder(old_cost_volume, cur_disp, left_image, right_image)
+            hidden_state = self.gru(offset_features, hidden_state)
+            bounds = self.offset(hidden_state)
+            disp = bounds_lookup(old_cost_volume, cur_disp, bounds, self.sample_points, consider_valid)
+        return disp, hidden_state
+
+
+class DisparityUpdateDLCWithMask(nn.Module):
+    """``DisparityUpdateDLCWithMask(input_channels, hidden_dim, sample_points=10)``
+    (Attempts/update.py:245-316) -> (disp [B,1,h,w], hidden [B,2*hidden_dim,h,w], mask [B,576,h,w])."""
+
+    def __init__(self, input_channels, hidden_dim, sample_points=10):
+        super().__init__()
+        self.sample_points = sample_points
+        self.hidden_dim = hidden_dim
+        self.encoder = BasicGuidanceNet(input_channels=input_channels, hidden_layer=self.hidden_dim)
+        self.gru = ConvGRU(nb_channel=self.hidden_dim * 2, softsign=False)
+        self.offset = OffsetPredictionHead(input_dim=self.hidden_dim * 2, hidden_dim=64)
+        self.mask = nn.Sequential(
+            nn.Conv2d(self.hidden_dim * 2, 256, 3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(256, 64 * 9, 1, padding=0))
+
+    def forward(self, old_cost_volume, cur_disp, left_image, right_image, hidden_state=None, consider_valid=True):
+        with torch.no_grad():
+            offset_features = self.encoder(old_cost_volume, cur_disp, left_image, right_image)
+            hidden_state = self.gru(offset_features, hidden_state)
+            mask = .25 * self.mask(hidden_state)
+            bounds = self.offset(hidden_state)          # [B,2,h,w]: (lower offset, upper offset)
+            disp = bounds_lookup(old_cost_volume, cur_disp, bounds, self.sample_points, consider_valid)
+        return disp, hidden_state, mask
+
+
+class DisparityUpdateDLCWithMaskV2(nn.Module):
+    """The ``updatev2.py:169-251`` variant: an extra left-feature encoder (256 -> 64 ch,
+    hard-wired in the reference) concatenated into the GRU input."""
+
+    def __init__(self, input_channels, feature_dim, hidden_dim, sample_points=10):
+        super().__init__()
+        self.sample_points = sample_points
+        self.hidden_dim = hidden_dim
+        self.feature_dim = feature_dim
+        self.encoder = BasicGuidanceNet(input_channels=input_channels, hidden_layer=self.hidden_dim)
+        self.feature_encode = nn.Sequential(
+            nn.Conv2d(256, 64, kernel_size=3, stride=1, padding=1, bias=False), nn.BatchNorm2d(64),
+            nn.ReLU(inplace=True))
+        ch = self.hidden_dim * 2 + self.feature_dim
+        self.gru = ConvGRU(nb_channel=ch, softsign=False)
+        self.offset = OffsetPredictionHead(input_dim=ch, hidden_dim=64)
+        self.mask = nn.Sequential(nn.Conv2d(ch, 256, 3, padding=1), nn.ReLU(inplace=True),
+                                  nn.Conv2d(256, 64 * 9, 1, padding=0))
+
+    def forward(self, old_cost_volume, cur_disp, left_image, right_image, hidden_state=None, left_feature=None,
+                consider_valid=True):
+        with torch.no_grad():
+            offset_features = self.encoder(old_cost_volume, cur_disp, left_image, right_image)
+            input_features = torch.cat((offset_features, self.feature_encode(left_feature)), dim=1)
+            hidden_state = self.gru(input_features, hidden_state)
+            mask = .25 * self.mask(hidden_state)
+            bounds = self.offset(hidden_state)
+            disp = bounds_lookup(old_cost_volume, cur_disp, bounds, self.sample_points, consider_valid)
+        return disp, hidden_state, mask

@@ -290,12 +290,12 @@ def test_gru_pointwise(S, oracle):
         a = [rng.standard_normal(n).astype(np.float32) * 2 for _ in range(5)]
         h, zc, qc, cz, cq = [dev(x) for x in a]
         out = torch.empty_like(h)
-        N.call("stereo_gru_blend_f32", N.ptr(h), N.ptr(zc), N.ptr(qc), N.ptr(cz), N.ptr(cq), N.ptr(out), n,
+        N.call("stereo_gru_blend_f32", N.ptr(h), N.ptr(zc), N.ptr(qc), N.ptr(cz), N.ptr(cq), N.ptr(out), n, 0,
                N.stream_ptr())
         close(out, oracle.gru_blend(*a), rtol=1e-5, atol=2e-6)
-        N.call("stereo_gru_blend_f32", N.ptr(h), N.ptr(zc), N.ptr(qc), N.ptr(None), N.ptr(None), N.ptr(out), n,
+        N.call("stereo_gru_blend_f32", N.ptr(h), N.ptr(zc), N.ptr(qc), N.ptr(None), N.ptr(None), N.ptr(out), n, 1,
                N.stream_ptr())
-        close(out, oracle.gru_blend(a[0], a[1], a[2]), rtol=1e-5, atol=2e-6)
+        close(out, oracle.gru_blend(a[0], a[1], a[2], softsign=True), rtol=1e-5, atol=2e-6)
         N.call("stereo_gru_reset_f32", N.ptr(h), N.ptr(zc), N.ptr(cz), N.ptr(out), n, N.stream_ptr())
         close(out, oracle.gru_reset(a[0], a[1], a[3]), rtol=1e-5, atol=2e-6)
 
