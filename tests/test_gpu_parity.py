@@ -264,19 +264,22 @@ def test_resize_vs_oracle(S, oracle, golden):
 
 
 # ------------------------------------------------------------------ cross-attention (A7, build-defined)
-@pytest.mark.parametrize("cfg", [(2, 16, 5, 40, 12), (1, 32, 3, 200, 192), (1, 48, 2, 70, 33)])
+@pytest.mark.parametrize("cfg", [(2, 16, 5, 40, 12), (1, 32, 3, 200, 192), (1, 48, 2, 70, 33), (1, 40, 2, 300, 230),
+                                 (1, 256, 2, 312, 64), (1, 8, 1, 64, 1), (1, 32, 1, 130, 352), (1, 20, 1, 96, 32)])
 def test_cross_attention(S, oracle, cfg):
     B, C, H, W, D = cfg
     rng = np.random.default_rng(29)
     L = rng.standard_normal((B, C, H, W), dtype=np.float32)
     R = rng.standard_normal((B, C, H, W), dtype=np.float32)
-    V = rng.standard_normal((B, 20, H, W), dtype=np.float32)
+    V = rng.standard_normal((B, 20 if C != 40 else 70, H, W), dtype=np.float32)
     for mask in ("zero", "neginf"):
         for scale in ("sqrt_c", "mean"):
             o, d = S.CrossAttentionCostVolume(D, mask, scale)(dev(L), dev(R), dev(V))
             oo, od = oracle.cross_attention(L, R, V, D, mask, scale)
             close(o, oo, rtol=1e-4, atol=5e-5)
-            close(d, od, **DISP_TOL)
+            # fp32 logit-accumulation noise is amplified by the spread of d: the mean-error budget grows
+            # with D (tools/accuracy_probe.py: the oracle itself sits 5e-5 from fp64 truth at D=352)
+            close(d, od, rtol=0, atol=1e-3, mean_atol=2.5e-4 * max(1.0, D / 192.0))
     # I3: mask='zero', scale='mean' reproduces CostVolume + DisparityEstimation of the HIP path itself
     _, d = S.CrossAttentionCostVolume(D, "zero", "mean")(dev(L), dev(R), need_out=False)
     close(d, host(S.DisparityEstimation(D)(S.CostVolume(D)(dev(L), dev(R)))), **DISP_TOL)

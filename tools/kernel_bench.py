@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Per-kernel timing at the BASELINE config sizes, with algorithmic bytes/flops (SURVEY 8(d),
+DESIGN.md section 4) and the fraction of the bounding roofline.  Writes a table to stdout and
+JSON to gpurun_out/kernel_bench.json.  Usage: python tools/kernel_bench.py [--only name]"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+import torch
+
+import stereoformer_amd as S
+
+HBM = 8000.0      # GB/s spec
+MFMA_F32 = 157.3  # TFLOP/s (f32-in MFMA == f32 VALU peak)
+
+
+def timeit(fn, reps=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--reps", type=int, default=10)
+    args = ap.parse_args()
+    dev = "cuda"
+    rows = []
+
+    def add(name, ms, gbytes=None, gflop=None, bound="hbm", note=""):
+        r = {"kernel": name, "ms": round(ms, 4), "bound": bound, "note": note}
+        if gbytes is not None:
+            r["GB"] = round(gbytes, 4)
+            r["GB/s"] = round(gbytes / ms * 1e3, 1)
+        if gflop is not None:
+            r["GFLOP"] = round(gflop, 2)
+            r["TFLOP/s"] = round(gflop / ms, 2)
+        if bound == "hbm" and gbytes is not None:
+            r["frac"] = round(gbytes / ms * 1e3 / HBM, 4)
+        if bound == "mfma" and gflop is not None:
+            r["frac"] = round(gflop / ms / MFMA_F32, 4)
+        rows.append(r)
+        print(json.dumps(r), flush=True)
+
+    def want(n):
+        return args.only is None or args.only in n
+
+    B, C, H, W, D, G = 8, 32, 540, 960, 192, 8
+    N = B * H * W
+    torch.manual_seed(0)
+    L = torch.randn(B, C, H, W, device=dev)
+    R = torch.randn(B, C, H, W, device=dev)
+    with torch.no_grad():
+        if want("A1_corr_volume"):
+            add("A1_corr_volume cfg-2", timeit(lambda: S.CostVolume(D)(L, R), args.reps),
+                (2 * N * C * 4 + N * D * 4) / 1e9, 2 * B * H * C * (D * W - D * (D - 1) / 2) / 1e9)
+        if want("A3_gwc_volume"):
+            add("A3_gwc_volume cfg-2 G=8", timeit(lambda: S.build_gwc_volume(L, R, D, G), 5),
+                (2 * N * C * 4 + N * G * D * 4) / 1e9)
+        vol = S.CostVolume(D)(L, R)
+        if want("A4_soft_argmin"):
+            add("A4_soft_argmin cfg-2", timeit(lambda: S.DisparityEstimation(D)(vol), args.reps), (N * D * 4 + N * 4) / 1e9)
+            add("A4_soft_argmin_with_prob cfg-2", timeit(lambda: S.DisparityEstimationWithProb(D)(vol), args.reps),
+                (2 * N * D * 4 + N * 4) / 1e9, note="1 read + 1 write algorithmic; the re-read is cache traffic")
+        disp = S.DisparityEstimation(D)(vol).unsqueeze(1)
+        if want("A5_local_lookup"):
+            add("A5_local_lookup r=2 S=20 cfg-2", timeit(lambda: S.LocalCostVolume(2, 20)(vol, disp, True), args.reps),
+                (N * D * 4 + 2 * N * 4) / 1e9, note="upper-bound bytes (whole volume); gather-only bound 0.73 GB")
+        if want("A6_variance_lookup"):
+            add("A6_variance_lookup g=1 S=10 cfg-2",
+                timeit(lambda: S.Variance_Based_Local_Cost_Volume(1, 10)(vol, disp, True), args.reps),
+                (N * D * 4 + 2 * N * 4) / 1e9)
+        if want("A4_group_mean"):
+            volg = S.build_gwc_volume(L, R, D, G)
+            add("group_mean_soft_argmin cfg-2", timeit(lambda: S.group_mean_soft_argmin(volg, return_mean=True), 5),
+                (N * G * D * 4 + N * D * 4 + N * 4) / 1e9)
+            add("group_mean_soft_argmin(no mean out) cfg-2", timeit(lambda: S.group_mean_soft_argmin(volg), 5),
+                (N * G * D * 4 + N * 4) / 1e9)
+            del volg
+        if want("A1A4_fused"):
+            add("A1+A4 fused corr_soft_argmin cfg-2", timeit(lambda: S.corr_soft_argmin(L, R, D), args.reps),
+                (2 * N * C * 4 + N * 4) / 1e9, 2 * B * H * C * (D * W - D * (D - 1) / 2) / 1e9, bound="valu")
+        if want("A2_"):
+            L1, R1 = L[:1, :8].contiguous(), R[:1, :8].contiguous()
+            n1 = H * W
+            add("A2_diff_volume B1 C8 D=192", timeit(lambda: S.CostVolume(D, "difference")(L1, R1), 5),
+                (2 * n1 * 8 * 4 + n1 * 8 * D * 4) / 1e9)
+            add("A2_concat_volume B1 C8 D=192", timeit(lambda: S.CostVolume(D, "concat")(L1, R1), 5),
+                (2 * n1 * 8 * 4 + n1 * 16 * D * 4) / 1e9)
+        del vol
+        if want("A7_cross_attention"):
+            att = S.CrossAttentionCostVolume(D, "zero", "sqrt_c")
+            band = D * W - D * (D - 1) / 2
+            add("A7_cross_attention cfg-3 C=32 D=192", timeit(lambda: att(L, R), 3, 1),
+                (4 * N * C * 4 + N * 4) / 1e9, 2 * 2 * B * H * C * band / 1e9, bound="mfma")
+            add("A7_cross_attention(disp only) cfg-3", timeit(lambda: att(L, R, need_out=False), 3, 1),
+                (2 * N * C * 4 + N * 4) / 1e9, 2 * B * H * C * band / 1e9, bound="mfma")
+        # ---- RAFT shapes (cfg-4 per GPU)
+        Br, Cr, Hr, Wr = 8, 256, 136, 240
+        f1 = torch.randn(Br, Cr, Hr, Wr, device=dev)
+        f2 = torch.randn(Br, Cr, Hr, Wr, device=dev)
+        if want("A8_allpairs"):
+            pyr_bytes = Br * Hr * Wr * (Wr + Wr // 2 + Wr // 4 + Wr // 8 + Wr // 16) * 4
+            add("A8_allpairs+pyramid cfg-4 [8,256,136,240]", timeit(lambda: S.CorrBlock1D(f1, f2, 4, 4), args.reps),
+                (2 * Br * Cr * Hr * Wr * 4 + pyr_bytes) / 1e9, 2 * Br * Hr * Wr * Wr * Cr / 1e9, bound="mfma")
+        blk = S.CorrBlock1D(f1, f2, 4, 4)
+        coords = S.coords_grid(Br, Hr, Wr, device=dev) - torch.rand(Br, 2, Hr, Wr, device=dev) * 30
+        coords = coords.contiguous()
+        if want("A9_corr_lookup"):
+            add("A9_corr_lookup cfg-4", timeit(lambda: blk(coords), args.reps),
+                (Br * 36 * Hr * Wr * 4 * 3) / 1e9, note="out + ~2 taps gathered per output")
+        if want("A10_alt"):
+            alt = S.PytorchAlternateCorrBlock1D(f1[:1], f2[:1], 4, 4)
+            add("A10_alt_corr_lookup B=1", timeit(lambda: alt(coords[:1]), 3, 1), None,
+                2 * 36 * Hr * Wr * Cr * 5 / 1e9, bound="valu")
+        if want("A13_upsample"):
+            d8 = torch.rand(8, 1, 72, 120, device=dev)
+            m8 = torch.randn(8, 576, 72, 120, device=dev)
+            nc = 8 * 72 * 120
+            add("A13_upsample_convex8 [8,1,72,120]", timeit(lambda: S.upsample_convex8(d8, m8), args.reps),
+                (nc * (9 * 64 + 1) * 4 + nc * 64 * 4) / 1e9)
+            d4 = torch.rand(8, 2, 136, 240, device=dev)
+            m4 = torch.randn(8, 144, 136, 240, device=dev)
+            nc = 8 * 136 * 240
+            add("A13_upsample_flow f=4 [8,2,136,240]", timeit(lambda: S.upsample_flow(d4, m4, 2), args.reps),
+                (nc * (9 * 16 + 2) * 4 + nc * 2 * 16 * 4) / 1e9)
+        if want("A12_disp_warp"):
+            img = torch.randn(8, 3, 540, 960, device=dev)
+            dd = torch.rand(8, 1, 540, 960, device=dev) * 100
+            add("A12_disp_warp [8,3,540,960]", timeit(lambda: S.disp_warp(img, dd), args.reps),
+                (8 * 540 * 960 * (3 + 1 + 6) * 4) / 1e9)
+        if want("gru"):
+            h = torch.randn(8, 128, 136, 240, device=dev)
+            a, b2 = torch.randn_like(h), torch.randn_like(h)
+            add("gru_blend [8,128,136,240] (+2 bias)", timeit(lambda: S.gru_blend(h, a, b2, a, b2), args.reps),
+                h.numel() * 4 * 6 / 1e9)
+            add("gru_reset [8,128,136,240] (+bias)", timeit(lambda: S.gru_reset(h, a, b2), args.reps), h.numel() * 4 * 4 / 1e9)
+        if want("A11_iter"):
+            net = S.DisparityUpdateDLCWithMask(24, 32, 20).eval().cuda()
+            v = torch.randn(8, 24, 72, 120, device=dev)
+            dsp = S.DisparityEstimation(24)(v).unsqueeze(1)
+            li = torch.randn(8, 3, 576, 960, device=dev)
+            ri = torch.randn(8, 3, 576, 960, device=dev)
+            hid = torch.zeros(8, 64, 72, 120, device=dev)
+            add("A11 one iteration B=8 [24,72,120] (+A13)",
+                timeit(lambda: S.upsample_convex8(*(lambda o: (o[0], o[2]))(net(v, dsp, li, ri, hid, True))), 5), None,
+                note="MIOpen convs + HIP pointwise; informational")
+        if want("A14_iter"):
+            blk14 = S.BasicMultiUpdateBlock_LZH(4, 4, 3, 2, [128, 128, 128]).eval().cuda()
+            nets = [torch.tanh(torch.randn(8, 128, Hr >> i, Wr >> i, device=dev)) for i in range(3)]
+            inps = [[torch.randn(8, 128, Hr >> i, Wr >> i, device=dev) for _ in range(3)] for i in range(3)]
+            corr = torch.randn(8, 36, Hr, Wr, device=dev)
+            flow = torch.randn(8, 2, Hr, Wr, device=dev)
+            add("A14 one iteration B=8 @136x240", timeit(lambda: blk14(list(nets), inps, corr, flow), 3, 1), None,
+                8 * 168.0, bound="miopen", note="168 GFLOP/iter/pair of convs (MIOpen); informational")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "kernel_bench.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
