@@ -109,47 +109,102 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(const float *__res
 //  phase 3  O^T[c][query] = V^T P: A <- value tile (rows = channels), B <- P read back along
 //           the band (address 65*q - 64*key: conflict-free); waves split the key range and
 //           meet in LDS; stores are 128-B W-contiguous row segments.
-constexpr int A2_TQ = 64, A2_CK = 32;
 
-// Stage ROWS x ncols floats: dst[r*dstride + x] = (r < nrows && 0 <= wstart+x < W) ? src[r*cstride + wstart + x] : 0.
-// Branch-free (clamped address + select) and unrolled so that 16 global loads per lane are in flight;
-// (r, x) advance incrementally: one integer division per call, none per element.
-template <int ROWS>
+// Stage ROWS x ncols floats (ncols % 4 == 0): dst[r*dstride + x] = (r < nrows && 0 <= wstart+x < W) ?
+// src[r*cstride + wstart + x] : 0.  VEC: 16-byte global loads (W % 4 == 0, wstart % 4 == 0, aligned
+// base: a quad is then entirely inside or outside the row).  Branch-free and unrolled so that U loads
+// per lane are in flight; (r, x) advance incrementally: one integer division per call.
+template <int ROWS, bool VEC, int NTH>
 __device__ __forceinline__ void stage_rows(float *__restrict__ dst, int dstride, const float *__restrict__ src,
                                            size_t cstride, int nrows, int wstart, int ncols, int W, int tid)
 {
-    const int total = ROWS * ncols;
-    const int dr = 256 / ncols, dx = 256 - dr * ncols;  // advance of (r, x) per 256-element step
-    int r = tid / ncols, x = tid - r * ncols;
-    constexpr int U = 16;
-    for (int base = tid; base < total; base += 256 * U) {
-        float v[U];
-        int rr[U], xx[U];
+    if (VEC) {
+        const int nq = ncols >> 2;                 // quads per row
+        const int total = ROWS * nq;
+        const int dr = NTH / nq, dx = NTH - dr * nq;
+        int r = tid / nq, x = tid - r * nq;
+        constexpr int U = NTH >= 512 ? 4 : 8;
+        for (int base = tid; base < total; base += NTH * U) {
+            f32x4 v[U];
+            int rr[U], xx[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            rr[u] = r;
-            xx[u] = x;
-            const int w = wstart + x;
-            const int wc = w < 0 ? 0 : (w >= W ? W - 1 : w);
-            const int rc = r < nrows ? r : (nrows > 0 ? nrows - 1 : 0);
-            v[u] = (base + u * 256 < total) ? src[(size_t)rc * cstride + wc] : 0.0f;
-            x += dx;
-            r += dr;
-            if (x >= ncols) {
-                x -= ncols;
-                ++r;
+            for (int u = 0; u < U; ++u) {
+                rr[u] = r;
+                xx[u] = x;
+                const int w = wstart + 4 * x;
+                const bool ok = (base + u * NTH < total) && r < nrows && w >= 0 && w + 3 < W;
+                const int wc = ok ? w : 0;
+                const int rc = ok ? r : 0;
+                v[u] = ld4(src + (size_t)rc * cstride + wc);
+                if (!ok) v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                x += dx;
+                r += dr;
+                if (x >= nq) {
+                    x -= nq;
+                    ++r;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (base + u * NTH < total) {
+                    float *d = dst + rr[u] * dstride + 4 * xx[u];
+                    d[0] = v[u][0];
+                    d[1] = v[u][1];
+                    d[2] = v[u][2];
+                    d[3] = v[u][3];
+                }
             }
         }
+    } else {
+        const int total = ROWS * ncols;
+        const int dr = NTH / ncols, dx = NTH - dr * ncols;
+        int r = tid / ncols, x = tid - r * ncols;
+        constexpr int U = NTH >= 512 ? 8 : 16;
+        for (int base = tid; base < total; base += NTH * U) {
+            float v[U];
+            int rr[U], xx[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int w = wstart + xx[u];
-            if (base + u * 256 < total) dst[rr[u] * dstride + xx[u]] = (rr[u] < nrows && w >= 0 && w < W) ? v[u] : 0.0f;
+            for (int u = 0; u < U; ++u) {
+                rr[u] = r;
+                xx[u] = x;
+                const int w = wstart + x;
+                const bool ok = (base + u * NTH < total) && r < nrows && w >= 0 && w < W;
+                v[u] = src[ok ? (size_t)r * cstride + w : 0];
+                if (!ok) v[u] = 0.0f;
+                x += dx;
+                r += dr;
+                if (x >= ncols) {
+                    x -= ncols;
+                    ++r;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (base + u * NTH < total) dst[rr[u] * dstride + xx[u]] = v[u];
         }
     }
 }
 
-template <int NPT>  // scores per lane in the softmax phase: NPT >= ceil(D / 4)
-__global__ __launch_bounds__(256) void cross_attention_mfma_kernel(const float *__restrict__ L,
+// ---------------------------------------------------------------------------
+// v2: both contractions on the matrix cores (exact-f32 v_mfma_f32_32x32x2_f32).
+// WG = (row, 64 queries), 8 waves: (query tile = wave & 1) x (key group = wave >> 1).  With dq = (query tile origin) - (key tile origin), a multiple
+// of 32, only tile pairs with 0 <= dq <= Dk touch the band; their entries have d in [-31, Dk+31].
+//  phase 1  S^T[key][query] = K Q^T: A <- right-feature tile (rows = keys), B <- left tile
+//           (cols = queries), accumulated over 32-channel chunks staged in LDS; each wave owns one
+//           32-query tile x up to four 32-key tiles (64 accumulator registers).  Every accumulator
+//           register is scattered, unconditionally and with immediate offsets, into the padded LDS
+//           score sheet P[32 + d][query] (32 pad rows below d=0, 32+ above d=D-1).
+//  phase 2  the pad rows are zeroed; masked softmax over d per query with the scores held in
+//           registers (the score sheet never leaves the CU) + disparity expectation.
+//  phase 3  O^T[c][query] = V^T P: A <- value tile (rows = channels), B <- P read back along the
+//           band (address 65*q - 64*key: conflict-free, immediate offsets, no bounds test thanks to
+//           the zero pad rows); waves split the key range and meet in LDS; stores are 128-B
+//           W-contiguous row segments.
+constexpr int A2_TQ = 64, A2_CK = 32, A2_PAD = 32;
+constexpr int A2_NW = 8, A2_NT = A2_NW * 64, A2_NKG = A2_NW / 2, A2_TPW = 2;  // waves, threads, key groups, tiles/wave/pass
+
+template <int NPT, bool VEC>  // NPT: scores per lane in the softmax phase, >= ceil(D / A2_NW)
+__global__ __launch_bounds__(A2_NT) void cross_attention_mfma_kernel(const float *__restrict__ L,
                                                                    const float *__restrict__ R,
                                                                    const float *__restrict__ V,
                                                                    float *__restrict__ out, float *__restrict__ disp,
@@ -159,10 +214,11 @@ __global__ __launch_bounds__(256) void cross_attention_mfma_kernel(const float *
     extern __shared__ f32x4 smem4[];
     const int KS = A2_TQ + Dk + 1;                 // odd row stride: row- and column-wise reads conflict-free
     const int NKT = (A2_TQ + Dk) / 32;             // key tiles covered by this WG
-    float *P = reinterpret_cast<float *>(smem4);   // [D][64]
-    float *Ks = P + (size_t)D * A2_TQ;             // [CK][KS]  (K chunk, later V chunk)
+    const int PROWS = Dk + 2 * A2_PAD;
+    float *P = reinterpret_cast<float *>(smem4);   // [PROWS][64], row = 32 + d
+    float *Ks = P + (size_t)PROWS * A2_TQ;         // [CK][KS]  (K chunk, later V chunk)
     float *Qs = Ks + A2_CK * KS;                   // [CK][64]  (Q chunk; later reduction scratch)
-    float *red = Qs;                               // [4][64] x 2 in phase 2; [2][16][64] in phase 3
+    float *red = Qs;
 
     const int w0 = blockIdx.x * A2_TQ, h = blockIdx.y, b = blockIdx.z;
     const int kb = w0 - Dk;                        // global w of key column 0
@@ -170,69 +226,71 @@ __global__ __launch_bounds__(256) void cross_attention_mfma_kernel(const float *
     const int l31 = lane & 31, half = lane >> 5;
     const size_t HW = (size_t)H * W;
     const int qt = wave & 1;                       // query tile of this wave
-    const int q_lo = w0 + qt * 32;                 // first query (global w) of the tile
+    const int qq = qt * 32 + l31;                  // query column of this lane
+    const int NKH = (NKT + A2_NKG - 1) / A2_NKG;
+    const int kg = wave >> 1;                      // key-tile group: tiles [kg*NKH, kt_end)
+    const int kt_end = ((kg + 1) * NKH < NKT) ? (kg + 1) * NKH : NKT;
+    // tile pair (qt, kt) touches the band iff 0 <= dq <= Dk, dq = Dk + (qt - kt)*32
+    auto in_band = [&](int kt) { const int dq = Dk + (qt - kt) * 32; return dq >= 0 && dq <= Dk; };
 
     // ---------------- phase 1: band logits
     {
-        const int kg = wave >> 1;                  // key-tile group: tiles kg*NKH .. (kg+1)*NKH-1
-        const int NKH = (NKT + 1) / 2;
-        f32x16 acc[4];                             // up to 4 key tiles per wave per pass
-        const int kt_end = ((kg + 1) * NKH < NKT) ? (kg + 1) * NKH : NKT;  // this wave's tiles: [kg*NKH, kt_end)
-        const int npass = (NKH + 3) / 4;           // identical for every wave: the loop body has barriers
+        f32x16 acc[A2_TPW];
+        const int npass = (NKH + A2_TPW - 1) / A2_TPW;           // identical for every wave: the loop body has barriers
         for (int pass = 0; pass < npass; ++pass) {
-            const int kt0 = kg * NKH + pass * 4;
+            const int kt0 = kg * NKH + pass * A2_TPW;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < A2_TPW; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
             for (int c0 = 0; c0 < C; c0 += A2_CK) {
                 const int ncc = (C - c0) < A2_CK ? (C - c0) : A2_CK;
                 __syncthreads();
-                stage_rows<A2_CK>(Ks, KS, R + ((size_t)b * C + c0) * HW + (size_t)h * W, HW, ncc, kb, A2_TQ + Dk, W, tid);
-                stage_rows<A2_CK>(Qs, A2_TQ, L + ((size_t)b * C + c0) * HW + (size_t)h * W, HW, ncc, w0, A2_TQ, W, tid);
+                stage_rows<A2_CK, VEC, A2_NT>(Ks, KS, R + ((size_t)b * C + c0) * HW + (size_t)h * W, HW, ncc, kb, A2_TQ + Dk, W, tid);
+                stage_rows<A2_CK, VEC, A2_NT>(Qs, A2_TQ, L + ((size_t)b * C + c0) * HW + (size_t)h * W, HW, ncc, w0, A2_TQ, W, tid);
                 __syncthreads();
+                const float *qp = Qs + half * A2_TQ + qq;
+                const float *kp = Ks + half * KS + kt0 * 32 + l31;
 #pragma unroll 4
                 for (int s = 0; s < A2_CK / 2; ++s) {
-                    const int c = 2 * s + half;
-                    const float qv = Qs[c * A2_TQ + qt * 32 + l31];
+                    const float qv = qp[2 * s * A2_TQ];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int kt = kt0 + t;
-                        if (kt < kt_end) {   // wave-uniform
-                            const float kv = Ks[c * KS + kt * 32 + l31];
+                    for (int t = 0; t < A2_TPW; ++t) {
+                        if (kt0 + t < kt_end && in_band(kt0 + t)) {   // wave-uniform
+                            const float kv = kp[2 * s * KS + t * 32];
                             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qv, acc[t], 0, 0, 0);
                         }
                     }
                 }
             }
-            // scatter the band part of each tile into the score sheet
+            // scatter: row = 32 + d, d = Dk + qq - (kt*32 + ko), ko = (r&3) + 8*(r>>2) + 4*half
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < A2_TPW; ++t) {
                 const int kt = kt0 + t;
-                if (kt < kt_end) {
+                if (kt < kt_end && in_band(kt)) {
+                    float *pp = P + (A2_PAD + Dk + qq - kt * 32 - 4 * half) * A2_TQ + qq;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kb + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;  // global w of the key
-                        const int d = (q_lo + l31) - key;
-                        if (d >= 0 && d < D) P[d * A2_TQ + qt * 32 + l31] = acc[t][r];
-                    }
+                    for (int r = 0; r < 16; ++r) pp[-((r & 3) + 8 * (r >> 2)) * A2_TQ] = acc[t][r];
                 }
             }
         }
     }
     __syncthreads();
-    // ---------------- phase 2: masked softmax over d (4 partial lanes per query), scores held in registers
+    // ---------------- phase 2: zero the pad rows; masked softmax over d (A2_NW partial lanes per query)
     {
+        for (int idx = tid; idx < A2_PAD * A2_TQ; idx += A2_NT) P[idx] = 0.0f;
+        for (int idx = (A2_PAD + D) * A2_TQ + tid; idx < PROWS * A2_TQ; idx += A2_NT) P[idx] = 0.0f;
         const int q = tid & 63, part = tid >> 6;
         const int w = w0 + q;
+        float *pc = P + (A2_PAD + part) * A2_TQ + q;
         float x[NPT];
         float m = -INFINITY;
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
-            const int d = part + 4 * i;
+            const int d = part + A2_NW * i;
             float v = -INFINITY;
             if (d < D) {
-                v = P[d * A2_TQ + q] * scale;
+                v = pc[A2_NW * i * A2_TQ] * scale;
                 if (w - d < 0) v = mask_mode == STEREO_MASK_ZERO ? 0.0f : -INFINITY;
             }
             x[i] = v;
@@ -240,67 +298,65 @@ __global__ __launch_bounds__(256) void cross_attention_mfma_kernel(const float *
         }
         red[part * 64 + q] = m;
         __syncthreads();
-        m = fmaxf(fmaxf(red[q], red[64 + q]), fmaxf(red[128 + q], red[192 + q]));
+        m = red[q];
+#pragma unroll
+        for (int k = 1; k < A2_NW; ++k) m = fmaxf(m, red[k * 64 + q]);
         float s = 0.0f, e = 0.0f;
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
             const float p = fast_exp(x[i] - m);   // x = -inf (d >= D or masked) -> 0
             x[i] = p;
             s += p;
-            e = fmaf(p, (float)(part + 4 * i), e);
+            e = fmaf(p, (float)(part + A2_NW * i), e);
         }
-        red[256 + part * 64 + q] = s;
-        red[512 + part * 64 + q] = e;
+        red[(A2_NW + part) * 64 + q] = s;
+        red[(2 * A2_NW + part) * 64 + q] = e;
         __syncthreads();
-        s = (red[256 + q] + red[320 + q]) + (red[384 + q] + red[448 + q]);
-        e = (red[512 + q] + red[576 + q]) + (red[640 + q] + red[704 + q]);
+        s = 0.0f, e = 0.0f;
+#pragma unroll
+        for (int k = 0; k < A2_NW; ++k) {
+            s += red[(A2_NW + k) * 64 + q];
+            e += red[(2 * A2_NW + k) * 64 + q];
+        }
         const float inv = 1.0f / s;
 #pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            const int d = part + 4 * i;
-            if (d < D) P[d * A2_TQ + q] = x[i] * inv;
-        }
+        for (int i = 0; i < NPT; ++i)
+            if (part + A2_NW * i < D) pc[A2_NW * i * A2_TQ] = x[i] * inv;
         if (part == 0 && disp && w < W) disp[((size_t)b * H + h) * W + w] = e * inv;
     }
     if (out == nullptr) return;
     // ---------------- phase 3: O^T = V^T P, 32 value channels per round
-    const int kh = wave >> 1;                      // key half of this wave
-    const int NKH3 = (NKT + 1) / 2;
     for (int c0 = 0; c0 < Cv; c0 += 32) {
         const int ncc = (Cv - c0) < 32 ? (Cv - c0) : 32;
         __syncthreads();                           // P final / previous round's readers done
-        stage_rows<32>(Ks, KS, V + ((size_t)b * Cv + c0) * HW + (size_t)h * W, HW, ncc, kb, A2_TQ + Dk, W, tid);
+        stage_rows<32, VEC, A2_NT>(Ks, KS, V + ((size_t)b * Cv + c0) * HW + (size_t)h * W, HW, ncc, kb, A2_TQ + Dk, W, tid);
         __syncthreads();
         f32x16 o;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] = 0.0f;
-        const int qq = qt * 32 + l31;              // query column of this lane (B operand)
-        for (int kt = kh * NKH3; kt < (kh + 1) * NKH3 && kt < NKT; ++kt) {
-            // skip key tiles entirely outside the band of this query tile (wave-uniform)
-            const int dmin = q_lo - (kb + kt * 32 + 31), dmax = q_lo + 31 - (kb + kt * 32);
-            if (dmax < 0 || dmin >= D) continue;
-#pragma unroll 4
-            for (int s = 0; s < 16; ++s) {
-                const int x = kt * 32 + 2 * s + half;          // key column in the staged tile
-                const float va = Ks[l31 * KS + x];             // A[i = channel l31][k = key]
-                const int d = (w0 + qq) - (kb + x);
-                const float pb = (d >= 0 && d < D) ? P[d * A2_TQ + qq] : 0.0f;  // B[k = key][j = query]
-                o = __builtin_amdgcn_mfma_f32_32x32x2f32(va, pb, o, 0, 0, 0);
-            }
-        }
-        // reduce the two key halves through LDS (Qs region: 2 x 16 x 64 floats)
-        __syncthreads();
-        if (kh == 1) {
+        for (int kt = kg * NKH; kt < kt_end; ++kt) {
+            if (!in_band(kt)) continue;            // wave-uniform
+            const float *ap = Ks + l31 * KS + kt * 32 + half;                                   // A[i = channel][k = key]
+            const float *bp = P + (A2_PAD + Dk + qq - kt * 32 - half) * A2_TQ + qq;             // B[k = key][j = query]
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[(qt * 16 + r) * 64 + lane] = o[r];
+            for (int s = 0; s < 16; ++s)
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[-2 * s * A2_TQ], o, 0, 0, 0);
+        }
+        // reduce the key groups through LDS (the value tile is no longer read: reuse Ks)
+        __syncthreads();
+        if (kg > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Ks[(((kg - 1) * 2 + qt) * 16 + r) * 64 + lane] = o[r];
         }
         __syncthreads();
-        if (kh == 0) {
+        if (kg == 0) {
             const int w = w0 + qq;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float v = o[r] + red[(qt * 16 + r) * 64 + lane];
+                float v = o[r];
+#pragma unroll
+                for (int k = 1; k < A2_NKG; ++k) v += Ks[(((k - 1) * 2 + qt) * 16 + r) * 64 + lane];
                 if (c < ncc && w < W) out[((size_t)b * Cv + c0 + c) * HW + (size_t)h * W + w] = v;
             }
         }
@@ -324,23 +380,24 @@ extern "C" int stereo_cross_attention_f32(const float *left, const float *right,
     if (!fits_grid_yz(H) || !fits_grid_yz(B)) return STEREO_ERR_UNSUPPORTED;
     {   // v2: MFMA path whenever its LDS footprint fits
         const int Dk = (D + 31) / 32 * 32;
-        const size_t lds2 = ((size_t)D * A2_TQ + (size_t)A2_CK * (A2_TQ + Dk + 1) + (size_t)A2_CK * A2_TQ) * sizeof(float);
-        if (lds2 <= 160 * 1024) {
-            const int npt = (D + 3) / 4;
-            auto kern = npt <= 16 ? cross_attention_mfma_kernel<16>
-                        : npt <= 32 ? cross_attention_mfma_kernel<32>
-                        : npt <= 48 ? cross_attention_mfma_kernel<48>
-                        : npt <= 64 ? cross_attention_mfma_kernel<64>
-                                    : cross_attention_mfma_kernel<104>;
-            if (npt > 104) return STEREO_ERR_UNSUPPORTED;
+        size_t tiles = (size_t)A2_CK * (A2_TQ + Dk + 1) + (size_t)A2_CK * A2_TQ;       // K/V chunk + Q chunk
+        const size_t redsz = (size_t)(A2_NKG - 1) * 2 * 16 * 64;                        // phase-3 partial tiles
+        if (tiles < redsz) tiles = redsz;
+        const size_t lds2 = ((size_t)(Dk + 2 * A2_PAD) * A2_TQ + tiles) * sizeof(float);
+        const int npt = (D + A2_NW - 1) / A2_NW;
+        if (lds2 <= 160 * 1024 && npt <= 64) {
+            const bool vec = (W % 4 == 0) && aligned16(left) && aligned16(right) && (out == nullptr || aligned16(value));
+#define ATT_K(N) (vec ? cross_attention_mfma_kernel<N, true> : cross_attention_mfma_kernel<N, false>)
+            auto kern = npt <= 8 ? ATT_K(8) : npt <= 16 ? ATT_K(16) : npt <= 24 ? ATT_K(24) : npt <= 32 ? ATT_K(32) : ATT_K(64);
+#undef ATT_K
             if (lds2 > 64 * 1024 &&
                 hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds2) != hipSuccess)
                 return STEREO_ERR_UNSUPPORTED;
             const float scale2 = scale_mode == STEREO_SCALE_MEAN ? 1.0f / (float)C : 1.0f / sqrtf((float)C);
             dim3 grid2((W + A2_TQ - 1) / A2_TQ, H, B);
-            hipLaunchKernelGGL(kern, grid2, dim3(256), lds2, as_stream(stream), left, right,
-                               value, out, disp, C, Cv, H, W, D, Dk, mask_mode, scale2);
+            hipLaunchKernelGGL(kern, grid2, dim3(A2_NT), lds2, as_stream(stream), left, right, value, out, disp, C, Cv, H,
+                               W, D, Dk, mask_mode, scale2);
             STEREO_LAUNCH_CHECK();
             return STEREO_OK;
         }
