@@ -17,6 +17,9 @@ constexpr int TW = 256;  // pixels per tile: 64 lanes x 4
 constexpr int NW = 8;    // waves per workgroup
 constexpr int NT = NW * 64;
 constexpr int CCMAX = 8;  // channels staged per LDS round
+#ifndef STEREO_PIPE_NW
+#define STEREO_PIPE_NW 4  // waves per workgroup of the pipelined store kernel
+#endif
 
 // EPI_STORE: write the volume.  EPI_ARGMIN: fold every disparity plane into an
 // online softmax-expectation instead (A1+A4 fused; `vol` is then disp [B,H,W]
@@ -189,6 +192,192 @@ __global__ __launch_bounds__(NT) void gwc_volume_kernel(const float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------
+// Software-pipelined variant (the fast path: W % 4 == 0, Dpad <= 256).
+// One workgroup = (row, 256-pixel tile, batch, disparity part) and walks ALL groups and channel
+// chunks as a sequence of items (g, c0): while the waves run the FMA/LDS loop of item i, the
+// 16-byte global loads of item i+1 are already in flight into registers; the store phase of a
+// group overlaps the next group's loads the same way.  NWV waves per workgroup, each owning DC
+// disparities; the store variant may split the disparity range over several small workgroups so
+// that more independent workgroups share a CU (barriers and phases of different workgroups overlap).
+template <int DC, int NWV, int EPI>
+__global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *__restrict__ L,
+                                                                   const float *__restrict__ R,
+                                                                   float *__restrict__ vol, int C, int H, int W, int D,
+                                                                   int G, int CPG, int Dpad, int CC, float inv_cpg,
+                                                                   int exact_div, float sgn, int nparts)
+{
+    extern __shared__ f32x4 smem4[];
+    float *Rs = reinterpret_cast<float *>(smem4);  // [CC][RS]
+    const int RS = TW + Dpad;
+    float *Ls = Rs + CC * RS;  // [CC][TW]
+
+    constexpr int NTV = NWV * 64;
+    constexpr int NSR = (CCMAX * 512 / 4 + NTV - 1) / NTV;  // staging slots per lane: right tile (Dpad <= 256)
+    constexpr int NSL = (CCMAX * TW / 4 + NTV - 1) / NTV;   //                         left tile
+    const int w0 = blockIdx.x * TW, h = blockIdx.y;
+    const int b = blockIdx.z / nparts, dpart = blockIdx.z - b * nparts;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wl = lane * 4;
+    const size_t HW = (size_t)H * W;
+    const float *Lrow = L + (size_t)b * C * HW + (size_t)h * W;
+    const float *Rrow = R + (size_t)b * C * HW + (size_t)h * W;
+
+    const int d0 = (dpart * NWV + wave) * DC;
+    const bool active = d0 < D;  // wave-uniform
+
+    const int rq = RS / 4, lq = TW / 4;
+    int rc[NSR], rx[NSR], lc[NSL], lx[NSL];
+#pragma unroll
+    for (int k = 0; k < NSR; ++k) {
+        const int q = tid + k * NTV;
+        rc[k] = q / rq;
+        rx[k] = (q - rc[k] * rq) * 4;
+    }
+#pragma unroll
+    for (int k = 0; k < NSL; ++k) {
+        const int q = tid + k * NTV;
+        lc[k] = q / lq;
+        lx[k] = (q - lc[k] * lq) * 4;
+    }
+
+    f32x4 pr[NSR], pl[NSL];
+    auto issue_loads = [&](int cbase, int ncc) {  // channels cbase .. cbase+ncc-1 of this row
+#pragma unroll
+        for (int k = 0; k < NSR; ++k) {
+            const int w = w0 - Dpad + rx[k];
+            const bool ok = rc[k] < ncc && w >= 0 && w + 3 < W;
+            pr[k] = ld4(Rrow + (size_t)(cbase + (ok ? rc[k] : 0)) * HW + (ok ? w : 0));
+            if (!ok) pr[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) {
+            const int w = w0 + lx[k];
+            const bool ok = lc[k] < ncc && w + 3 < W;
+            pl[k] = ld4(Lrow + (size_t)(cbase + (ok ? lc[k] : 0)) * HW + (ok ? w : 0));
+            if (!ok) pl[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    float sm_m[4], sm_s[4], sm_e[4];  // EPI_ARGMIN state
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sm_m[i] = -INFINITY, sm_s[i] = 0.0f, sm_e[i] = 0.0f;
+
+    const int nchunk = (CPG + CC - 1) / CC;
+    const int nitems = G * nchunk;
+    issue_loads(0, CPG < CC ? CPG : CC);
+
+    f32x4 acc[DC];
+    for (int it = 0; it < nitems; ++it) {
+        const int g = it / nchunk, ck = it - g * nchunk;
+        const int c0 = ck * CC;
+        const int ncc = (CPG - c0) < CC ? (CPG - c0) : CC;
+        if (ck == 0) {
+#pragma unroll
+            for (int i = 0; i < DC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();  // readers of the previous item are done
+#pragma unroll
+        for (int k = 0; k < NSR; ++k)
+            if (rc[k] < CC) *reinterpret_cast<f32x4 *>(Rs + rc[k] * RS + rx[k]) = pr[k];
+#pragma unroll
+        for (int k = 0; k < NSL; ++k)
+            if (lc[k] < CC) *reinterpret_cast<f32x4 *>(Ls + lc[k] * TW + lx[k]) = pl[k];
+        __syncthreads();
+        if (it + 1 < nitems) {  // next item's loads fly during this item's math and stores
+            const int g2 = (it + 1) / nchunk, ck2 = (it + 1) - g2 * nchunk;
+            const int c2 = ck2 * CC;
+            issue_loads(g2 * CPG + c2, (CPG - c2) < CC ? (CPG - c2) : CC);
+        }
+        if (active) {
+            const float *rwin = Rs + (Dpad + wl - d0 - DC);
+            for (int c = 0; c < ncc; ++c) {
+                const f32x4 lv = *reinterpret_cast<const f32x4 *>(Ls + c * TW + wl);
+                float win[DC + 4];
+#pragma unroll
+                for (int q = 0; q < DC / 4 + 1; ++q) {
+                    const f32x4 t = *reinterpret_cast<const f32x4 *>(rwin + c * RS + 4 * q);
+                    win[4 * q + 0] = t[0];
+                    win[4 * q + 1] = t[1];
+                    win[4 * q + 2] = t[2];
+                    win[4 * q + 3] = t[3];
+                }
+#pragma unroll
+                for (int dd = 0; dd < DC; ++dd) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[dd][i] = fmaf(lv[i], win[DC + i - dd], acc[dd][i]);
+                }
+            }
+        }
+        if (ck == nchunk - 1 && active) {  // group finished: epilogue
+            const int w = w0 + wl;
+            if (EPI == EPI_STORE) {
+                float *vbase = vol + (((size_t)b * G + g) * D) * HW + (size_t)h * W;
+#pragma unroll
+                for (int dd = 0; dd < DC; ++dd) {
+                    const int d = d0 + dd;
+                    if (d < D) {
+                        f32x4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float m = exact_div ? acc[dd][i] / (float)CPG : acc[dd][i] * inv_cpg;
+                            o[i] = (w + i >= d) ? m : 0.0f;
+                        }
+                        if (w + 3 < W) st4(vbase + (size_t)d * HW + w, o);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float x[DC];
+                    float cm = sm_m[i];
+#pragma unroll
+                    for (int dd = 0; dd < DC; ++dd) {
+                        const float m = exact_div ? acc[dd][i] / (float)CPG : acc[dd][i] * inv_cpg;
+                        x[dd] = (w + i >= d0 + dd) ? sgn * m : sgn * 0.0f;
+                        if (d0 + dd < D) cm = fmaxf(cm, x[dd]);
+                    }
+                    const float sc = (sm_m[i] == cm) ? 1.0f : fast_exp(sm_m[i] - cm);
+                    float ss = sm_s[i] * sc, ee = sm_e[i] * sc;
+#pragma unroll
+                    for (int dd = 0; dd < DC; ++dd)
+                        if (d0 + dd < D) {
+                            const float p = fast_exp(x[dd] - cm);
+                            ss += p;
+                            ee = fmaf(p, (float)(d0 + dd), ee);
+                        }
+                    sm_m[i] = cm, sm_s[i] = ss, sm_e[i] = ee;
+                }
+            }
+        }
+    }
+    if (EPI == EPI_ARGMIN) {  // single disparity part only (the launcher guarantees nparts == 1)
+        __syncthreads();
+        float *stt = reinterpret_cast<float *>(smem4);  // [3][NWV][TW]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            stt[(0 * NWV + wave) * TW + wl + i] = sm_m[i];
+            stt[(1 * NWV + wave) * TW + wl + i] = sm_s[i];
+            stt[(2 * NWV + wave) * TW + wl + i] = sm_e[i];
+        }
+        __syncthreads();
+        if (tid < TW && w0 + tid < W) {
+            float M = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < NWV; ++k) M = fmaxf(M, stt[(0 * NWV + k) * TW + tid]);
+            float S = 0.0f, E = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NWV; ++k) {
+                const float mk = stt[(0 * NWV + k) * TW + tid];
+                const float sc = (mk == -INFINITY) ? 0.0f : fast_exp(mk - M);
+                S = fmaf(stt[(1 * NWV + k) * TW + tid], sc, S);
+                E = fmaf(stt[(2 * NWV + k) * TW + tid], sc, E);
+            }
+            vol[((size_t)b * H + h) * W + w0 + tid] = E / S;
+        }
+    }
+}
+
 template <int DC, int EPI>
 int launch_gwc(const float *L, const float *R, float *vol, int B, int C, int H, int W, int D, int G, float sgn,
                hipStream_t st)
@@ -201,6 +390,20 @@ int launch_gwc(const float *L, const float *R, float *vol, int B, int C, int H, 
     if (lds > 160 * 1024) return STEREO_ERR_UNSUPPORTED;
     const bool pow2 = (CPG & (CPG - 1)) == 0;
     const bool vec = (W % 4 == 0) && aligned16(L) && aligned16(R) && aligned16(vol);
+    if (vec && D <= NW * DC && Dpad <= 256 && (EPI == EPI_STORE || G == 1)) {
+        // pipelined fast path.  PNW waves per workgroup; the store variant splits the disparity range over
+        // several small workgroups (more independent workgroups per CU), the arg-min variant cannot.
+        constexpr int PNW = (EPI == EPI_STORE) ? STEREO_PIPE_NW : NW;
+        const int nparts = (D + PNW * DC - 1) / (PNW * DC);
+        if (fits_grid_yz((long long)B * nparts)) {
+            auto pk = gwc_volume_pipe_kernel<DC, PNW, EPI>;
+            dim3 pgrid((W + TW - 1) / TW, H, (unsigned)(B * nparts));
+            hipLaunchKernelGGL(pk, pgrid, dim3(PNW * 64), lds, st, L, R, vol, C, H, W, D, G, CPG, Dpad, CC,
+                               1.0f / (float)CPG, pow2 ? 0 : 1, sgn, nparts);
+            STEREO_LAUNCH_CHECK();
+            return STEREO_OK;
+        }
+    }
     dim3 grid((W + TW - 1) / TW, H, (unsigned)(B * G));
     auto kern = vec ? gwc_volume_kernel<DC, true, EPI> : gwc_volume_kernel<DC, false, EPI>;
     if (lds > 64 * 1024) {
