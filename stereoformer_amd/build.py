@@ -31,7 +31,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    flags = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-fno-fast-math", "-Wall",
+    flags = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-fno-fast-math", "-fno-slp-vectorize", "-Wall",
              "-Wno-unused-function"]
     objs = []
     procs = []

@@ -9,6 +9,9 @@
 // the right tile as a sliding window of ds_read_b128.  Every store is a full
 // 1-KiB W-contiguous wave store (16 B/lane); the w<d zeros are written by the
 // same kernel (the reference's new_zeros pass does not exist here).
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
                                                                    const float *__restrict__ R,
                                                                    float *__restrict__ vol, int C, int H, int W, int D,
                                                                    int G, int CPG, int Dpad, int CC, float inv_cpg,
-                                                                   int exact_div, float sgn, int nparts)
+                                                                   int exact_div, float sgn, int nparts, int RB)
 {
     extern __shared__ f32x4 smem4[];
     float *Rs = reinterpret_cast<float *>(smem4);  // [CC][RS]
@@ -215,13 +218,14 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
     constexpr int NTV = NWV * 64;
     constexpr int NSR = (CCMAX * 512 / 4 + NTV - 1) / NTV;  // staging slots per lane: right tile (Dpad <= 256)
     constexpr int NSL = (CCMAX * TW / 4 + NTV - 1) / NTV;   //                         left tile
-    const int w0 = blockIdx.x * TW, h = blockIdx.y;
+    const int w0 = blockIdx.x * TW, h0 = blockIdx.y * RB;  // RB consecutive rows per workgroup
+    const int nrows = (H - h0) < RB ? (H - h0) : RB;
     const int b = blockIdx.z / nparts, dpart = blockIdx.z - b * nparts;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wl = lane * 4;
     const size_t HW = (size_t)H * W;
-    const float *Lrow = L + (size_t)b * C * HW + (size_t)h * W;
-    const float *Rrow = R + (size_t)b * C * HW + (size_t)h * W;
+    const float *Lb = L + (size_t)b * C * HW;
+    const float *Rb = R + (size_t)b * C * HW;
 
     const int d0 = (dpart * NWV + wave) * DC;
     const bool active = d0 < D;  // wave-uniform
@@ -242,7 +246,8 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
     }
 
     f32x4 pr[NSR], pl[NSL];
-    auto issue_loads = [&](int cbase, int ncc) {  // channels cbase .. cbase+ncc-1 of this row
+    auto issue_loads = [&](int h, int cbase, int ncc) {  // channels cbase .. cbase+ncc-1 of row h
+        const float *Rrow = Rb + (size_t)h * W, *Lrow = Lb + (size_t)h * W;
 #pragma unroll
         for (int k = 0; k < NSR; ++k) {
             const int w = w0 - Dpad + rx[k];
@@ -264,35 +269,50 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
     for (int i = 0; i < 4; ++i) sm_m[i] = -INFINITY, sm_s[i] = 0.0f, sm_e[i] = 0.0f;
 
     const int nchunk = (CPG + CC - 1) / CC;
-    const int nitems = G * nchunk;
-    issue_loads(0, CPG < CC ? CPG : CC);
+    const int per_row = G * nchunk;
+    const int nitems = nrows * per_row;  // the pipeline runs across groups, chunks AND rows: the stores of one
+                                         // row drain while the next row is being computed
+    const int BUF = CC * (RS + TW);  // floats per LDS buffer; two buffers, ONE barrier per item
+    auto item_loads = [&](int item) {
+        const int r2 = item / per_row, i2 = item - r2 * per_row;
+        const int g2 = i2 / nchunk, ck2 = i2 - g2 * nchunk;
+        const int c2 = ck2 * CC;
+        issue_loads(h0 + r2, g2 * CPG + c2, (CPG - c2) < CC ? (CPG - c2) : CC);
+    };
+    auto commit = [&](int buf) {  // prefetched registers -> LDS buffer `buf`
+        float *rs = Rs + buf * BUF, *ls = Ls + buf * BUF;
+#pragma unroll
+        for (int k = 0; k < NSR; ++k)
+            if (rc[k] < CC) *reinterpret_cast<f32x4 *>(rs + rc[k] * RS + rx[k]) = pr[k];
+#pragma unroll
+        for (int k = 0; k < NSL; ++k)
+            if (lc[k] < CC) *reinterpret_cast<f32x4 *>(ls + lc[k] * TW + lx[k]) = pl[k];
+    };
+    item_loads(0);
+    commit(0);
+    if (nitems > 1) item_loads(1);
+    __syncthreads();
 
     f32x4 acc[DC];
     for (int it = 0; it < nitems; ++it) {
-        const int g = it / nchunk, ck = it - g * nchunk;
+        const int r = it / per_row, ir = it - r * per_row;
+        const int g = ir / nchunk, ck = ir - g * nchunk;
+        const int h = h0 + r;
         const int c0 = ck * CC;
         const int ncc = (CPG - c0) < CC ? (CPG - c0) : CC;
         if (ck == 0) {
 #pragma unroll
             for (int i = 0; i < DC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        __syncthreads();  // readers of the previous item are done
-#pragma unroll
-        for (int k = 0; k < NSR; ++k)
-            if (rc[k] < CC) *reinterpret_cast<f32x4 *>(Rs + rc[k] * RS + rx[k]) = pr[k];
-#pragma unroll
-        for (int k = 0; k < NSL; ++k)
-            if (lc[k] < CC) *reinterpret_cast<f32x4 *>(Ls + lc[k] * TW + lx[k]) = pl[k];
-        __syncthreads();
-        if (it + 1 < nitems) {  // next item's loads fly during this item's math and stores
-            const int g2 = (it + 1) / nchunk, ck2 = (it + 1) - g2 * nchunk;
-            const int c2 = ck2 * CC;
-            issue_loads(g2 * CPG + c2, (CPG - c2) < CC ? (CPG - c2) : CC);
-        }
+        // item it+1 (in registers since the previous iteration) -> the other buffer: its last readers
+        // (item it-1) passed the barrier that ended the previous iteration.
+        if (it + 1 < nitems) commit((it + 1) & 1);
+        if (it + 2 < nitems) item_loads(it + 2);  // in flight during this item's math and stores
+        const float *Rcur = Rs + (it & 1) * BUF, *Lcur = Ls + (it & 1) * BUF;
         if (active) {
-            const float *rwin = Rs + (Dpad + wl - d0 - DC);
+            const float *rwin = Rcur + (Dpad + wl - d0 - DC);
             for (int c = 0; c < ncc; ++c) {
-                const f32x4 lv = *reinterpret_cast<const f32x4 *>(Ls + c * TW + wl);
+                const f32x4 lv = *reinterpret_cast<const f32x4 *>(Lcur + c * TW + wl);
                 float win[DC + 4];
 #pragma unroll
                 for (int q = 0; q < DC / 4 + 1; ++q) {
@@ -313,17 +333,28 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
             const int w = w0 + wl;
             if (EPI == EPI_STORE) {
                 float *vbase = vol + (((size_t)b * G + g) * D) * HW + (size_t)h * W;
+                const bool interior = (w0 >= d0 + DC - 1) && (w0 + TW <= W) && (d0 + DC <= D);  // wave-uniform
+                if (interior) {  // no w<d zeros, no ragged edge: straight scaled stores
 #pragma unroll
-                for (int dd = 0; dd < DC; ++dd) {
-                    const int d = d0 + dd;
-                    if (d < D) {
+                    for (int dd = 0; dd < DC; ++dd) {
                         f32x4 o;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float m = exact_div ? acc[dd][i] / (float)CPG : acc[dd][i] * inv_cpg;
-                            o[i] = (w + i >= d) ? m : 0.0f;
+                        for (int i = 0; i < 4; ++i) o[i] = exact_div ? acc[dd][i] / (float)CPG : acc[dd][i] * inv_cpg;
+                        st4(vbase + (size_t)(d0 + dd) * HW + w, o);
+                    }
+                } else {
+#pragma unroll
+                    for (int dd = 0; dd < DC; ++dd) {
+                        const int d = d0 + dd;
+                        if (d < D) {
+                            f32x4 o;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float m = exact_div ? acc[dd][i] / (float)CPG : acc[dd][i] * inv_cpg;
+                                o[i] = (w + i >= d) ? m : 0.0f;
+                            }
+                            if (w + 3 < W) st4(vbase + (size_t)d * HW + w, o);
                         }
-                        if (w + 3 < W) st4(vbase + (size_t)d * HW + w, o);
                     }
                 }
             } else {
@@ -350,32 +381,326 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
                 }
             }
         }
-    }
-    if (EPI == EPI_ARGMIN) {  // single disparity part only (the launcher guarantees nparts == 1)
-        __syncthreads();
-        float *stt = reinterpret_cast<float *>(smem4);  // [3][NWV][TW]
+        if (EPI == EPI_ARGMIN && ir == per_row - 1) {  // row finished: combine the waves' softmax states
+            // (single disparity part: the launcher guarantees nparts == 1).  Uses its own LDS region.
+            float *stt = reinterpret_cast<float *>(smem4) + 2 * BUF;  // [3][NWV][TW]
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            stt[(0 * NWV + wave) * TW + wl + i] = sm_m[i];
-            stt[(1 * NWV + wave) * TW + wl + i] = sm_s[i];
-            stt[(2 * NWV + wave) * TW + wl + i] = sm_e[i];
-        }
-        __syncthreads();
-        if (tid < TW && w0 + tid < W) {
-            float M = -INFINITY;
-#pragma unroll
-            for (int k = 0; k < NWV; ++k) M = fmaxf(M, stt[(0 * NWV + k) * TW + tid]);
-            float S = 0.0f, E = 0.0f;
-#pragma unroll
-            for (int k = 0; k < NWV; ++k) {
-                const float mk = stt[(0 * NWV + k) * TW + tid];
-                const float sc = (mk == -INFINITY) ? 0.0f : fast_exp(mk - M);
-                S = fmaf(stt[(1 * NWV + k) * TW + tid], sc, S);
-                E = fmaf(stt[(2 * NWV + k) * TW + tid], sc, E);
+            for (int i = 0; i < 4; ++i) {
+                stt[(0 * NWV + wave) * TW + wl + i] = sm_m[i];
+                stt[(1 * NWV + wave) * TW + wl + i] = sm_s[i];
+                stt[(2 * NWV + wave) * TW + wl + i] = sm_e[i];
+                sm_m[i] = -INFINITY, sm_s[i] = 0.0f, sm_e[i] = 0.0f;
             }
-            vol[((size_t)b * H + h) * W + w0 + tid] = E / S;
+            __syncthreads();
+            if (tid < TW && w0 + tid < W) {
+                float M = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < NWV; ++k) M = fmaxf(M, stt[(0 * NWV + k) * TW + tid]);
+                float S = 0.0f, E = 0.0f;
+#pragma unroll
+                for (int k = 0; k < NWV; ++k) {
+                    const float mk = stt[(0 * NWV + k) * TW + tid];
+                    const float sc = (mk == -INFINITY) ? 0.0f : fast_exp(mk - M);
+                    S = fmaf(stt[(1 * NWV + k) * TW + tid], sc, S);
+                    E = fmaf(stt[(2 * NWV + k) * TW + tid], sc, E);
+                }
+                vol[((size_t)b * H + h) * W + w0 + tid] = E / S;
+            }
         }
+        __syncthreads();  // all waves: done reading buffer it&1, buffer (it+1)&1 fully written
     }
+}
+
+// ---------------------------------------------------------------------------
+// Channel-pair packed variant: the FMA stream is v_pk_fma_f32 with NO operand shuffles.
+// fp32 VALU peak on CDNA4 needs the packed form (one v_fma_f32 and one v_pk_fma_f32 both hold the
+// SIMD for 4 cycles); pairing two PIXELS (what the SLP vectoriser does with the kernel above) makes
+// every odd disparity read a mis-aligned register pair -> one v_pk_mov per 4 FMAs.  Here the two
+// halves of a packed register are two CHANNELS: LDS holds the tiles channel-interleaved
+// ([pair][x][2]), so any window offset is an aligned pair, and each lane keeps two partial sums
+// (even / odd channels) per output that are added in the epilogue.  Same software pipeline as
+// above (two LDS buffers, one barrier per item, next item's global loads in flight), extended over
+// rows and over disparity passes (NWV*DC disparities per pass).
+template <int DC, int NWV, int EPI>
+__global__ __launch_bounds__(NWV * 64) void gwc_volume_pk_kernel(const float *__restrict__ L,
+                                                                 const float *__restrict__ R,
+                                                                 float *__restrict__ vol, int C, int H, int W, int D,
+                                                                 int G, int CPG, int Dpad, int CP, float inv_cpg,
+                                                                 int exact_div, float sgn, int RB)
+{
+    extern __shared__ f32x4 smem4[];
+    constexpr int NTV = NWV * 64;
+    const int RS = TW + Dpad;                       // pixels per right-tile row
+    const int BUF = CP * (RS + TW) * 2;             // floats per buffer: [CP][RS][2] + [CP][TW][2]
+    float *S0 = reinterpret_cast<float *>(smem4);
+
+    const int w0 = blockIdx.x * TW, h0 = blockIdx.y * RB, b = blockIdx.z;
+    const int nrows = (H - h0) < RB ? (H - h0) : RB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wl = lane * 4;
+    const size_t HW = (size_t)H * W;
+    const float *Lb = L + (size_t)b * C * HW;
+    const float *Rb = R + (size_t)b * C * HW;
+
+    // staging slot of this lane: one (channel pair, pixel quad) of the right tile and one of the left tile
+    const int rq = RS / 4, lq = TW / 4;
+    const int rcp = tid / rq, rx = (tid - rcp * rq) * 4;
+    const int lcp = tid / lq, lx = (tid - lcp * lq) * 4;
+    f32x4 pr0, pr1, pl0, pl1;  // even / odd channel of the pair
+    auto issue_loads = [&](int h, int cbase, int ncc) {
+        const float *Rrow = Rb + (size_t)h * W, *Lrow = Lb + (size_t)h * W;
+        {
+            const int w = w0 - Dpad + rx, c = 2 * rcp;
+            const bool okw = rcp < CP && w >= 0 && w + 3 < W;
+            const bool ok0 = okw && c < ncc, ok1 = okw && c + 1 < ncc;
+            pr0 = ld4(Rrow + (size_t)(cbase + (ok0 ? c : 0)) * HW + (ok0 ? w : 0));
+            pr1 = ld4(Rrow + (size_t)(cbase + (ok1 ? c + 1 : 0)) * HW + (ok1 ? w : 0));
+            if (!ok0) pr0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (!ok1) pr1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        {
+            const int w = w0 + lx, c = 2 * lcp;
+            const bool okw = lcp < CP && w + 3 < W;
+            const bool ok0 = okw && c < ncc, ok1 = okw && c + 1 < ncc;
+            pl0 = ld4(Lrow + (size_t)(cbase + (ok0 ? c : 0)) * HW + (ok0 ? w : 0));
+            pl1 = ld4(Lrow + (size_t)(cbase + (ok1 ? c + 1 : 0)) * HW + (ok1 ? w : 0));
+            if (!ok0) pl0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (!ok1) pl1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto commit = [&](int buf) {
+        float *rs = S0 + buf * BUF, *ls = rs + CP * RS * 2;
+        if (rcp < CP) {
+            float *d = rs + (rcp * RS + rx) * 2;
+            *reinterpret_cast<f32x4 *>(d) = (f32x4){pr0[0], pr1[0], pr0[1], pr1[1]};
+            *reinterpret_cast<f32x4 *>(d + 4) = (f32x4){pr0[2], pr1[2], pr0[3], pr1[3]};
+        }
+        if (lcp < CP) {
+            float *d = ls + (lcp * TW + lx) * 2;
+            *reinterpret_cast<f32x4 *>(d) = (f32x4){pl0[0], pl1[0], pl0[1], pl1[1]};
+            *reinterpret_cast<f32x4 *>(d + 4) = (f32x4){pl0[2], pl1[2], pl0[3], pl1[3]};
+        }
+    };
+
+    float sm_m[4], sm_s[4], sm_e[4];  // EPI_ARGMIN state
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sm_m[i] = -INFINITY, sm_s[i] = 0.0f, sm_e[i] = 0.0f;
+
+    const int CCH = 2 * CP;                          // channels per item
+    const int nchunk = (CPG + CCH - 1) / CCH;
+    const int npass = (D + NWV * DC - 1) / (NWV * DC);
+    const int per_pass = G * nchunk, per_row = npass * per_pass;
+    const int nitems = nrows * per_row;
+    auto item_loads = [&](int item) {
+        const int r2 = item / per_row, i2 = (item - r2 * per_row) % per_pass;
+        const int g2 = i2 / nchunk, ck2 = i2 - g2 * nchunk;
+        const int c2 = ck2 * CCH;
+        issue_loads(h0 + r2, g2 * CPG + c2, (CPG - c2) < CCH ? (CPG - c2) : CCH);
+    };
+    item_loads(0);
+    commit(0);
+    if (nitems > 1) item_loads(1);
+    __syncthreads();
+
+    f32x2 acc[DC][4];
+    for (int it = 0; it < nitems; ++it) {
+        const int r = it / per_row, ir = it - r * per_row;
+        const int pass = ir / per_pass, ip = ir - pass * per_pass;
+        const int g = ip / nchunk, ck = ip - g * nchunk;
+        const int h = h0 + r;
+        const int c0 = ck * CCH;
+        const int npair = (((CPG - c0) < CCH ? (CPG - c0) : CCH) + 1) >> 1;
+        const int d0 = (pass * NWV + wave) * DC;
+        const bool active = d0 < D;  // wave-uniform
+        if (ck == 0) {
+#pragma unroll
+            for (int dd = 0; dd < DC; ++dd)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[dd][i] = (f32x2){0.f, 0.f};
+        }
+        if (it + 1 < nitems) commit((it + 1) & 1);
+        if (it + 2 < nitems) item_loads(it + 2);
+        const float *Rcur = S0 + (it & 1) * BUF, *Lcur = Rcur + CP * RS * 2;
+        if (active) {
+            const float *rwin = Rcur + (Dpad + wl - d0 - DC) * 2;  // window origin, pixel units -> float2
+            const float *lwin = Lcur + wl * 2;
+            for (int cp = 0; cp < npair; ++cp) {
+                f32x2 lv[4], win[DC + 4];
+                {
+                    const f32x4 t0 = *reinterpret_cast<const f32x4 *>(lwin + cp * TW * 2);
+                    const f32x4 t1 = *reinterpret_cast<const f32x4 *>(lwin + cp * TW * 2 + 4);
+                    lv[0] = (f32x2){t0[0], t0[1]};
+                    lv[1] = (f32x2){t0[2], t0[3]};
+                    lv[2] = (f32x2){t1[0], t1[1]};
+                    lv[3] = (f32x2){t1[2], t1[3]};
+                }
+#pragma unroll
+                for (int q = 0; q < (DC + 4) / 2; ++q) {
+                    const f32x4 t = *reinterpret_cast<const f32x4 *>(rwin + cp * RS * 2 + 4 * q);
+                    win[2 * q] = (f32x2){t[0], t[1]};
+                    win[2 * q + 1] = (f32x2){t[2], t[3]};
+                }
+#pragma unroll
+                for (int dd = 0; dd < DC; ++dd) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[dd][i] = __builtin_elementwise_fma(lv[i], win[DC + i - dd], acc[dd][i]);
+                }
+            }
+        }
+        if (ck == nchunk - 1 && active) {  // group finished for this pass: epilogue
+            const int w = w0 + wl;
+            if (EPI == EPI_STORE) {
+                float *vbase = vol + (((size_t)b * G + g) * D) * HW + (size_t)h * W;
+                const bool interior = (w0 >= d0 + DC - 1) && (w0 + TW <= W) && (d0 + DC <= D);  // wave-uniform
+#pragma unroll
+                for (int dd = 0; dd < DC; ++dd) {
+                    const int d = d0 + dd;
+                    f32x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float sum = acc[dd][i][0] + acc[dd][i][1];
+                        const float m = exact_div ? sum / (float)CPG : sum * inv_cpg;
+                        o[i] = (interior || w + i >= d) ? m : 0.0f;
+                    }
+                    if (interior || (d < D && w + 3 < W)) st4(vbase + (size_t)d * HW + w, o);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float x[DC];
+                    float cm = sm_m[i];
+#pragma unroll
+                    for (int dd = 0; dd < DC; ++dd) {
+                        const float sum = acc[dd][i][0] + acc[dd][i][1];
+                        const float m = exact_div ? sum / (float)CPG : sum * inv_cpg;
+                        x[dd] = (w + i >= d0 + dd) ? sgn * m : sgn * 0.0f;
+                        if (d0 + dd < D) cm = fmaxf(cm, x[dd]);
+                    }
+                    const float sc = (sm_m[i] == cm) ? 1.0f : fast_exp(sm_m[i] - cm);
+                    float ss = sm_s[i] * sc, ee = sm_e[i] * sc;
+#pragma unroll
+                    for (int dd = 0; dd < DC; ++dd)
+                        if (d0 + dd < D) {
+                            const float p = fast_exp(x[dd] - cm);
+                            ss += p;
+                            ee = fmaf(p, (float)(d0 + dd), ee);
+                        }
+                    sm_m[i] = cm, sm_s[i] = ss, sm_e[i] = ee;
+                }
+            }
+        }
+        if (EPI == EPI_ARGMIN && ir == per_row - 1) {  // row finished: combine the waves' softmax states
+            float *stt = S0 + 2 * BUF;                  // [3][NWV][TW], its own LDS region
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                stt[(0 * NWV + wave) * TW + wl + i] = sm_m[i];
+                stt[(1 * NWV + wave) * TW + wl + i] = sm_s[i];
+                stt[(2 * NWV + wave) * TW + wl + i] = sm_e[i];
+                sm_m[i] = -INFINITY, sm_s[i] = 0.0f, sm_e[i] = 0.0f;
+            }
+            __syncthreads();
+            if (tid < TW && w0 + tid < W) {
+                float M = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < NWV; ++k) M = fmaxf(M, stt[(0 * NWV + k) * TW + tid]);
+                float S = 0.0f, E = 0.0f;
+#pragma unroll
+                for (int k = 0; k < NWV; ++k) {
+                    const float mk = stt[(0 * NWV + k) * TW + tid];
+                    const float sc = (mk == -INFINITY) ? 0.0f : fast_exp(mk - M);
+                    S = fmaf(stt[(1 * NWV + k) * TW + tid], sc, S);
+                    E = fmaf(stt[(2 * NWV + k) * TW + tid], sc, E);
+                }
+                vol[((size_t)b * H + h) * W + w0 + tid] = E / S;
+            }
+        }
+        __syncthreads();  // all waves: done reading buffer it&1, buffer (it+1)&1 fully written
+    }
+}
+
+template <int DC, int NWV, int EPI>
+int launch_pk(const float *L, const float *R, float *vol, int B, int C, int H, int W, int D, int G, float sgn,
+              hipStream_t st)
+{
+    const int CPG = C / G;
+    const int Dpad = ((D + DC - 1) / DC) * DC;
+    int CP = (CPG + 1) / 2;                          // channel pairs staged per item
+    if (CP > 4) CP = 4;
+    // staging: one (pair, quad) slot per lane
+    if (CP * ((TW + Dpad) / 4) > NWV * 64 || CP * (TW / 4) > NWV * 64) return STEREO_ERR_UNSUPPORTED;
+    size_t lds = (size_t)2 * CP * (size_t)(TW + Dpad + TW) * 2 * sizeof(float);
+    if (EPI == EPI_ARGMIN) lds += (size_t)3 * NWV * TW * sizeof(float);
+    if (lds > 160 * 1024 || !fits_grid_yz(B)) return STEREO_ERR_UNSUPPORTED;
+    int RB = 4;
+    if (const char *e = getenv("STEREO_VOL_ROWS")) RB = atoi(e) > 0 ? atoi(e) : RB;
+    while (RB > 1 && (long long)((H + RB - 1) / RB) * ((W + TW - 1) / TW) * B < 2048) RB >>= 1;
+    auto kern = gwc_volume_pk_kernel<DC, NWV, EPI>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return STEREO_ERR_UNSUPPORTED;
+    const bool pow2 = (CPG & (CPG - 1)) == 0;
+    dim3 grid((W + TW - 1) / TW, (H + RB - 1) / RB, (unsigned)B);
+    hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, st, L, R, vol, C, H, W, D, G, CPG, Dpad, CP, 1.0f / (float)CPG,
+                       pow2 ? 0 : 1, sgn, RB);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+template <int DC, int NWV, int EPI>
+int launch_pipe(const float *L, const float *R, float *vol, int B, int C, int H, int W, int D, int G, float sgn,
+                hipStream_t st)
+{
+    const int CPG = C / G;
+    const int Dpad = ((D + DC - 1) / DC) * DC;
+    const int CC = CPG < CCMAX ? CPG : CCMAX;
+    size_t lds = (size_t)2 * CC * (size_t)(TW + Dpad + TW) * sizeof(float);  // two staging buffers
+    if (EPI == EPI_ARGMIN) lds += (size_t)3 * NWV * TW * sizeof(float);          // + softmax-state exchange
+    int RB = 4;                                                                  // rows per workgroup
+    if (const char *e = getenv("STEREO_VOL_ROWS")) RB = atoi(e) > 0 ? atoi(e) : RB;
+    while (RB > 1 && (long long)((H + RB - 1) / RB) * ((W + TW - 1) / TW) * B * ((D + NWV * DC - 1) / (NWV * DC)) < 2048)
+        RB >>= 1;                                                                // keep >= 8 workgroups per CU
+    const int nparts = (D + NWV * DC - 1) / (NWV * DC);
+    if (Dpad > 256 || lds > 64 * 1024 || !fits_grid_yz((long long)B * nparts) || (EPI == EPI_ARGMIN && nparts != 1))
+        return STEREO_ERR_UNSUPPORTED;
+    const bool pow2 = (CPG & (CPG - 1)) == 0;
+    dim3 pgrid((W + TW - 1) / TW, (H + RB - 1) / RB, (unsigned)(B * nparts));
+    hipLaunchKernelGGL((gwc_volume_pipe_kernel<DC, NWV, EPI>), pgrid, dim3(NWV * 64), lds, st, L, R, vol, C, H, W, D, G,
+                       CPG, Dpad, CC, 1.0f / (float)CPG, pow2 ? 0 : 1, sgn, nparts, RB);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+// Pipelined-path configuration (DC disparities per wave, NWV waves per workgroup).
+template <int EPI>
+int pipe_dispatch(const float *L, const float *R, float *vol, int B, int C, int H, int W, int D, int G, float sgn,
+                  hipStream_t st)
+{
+    int dc = 0, nw = 0;
+    if (const char *e = getenv("STEREO_VOL_CFG")) sscanf(e, "%d,%d", &dc, &nw);  // tuning knob (dev only)
+    if (dc == 0) {  // measured on MI355X at cfg-2 (tools/vol_sweep.sh): (16,12) is the fastest for both epilogues
+        if (D <= 64) dc = 8, nw = 8;
+        else dc = 16, nw = 12;
+    }
+#define PK_CASE(DCV, NWVV) \
+    if (dc == -DCV && nw == NWVV) return launch_pk<DCV, NWVV, EPI>(L, R, vol, B, C, H, W, D, G, sgn, st)
+    PK_CASE(8, 12);   // negative dc selects the channel-pair packed kernel
+    PK_CASE(8, 8);
+    PK_CASE(12, 8);
+    PK_CASE(12, 16);
+    PK_CASE(16, 12);
+#undef PK_CASE
+#define PIPE_CASE(DCV, NWVV) \
+    if (dc == DCV && nw == NWVV) return launch_pipe<DCV, NWVV, EPI>(L, R, vol, B, C, H, W, D, G, sgn, st)
+    PIPE_CASE(8, 8);
+    PIPE_CASE(12, 8);
+    PIPE_CASE(16, 6);
+    PIPE_CASE(16, 8);
+    PIPE_CASE(16, 12);
+    PIPE_CASE(24, 8);
+#undef PIPE_CASE
+    return STEREO_ERR_UNSUPPORTED;
 }
 
 template <int DC, int EPI>
@@ -390,20 +715,6 @@ int launch_gwc(const float *L, const float *R, float *vol, int B, int C, int H, 
     if (lds > 160 * 1024) return STEREO_ERR_UNSUPPORTED;
     const bool pow2 = (CPG & (CPG - 1)) == 0;
     const bool vec = (W % 4 == 0) && aligned16(L) && aligned16(R) && aligned16(vol);
-    if (vec && D <= NW * DC && Dpad <= 256 && (EPI == EPI_STORE || G == 1)) {
-        // pipelined fast path.  PNW waves per workgroup; the store variant splits the disparity range over
-        // several small workgroups (more independent workgroups per CU), the arg-min variant cannot.
-        constexpr int PNW = (EPI == EPI_STORE) ? STEREO_PIPE_NW : NW;
-        const int nparts = (D + PNW * DC - 1) / (PNW * DC);
-        if (fits_grid_yz((long long)B * nparts)) {
-            auto pk = gwc_volume_pipe_kernel<DC, PNW, EPI>;
-            dim3 pgrid((W + TW - 1) / TW, H, (unsigned)(B * nparts));
-            hipLaunchKernelGGL(pk, pgrid, dim3(PNW * 64), lds, st, L, R, vol, C, H, W, D, G, CPG, Dpad, CC,
-                               1.0f / (float)CPG, pow2 ? 0 : 1, sgn, nparts);
-            STEREO_LAUNCH_CHECK();
-            return STEREO_OK;
-        }
-    }
     dim3 grid((W + TW - 1) / TW, H, (unsigned)(B * G));
     auto kern = vec ? gwc_volume_kernel<DC, true, EPI> : gwc_volume_kernel<DC, false, EPI>;
     if (lds > 64 * 1024) {
@@ -433,6 +744,10 @@ int gwc_dispatch(const float *L, const float *R, float *vol, int B, int C, int H
     if (!fits_grid_yz(H) || !fits_grid_yz((long long)B * G)) return STEREO_ERR_UNSUPPORTED;
     if (D > 4096) return STEREO_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);
+    if ((W % 4 == 0) && aligned16(L) && aligned16(R) && aligned16(vol) && (EPI == EPI_STORE || G == 1)) {
+        const int rc = pipe_dispatch<EPI>(L, R, vol, B, C, H, W, D, G, sgn, st);
+        if (rc != STEREO_ERR_UNSUPPORTED) return rc;  // otherwise: generic kernel below
+    }
     if (D <= NW * 8) return launch_gwc<8, EPI>(L, R, vol, B, C, H, W, D, G, sgn, st);
     if (D <= NW * 16) return launch_gwc<16, EPI>(L, R, vol, B, C, H, W, D, G, sgn, st);
     return launch_gwc<24, EPI>(L, R, vol, B, C, H, W, D, G, sgn, st);

@@ -78,6 +78,21 @@ def test_volumes_vs_oracle(S, oracle, shape):
     close(S.build_gwc_volume(dev(L), dev(R), D, G), oracle.gwc_volume(L, R, D, G), **VOL_TOL)
 
 
+@pytest.mark.parametrize("cfg", ["24,8", "16,8", "12,8", "-8,12", "-12,8", "16,12"])
+def test_volume_kernel_variants(S, oracle, cfg, monkeypatch):
+    """Every instantiated (disparities-per-wave, waves) variant of the pipelined volume kernel -- including the
+    channel-pair packed one (negative dc) -- against the oracle, store and fused arg-min epilogues."""
+    monkeypatch.setenv("STEREO_VOL_CFG", cfg)
+    rng = np.random.default_rng(3)
+    for (B, C, H, W, D, G) in ((1, 32, 5, 960, 192, 8), (2, 12, 6, 520, 150, 4), (1, 6, 9, 260, 97, 2)):
+        L = rng.standard_normal((B, C, H, W), dtype=np.float32)
+        R = rng.standard_normal((B, C, H, W), dtype=np.float32)
+        close(S.build_gwc_volume(dev(L), dev(R), D, G), oracle.gwc_volume(L, R, D, G), **VOL_TOL)
+        ref = oracle.corr_volume(L, R, D)
+        close(S.CostVolume(D)(dev(L), dev(R)), ref, **VOL_TOL)
+        close(S.corr_soft_argmin(dev(L), dev(R), D), oracle.soft_argmin(ref), **DISP_TOL)
+
+
 def test_volume_errors_and_edges(S):
     L = torch.randn(1, 6, 3, 8, device="cuda")
     with pytest.raises(NotImplementedError):
