@@ -17,6 +17,7 @@ from .corr import (AlternateCorrBlock, CorrBlock1D, InputPadder, PytorchAlternat
                    coords_grid)
 from .cross_attention import CrossAttentionCostVolume
 from .disparity_warper import disp_warp
+from .pipelines import LowCNNGRULoop, RAFTStereoLoop
 from .update_dlc import (BasicGuidanceNet, DisparityUpdateDLC, DisparityUpdateDLCWithMask,
                          DisparityUpdateDLCWithMaskV2, OffsetPredictionHead, gru_blend, gru_reset)
 from .update_raft import BasicMotionEncoder_LZH, BasicMultiUpdateBlock_LZH, FlowHead, SepConvGRU, pool2x, pool4x
@@ -24,6 +25,7 @@ from .upsample import (ConvAffinityUpsample, interp, resize_bilinear, upflow8, u
                        upsample_flow, upsample_simple8)
 
 __all__ = [
+    "LowCNNGRULoop", "RAFTStereoLoop",
     "BasicGuidanceNet", "DisparityUpdateDLC", "DisparityUpdateDLCWithMask", "DisparityUpdateDLCWithMaskV2",
     "OffsetPredictionHead", "gru_blend", "gru_reset", "BasicMotionEncoder_LZH", "BasicMultiUpdateBlock_LZH",
     "FlowHead", "SepConvGRU", "pool2x", "pool4x",

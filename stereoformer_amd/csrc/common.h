@@ -28,6 +28,7 @@ static inline bool fits_grid_yz(long long v) { return v >= 1 && v <= 65535; }
 
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+__device__ __forceinline__ void st4_nt(float *p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p)); }
 
 // v_exp_f32 based exp: |rel err| ~1e-6 on the softmax range; far inside the 1e-3 disparity bar
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }

@@ -5,6 +5,9 @@
 // along W), keeping an online-softmax state (running max, sum, d-weighted sum)
 // per pixel: the volume is read exactly once.  The with-prob variant re-reads
 // the (then L2/MALL-warm) column to write the normalised probabilities.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void soft_argmin_kernel(const float *__restric
 }
 
 // volg [B, G, D, HW] -> mean over G -> (vol_mean [B, D, HW]) -> disp [B, HW]
-template <int V, int U, bool WRITE_MEAN>
+template <int V, int U, bool WRITE_MEAN, bool NT>
 __global__ __launch_bounds__(256) void group_mean_soft_argmin_kernel(const float *__restrict__ volg,
                                                                      float *__restrict__ vol_mean,
                                                                      float *__restrict__ disp, int G, int D,
@@ -137,7 +140,9 @@ __global__ __launch_bounds__(256) void group_mean_soft_argmin_kernel(const float
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (u < nv) {
-                        const typename Vec<V>::T r = Vec<V>::load(v + (size_t)g * gstride + (size_t)(d0 + u) * HW);
+                        const float *src = v + (size_t)g * gstride + (size_t)(d0 + u) * HW;
+                        const typename Vec<V>::T r =
+                            NT ? __builtin_nontemporal_load(reinterpret_cast<const typename Vec<V>::T *>(src)) : Vec<V>::load(src);
 #pragma unroll
                         for (int i = 0; i < V; ++i) x[u][i] += r[i];
                     }
@@ -246,21 +251,35 @@ extern "C" int stereo_group_mean_soft_argmin_f32(const float *volg, float *vol_m
     hipStream_t st = as_stream(stream);
     const bool vec =
         (HW % 4 == 0) && aligned16(volg) && aligned16(disp) && (vol_mean == nullptr || aligned16(vol_mean));
-#define GM_LAUNCH(V, U, WM)                                                                                           \
-    hipLaunchKernelGGL((group_mean_soft_argmin_kernel<V, U, WM>), dim3(grid_for(n)), dim3(256), 0, st, volg, vol_mean, \
+    int cfg_u = 1, cfg_nt = 1, cfg_cap = 1 << 20;  // measured best on MI355X (tools/gm_sweep.sh): 1 plane x G loads, nt
+    if (const char *e = getenv("STEREO_GM_CFG")) sscanf(e, "%d,%d,%d", &cfg_u, &cfg_nt, &cfg_cap);  // dev tuning knob
+#define GM_LAUNCH(V, U, WM, NTV)                                                                                      \
+    hipLaunchKernelGGL((group_mean_soft_argmin_kernel<V, U, WM, NTV>), dim3(gm_grid), dim3(256), 0, st, volg, vol_mean, \
                        disp, G, D, HW, n, sgn, 1.0f / (float)G, pow2 ? 0 : 1)
     if (vec) {
         const long long n = (long long)B * (HW / 4);
-        if (vol_mean)
-            GM_LAUNCH(4, 2, true);
-        else
-            GM_LAUNCH(4, 2, false);
+        long long gb = (n + 255) / 256;
+        if (gb > 256LL * cfg_cap) gb = 256LL * cfg_cap;
+        const unsigned gm_grid = (unsigned)gb;
+        if (vol_mean) {
+            if (cfg_u == 4 && cfg_nt) GM_LAUNCH(4, 4, true, true);
+            else if (cfg_u == 4) GM_LAUNCH(4, 4, true, false);
+            else if (cfg_u == 1 && cfg_nt) GM_LAUNCH(4, 1, true, true);
+            else if (cfg_u == 1) GM_LAUNCH(4, 1, true, false);
+            else if (cfg_nt) GM_LAUNCH(4, 2, true, true);
+            else GM_LAUNCH(4, 2, true, false);
+        } else {
+            if (cfg_u == 1 && cfg_nt) GM_LAUNCH(4, 1, false, true);
+            else if (cfg_nt) GM_LAUNCH(4, 2, false, true);
+            else GM_LAUNCH(4, 2, false, false);
+        }
     } else {
+        const unsigned gm_grid = grid_for((long long)B * HW);
         const long long n = (long long)B * HW;
         if (vol_mean)
-            GM_LAUNCH(1, 4, true);
+            GM_LAUNCH(1, 4, true, false);
         else
-            GM_LAUNCH(1, 4, false);
+            GM_LAUNCH(1, 4, false, false);
     }
 #undef GM_LAUNCH
     STEREO_LAUNCH_CHECK();

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
                                                                    const float *__restrict__ R,
                                                                    float *__restrict__ vol, int C, int H, int W, int D,
                                                                    int G, int CPG, int Dpad, int CC, float inv_cpg,
-                                                                   int exact_div, float sgn, int nparts, int RB)
+                                                                   int exact_div, float sgn, int nparts, int RB, int nt)
 {
     extern __shared__ f32x4 smem4[];
     float *Rs = reinterpret_cast<float *>(smem4);  // [CC][RS]
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
                         f32x4 o;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) o[i] = exact_div ? acc[dd][i] / (float)CPG : acc[dd][i] * inv_cpg;
-                        st4(vbase + (size_t)(d0 + dd) * HW + w, o);
+                        if (nt) st4_nt(vbase + (size_t)(d0 + dd) * HW + w, o); else st4(vbase + (size_t)(d0 + dd) * HW + w, o);
                     }
                 } else {
 #pragma unroll
@@ -665,9 +665,11 @@ int launch_pipe(const float *L, const float *R, float *vol, int B, int C, int H,
     if (Dpad > 256 || lds > 64 * 1024 || !fits_grid_yz((long long)B * nparts) || (EPI == EPI_ARGMIN && nparts != 1))
         return STEREO_ERR_UNSUPPORTED;
     const bool pow2 = (CPG & (CPG - 1)) == 0;
+    int nt = 0;
+    if (const char *e = getenv("STEREO_VOL_NT")) nt = atoi(e);
     dim3 pgrid((W + TW - 1) / TW, (H + RB - 1) / RB, (unsigned)(B * nparts));
     hipLaunchKernelGGL((gwc_volume_pipe_kernel<DC, NWV, EPI>), pgrid, dim3(NWV * 64), lds, st, L, R, vol, C, H, W, D, G,
-                       CPG, Dpad, CC, 1.0f / (float)CPG, pow2 ? 0 : 1, sgn, nparts, RB);
+                       CPG, Dpad, CC, 1.0f / (float)CPG, pow2 ? 0 : 1, sgn, nparts, RB, nt);
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }

@@ -5,11 +5,17 @@ import math
 import torch
 
 
-def fill_state_dict_(module: torch.nn.Module, seed: float = 0.0) -> None:
+def fill_state_dict_(module: torch.nn.Module, seed: float = 0.0, keys=None, prefix: str = "") -> None:
     """In-place: every float parameter/buffer gets a smooth pseudo-random
-    pattern scaled by 1/sqrt(fan_in); BN running_var kept positive."""
+    pattern scaled by 1/sqrt(fan_in); BN running_var kept positive.
+
+    The pattern of a tensor depends on its index in the sorted key list.  When the
+    module is a sub-module of the model that was filled on the reference side, pass
+    that model's sorted ``keys`` and the sub-module's ``prefix`` to get the same values."""
+    order = None if keys is None else {str(k): i for i, k in enumerate(keys)}
     with torch.no_grad():
-        for t_idx, (name, t) in enumerate(sorted(module.state_dict().items())):
+        for pos, (name, t) in enumerate(sorted(module.state_dict().items())):
+            t_idx = pos if order is None else order[prefix + name]
             if not t.is_floating_point():
                 continue
             n = t.numel()

@@ -11,7 +11,7 @@ never copied.  Usage:
 Fixture groups follow SURVEY.md section 8(c): G1 volumes (A1/A2/A3), G2 soft-argmin
 (A4), G3 local lookups (A5/A6), G4 RAFT correlation (A8/A9/A10), G5 GRU local
 updater (A11), G6 disp_warp (A12), G7 convex upsample (A13), G8 RAFT update
-block (A14).
+block (A14), G9 the RAFT_Stereo hot loop end to end (A8+A9+A13+A14+A15).
 """
 import contextlib
 import io
@@ -276,6 +276,52 @@ def g8_raft_update():
     save("g8_raft_update", **out)
 
 
+# ------------------------------------------------------------------ G9
+def g9_raft_loop():
+    """RAFT_Stereo end to end (4 iterations, test_mode) with RNG-free weights; the tensors the
+    (out-of-scope) extractors hand to the hot loop are captured, so the build's re-hosted loop can
+    be fed the same inputs and compared with the reference's final outputs."""
+    import types
+    t = types.ModuleType("turtle"); t.left = t.right = None; sys.modules["turtle"] = t
+    sys.argv = ["x"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        from models.IterativeLocalCostVolume import raft_stereo as RS
+    torch.manual_seed(901)
+    model = RS.RAFT_Stereo(hidden_dim=[32, 32, 32]).eval()
+    fill_state_dict_(model, seed=0.125)
+    cap = {}
+    orig_init = RS.CorrBlock1D.__init__
+
+    def rec_init(self, fmap1, fmap2, num_levels=4, radius=4):
+        cap["fmap1"], cap["fmap2"] = fmap1.clone(), fmap2.clone()
+        orig_init(self, fmap1, fmap2, num_levels=num_levels, radius=radius)
+
+    RS.CorrBlock1D.__init__ = rec_init
+
+    def pre_hook(mod, args, kwargs):
+        if "net" not in cap:
+            cap["net"] = [n.clone() for n in args[0]]
+            cap["inp"] = [[c.clone() for c in lvl] for lvl in args[1]]
+
+    hk = model.update_block.register_forward_pre_hook(pre_hook, with_kwargs=True)
+    left = torch.rand(1, 3, 64, 96) * 255
+    right = torch.rand(1, 3, 64, 96) * 255
+    with contextlib.redirect_stdout(io.StringIO()):
+        flow_lo, flow_up = model(left, right, iters=4, test_mode=True)
+        preds = model(left, right, iters=3, test_mode=False)
+    hk.remove()
+    RS.CorrBlock1D.__init__ = orig_init
+    out = {"fmap1": npy(cap["fmap1"]), "fmap2": npy(cap["fmap2"]), "flow_lo": npy(flow_lo), "flow_up": npy(flow_up)}
+    out["keys"] = np.array(sorted(model.state_dict().keys()))   # fill_state_dict_ indexes tensors by this order
+    for i in range(3):
+        out[f"net{i}"] = npy(cap["net"][i])
+        for j in range(3):
+            out[f"inp{i}{j}"] = npy(cap["inp"][i][j])
+    for k, p in enumerate(preds):
+        out[f"pred{k}"] = npy(p)
+    save("g9_raft_loop", **out)
+
+
 # ------------------------------------------------------------------ cfg-1 check
 def check_oracle_cfg1():
     """Not a fixture: proves the C oracle == the reference at BASELINE
@@ -309,5 +355,6 @@ if __name__ == "__main__":
     g6_disp_warp()
     g7_upsample()
     g8_raft_update()
+    g9_raft_loop()
     if CHECK:
         check_oracle_cfg1()

@@ -111,3 +111,48 @@ def test_lowcnn_gru_loop_16_iters_no_sync(S):
         up = S.upsample_convex8(disp, mask)
     assert up.shape == (B, 1, 8 * h, 8 * w) and torch.isfinite(up).all()
     assert disp.min().item() >= 0 and disp.max().item() <= D
+
+
+def _raft_inputs(g):
+    net = [dev(g[f"net{i}"]) for i in range(3)]
+    inp = [[dev(g[f"inp{i}{j}"]) for j in range(3)] for i in range(3)]
+    return dev(g["fmap1"]), dev(g["fmap2"]), net, inp
+
+
+def test_raft_stereo_loop_end_to_end_g9(S, golden):
+    """cfg-4 RAFT leg: the re-hosted loop (A8 -> 4 x (A9 + A14 + coords) -> A13) fed with the tensors the
+    reference's extractors produced, against the reference's own final outputs."""
+    g = golden("g9_raft_loop")
+    loop = S.RAFTStereoLoop(hidden_dims=[32, 32, 32]).eval()
+    # same RNG-free recipe as on the reference side, where it was applied to the WHOLE RAFT_Stereo model:
+    # the fixture carries that model's sorted key list so the update block gets identical values
+    fill_state_dict_(loop.update_block, seed=0.125, keys=list(g["keys"]), prefix="update_block.")
+    loop = loop.cuda()
+    f1, f2, net, inp = _raft_inputs(g)
+    flow_lo, flow_up = loop(f1, f2, net, inp, iters=4, test_mode=True)
+    close(flow_lo, g["flow_lo"], rtol=1e-4, atol=1e-3)
+    close(flow_up, g["flow_up"], rtol=1e-4, atol=2e-3)      # x4 upsampled flow: 4x the 1/4-scale error
+    assert float(np.abs(flow_up.cpu().numpy() - g["flow_up"]).mean()) < 2e-4
+    f1, f2, net, inp = _raft_inputs(g)
+    preds = loop(f1, f2, net, inp, iters=3, test_mode=False)
+    assert len(preds) == 3
+    for k, p in enumerate(preds):
+        close(p, g[f"pred{k}"], rtol=1e-4, atol=2e-3)
+    # HIP-graph replay of the iteration == eager
+    f1, f2, net, inp = _raft_inputs(g)
+    lo_g, up_g = loop(f1, f2, net, inp, iters=4, test_mode=True, use_graph=True)
+    assert (lo_g - flow_lo).abs().max().item() < 1e-5 and (up_g - flow_up).abs().max().item() < 1e-5
+
+
+def test_lowcnn_gru_loop_graph_matches_eager(S):
+    B, D, h, w = 2, 24, 36, 60
+    torch.manual_seed(1)
+    loop = S.LowCNNGRULoop(D, 32, 20).eval().cuda()
+    vol = torch.randn(B, D, h, w, device="cuda")
+    left = torch.randn(B, 3, 8 * h, 8 * w, device="cuda")
+    right = torch.randn(B, 3, 8 * h, 8 * w, device="cuda")
+    disp = S.DisparityEstimation(D)(vol).unsqueeze(1)
+    eager = loop(vol, disp, left, right, iters=6)
+    graphed = loop(vol, disp, left, right, iters=6, use_graph=True)
+    assert len(eager) == 6 and len(graphed) == 1
+    assert (eager[-1] - graphed[0]).abs().max().item() < 1e-4
