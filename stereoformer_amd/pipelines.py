@@ -23,6 +23,36 @@ from .update_raft import BasicMultiUpdateBlock_LZH
 from .upsample import upflow8, upsample_convex8, upsample_flow
 
 
+class _GraphCache:
+    """Whole-forward HIP-graph capture keyed by input shapes: inputs are copied into static buffers,
+    the captured launch sequence (every kernel goes to the capturing stream: the C ABI takes the
+    stream explicitly and never synchronises) is replayed, static outputs are returned as clones."""
+
+    def __init__(self):
+        self._entries = {}
+
+    def run(self, key, fn, tensors):
+        ent = self._entries.get(key)
+        if ent is None:
+            static_in = [t.clone() for t in tensors]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):               # warm-up outside capture: MIOpen picks algorithms here
+                for _ in range(2):
+                    fn(static_in)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = fn(static_in)
+            ent = (graph, static_in, static_out)
+            self._entries[key] = ent
+        graph, static_in, static_out = ent
+        for s, t in zip(static_in, tensors):
+            s.copy_(t)
+        graph.replay()
+        return [o.clone() for o in static_out]
+
+
 class RAFTStereoLoop(nn.Module):
     def __init__(self, hidden_dims=(128, 128, 128), downsample=2, corr_levels=4, corr_radius=4, n_gru_layers=3):
         super().__init__()
@@ -34,7 +64,7 @@ class RAFTStereoLoop(nn.Module):
         self.update_block = BasicMultiUpdateBlock_LZH(corr_levels=corr_levels, corr_radius=corr_radius,
                                                       n_gru_layers=n_gru_layers, n_downsample=downsample,
                                                       hidden_dims=self.hidden_dims)
-        self._graph = None
+        self._graphs = _GraphCache()
 
     def _iteration(self, corr_fn, coords0, coords1, net_list, inp_list):
         corr = corr_fn(coords1)                                     # raft_stereo.py:173
@@ -48,7 +78,31 @@ class RAFTStereoLoop(nn.Module):
     @torch.no_grad()
     def forward(self, fmap1, fmap2, net_list, inp_list, iters=12, flow_init=None, test_mode=False, use_graph=False):
         """fmap1/fmap2 [B,256,H/4,W/4] (fnet outputs), net_list: tanh'ed hidden states per scale,
-        inp_list: per scale the (cz, cr, cq) context tensors (``raft_stereo.py:143-148``)."""
+        inp_list: per scale the (cz, cr, cq) context tensors (``raft_stereo.py:143-148``).
+        ``use_graph``: replay the whole loop as one captured HIP graph (same numbers, no per-kernel
+        host launch cost)."""
+        if not use_graph:
+            return self._forward_eager(fmap1, fmap2, net_list, inp_list, iters, flow_init, test_mode)
+        nl, ni = len(net_list), [len(x) for x in inp_list]
+        flat = [fmap1, fmap2, *net_list, *[t for lvl in inp_list for t in lvl]]
+        if flow_init is not None:
+            flat.append(flow_init)
+
+        def fn(ts):
+            nets = list(ts[2:2 + nl])
+            rest, inps = ts[2 + nl:], []
+            for n in ni:
+                inps.append(list(rest[:n]))
+                rest = rest[n:]
+            out = self._forward_eager(ts[0], ts[1], nets, inps, iters, rest[0] if flow_init is not None else None,
+                                      test_mode)
+            return list(out)
+
+        key = (tuple(tuple(t.shape) for t in flat), iters, bool(test_mode), flat[0].device.index)
+        out = self._graphs.run(key, fn, flat)
+        return tuple(out) if test_mode else out
+
+    def _forward_eager(self, fmap1, fmap2, net_list, inp_list, iters, flow_init, test_mode):
         corr_fn = CorrBlock1D(fmap1.float(), fmap2.float(), radius=self.corr_radius, num_levels=self.corr_levels)
         N, _, H, W = net_list[0].shape
         coords0 = coords_grid(N, H, W, device=fmap1.device)
@@ -58,12 +112,6 @@ class RAFTStereoLoop(nn.Module):
         net_list = [n.contiguous() for n in net_list]
         preds = []
         up_mask = None
-        if use_graph and iters > 2:
-            coords1, net_list, up_mask = self._run_graphed(corr_fn, coords0, coords1, net_list, inp_list, iters)
-            flow_up = upsample_flow(coords1 - coords0, up_mask, self.downsample)[:, :1]
-            if test_mode:
-                return coords1 - coords0, flow_up
-            return [flow_up]
         for itr in range(iters):
             net_list, up_mask, coords1 = self._iteration(corr_fn, coords0, coords1, net_list, inp_list)
             if test_mode and itr < iters - 1:
@@ -77,36 +125,12 @@ class RAFTStereoLoop(nn.Module):
             return coords1 - coords0, preds[-1]
         return preds
 
-    def _run_graphed(self, corr_fn, coords0, coords1, net_list, inp_list, iters):
-        """Capture ONE iteration on static buffers and replay it; returns the final state.  (test_mode
-        semantics: only the last iteration is upsampled, raft_stereo.py:184-185.)"""
-        s_coords = coords1.clone()
-        s_net = [n.clone() for n in net_list]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                               # warm-up: MIOpen picks its algorithms here
-            for _ in range(2):
-                nl, mask, c1 = self._iteration(corr_fn, coords0, s_coords, list(s_net), inp_list)
-            s_coords.copy_(coords1)
-            for a, b in zip(s_net, net_list):
-                a.copy_(b)
-        torch.cuda.current_stream().wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            nl, s_mask, c1 = self._iteration(corr_fn, coords0, s_coords, list(s_net), inp_list)
-            s_coords.copy_(c1)
-            for a, b in zip(s_net, nl):
-                a.copy_(b)
-        for _ in range(iters):
-            g.replay()
-        return s_coords, s_net, s_mask
-
-
 class LowCNNGRULoop(nn.Module):
     def __init__(self, input_channels=24, hidden_dim=32, sample_points=20):
         super().__init__()
         self.update = DisparityUpdateDLCWithMask(input_channels=input_channels, hidden_dim=hidden_dim,
                                                  sample_points=sample_points)
+        self._graphs = _GraphCache()
 
     @torch.no_grad()
     def forward(self, cost_volume, disp, left_image, right_image, iters=12, use_graph=False):
@@ -114,22 +138,15 @@ class LowCNNGRULoop(nn.Module):
         (one per iteration, like the reference), or only the last one when ``use_graph``."""
         B, D, h, w = cost_volume.shape
         hidden = torch.zeros(B, 2 * self.update.hidden_dim, h, w, device=cost_volume.device)
-        if use_graph and iters > 2:
-            s_disp, s_hidden = disp.clone(), hidden.clone()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    self.update(cost_volume, s_disp, left_image, right_image, s_hidden, True)
-            torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                d2, h2, s_mask = self.update(cost_volume, s_disp, left_image, right_image, s_hidden, True)
-                s_disp.copy_(d2)
-                s_hidden.copy_(h2)
-            for _ in range(iters):
-                g.replay()
-            return [upsample_convex8(s_disp, s_mask)]
+        if use_graph:
+            def fn(ts):
+                d, hid = ts[1], torch.zeros_like(hidden)
+                for _ in range(iters):
+                    d, hid, mask = self.update(ts[0], d, ts[2], ts[3], hid, True)
+                return [upsample_convex8(d, mask)]
+
+            key = (tuple(cost_volume.shape), tuple(left_image.shape), iters, cost_volume.device.index)
+            return self._graphs.run(key, fn, [cost_volume, disp, left_image, right_image])
         outs = []
         for _ in range(iters):
             disp, hidden, mask = self.update(cost_volume, disp, left_image, right_image, hidden, True)

@@ -164,6 +164,25 @@ def main():
             flow = torch.randn(8, 2, Hr, Wr, device=dev)
             add("A14 one iteration B=8 @136x240", timeit(lambda: blk14(list(nets), inps, corr, flow), 3, 1), None,
                 8 * 168.0, bound="miopen", note="168 GFLOP/iter/pair of convs (MIOpen); informational")
+        if want("loop_raft"):
+            loop = S.RAFTStereoLoop([128, 128, 128]).eval().cuda()
+            nets = [torch.tanh(torch.randn(8, 128, Hr >> i, Wr >> i, device=dev)) for i in range(3)]
+            inps = [[torch.randn(8, 128, Hr >> i, Wr >> i, device=dev) for _ in range(3)] for i in range(3)]
+            for graph in (False, True):
+                ms = timeit(lambda: loop(f1, f2, [n.clone() for n in nets], inps, iters=16, test_mode=True,
+                                         use_graph=graph), 2, 1)
+                add(f"cfg-4 RAFT loop 16 iters B=8 {'graph' if graph else 'eager'}", ms, None, 8 * 16 * 168.0 + 32.09,
+                    bound="miopen", note=f"{8 / ms * 1e3:.1f} pairs/s per GPU; conv FLOPs dominate (MIOpen fp32)")
+        if want("loop_lowcnn"):
+            lp = S.LowCNNGRULoop(24, 32, 20).eval().cuda()
+            v = torch.randn(8, 24, 72, 120, device=dev)
+            dsp = S.DisparityEstimation(24)(v).unsqueeze(1)
+            li = torch.randn(8, 3, 576, 960, device=dev)
+            ri = torch.randn(8, 3, 576, 960, device=dev)
+            for graph in (False, True):
+                ms = timeit(lambda: lp(v, dsp, li, ri, iters=16, use_graph=graph), 3, 1)
+                add(f"cfg-4 LowCNN-GRU loop 16 iters B=8 {'graph' if graph else 'eager'}", ms, None, None,
+                    note=f"{8 / ms * 1e3:.1f} pairs/s per GPU")
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "kernel_bench.json"), "w"), indent=1)
 
