@@ -13,7 +13,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstereo_hip.so")
+LIB_PATH = os.environ.get("STEREO_HIP_LIB") or os.path.join(_HERE, "libstereo_hip.so")  # env: dev A/B builds only
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int

@@ -98,6 +98,55 @@ __global__ __launch_bounds__(256) void lookup_kernel(const float *__restrict__ v
     }
 }
 
+// A6 with 4 pixels per lane: the softmax-variance pass streams the volume with 16-byte loads
+// (one wave load = 1 KiB along W) exactly like soft-argmin; the four lookups follow in registers.
+__global__ __launch_bounds__(256) void variance_lookup_vec_kernel(const float *__restrict__ vol,
+                                                                  const float *__restrict__ disp,
+                                                                  float *__restrict__ out, int D, int W, long long HW,
+                                                                  long long nquads, float gamma, int S,
+                                                                  int consider_valid)
+{
+    const long long HWq = HW / 4;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nquads;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long b = t / HWq, p = (t - b * HWq) * 4;
+        const float *v = vol + (size_t)b * D * HW + p;
+        const f32x4 cur = ld4(disp + (size_t)b * HW + p);
+        float m[4], s[4], var[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m[i] = -INFINITY, s[i] = 0.0f, var[i] = 0.0f;
+#pragma unroll 4
+        for (int d = 0; d < D; ++d) {
+            const f32x4 x = ld4(v + (size_t)d * HW);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float cm = fmaxf(m[i], x[i]);
+                const float sc = (m[i] == cm) ? 1.0f : fast_exp(m[i] - cm);
+                const float pe = fast_exp(x[i] - cm);
+                const float err = (float)d - cur[i];
+                s[i] = s[i] * sc + pe;
+                var[i] = var[i] * sc + pe * (err * err);
+                m[i] = cm;
+            }
+        }
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float sigma = sqrtf(var[i] / s[i]);
+            float lower = cur[i] - gamma * sigma, upper = cur[i] + gamma * sigma;
+            int invalid = -1;
+            if (consider_valid) {
+                invalid = (lower < 0.0f) || (upper >= (float)(D - 1)) || (upper > (float)((p + i) % W));
+            } else {
+                lower = clampf(lower, 0.0f, (float)(D - 1));
+                upper = clampf(upper, 0.0f, (float)(D - 1));
+            }
+            o[i] = lookup_pixel(v + i, (size_t)HW, D, cur[i], lower, upper, S, invalid);
+        }
+        st4(out + (size_t)b * HW + p, o);
+    }
+}
+
 __global__ __launch_bounds__(256) void sample_volume_kernel(const float *__restrict__ vol,
                                                             const float *__restrict__ cand, float *__restrict__ out,
                                                             int D, int K, long long HW, long long n)
@@ -153,6 +202,12 @@ int lookup_dispatch(const float *vol, const float *disp, const float *bounds, fl
     if (MODE == MODE_BOUNDS) STEREO_REQUIRE_PTR(bounds);
     if (D == 0) return STEREO_ERR_BAD_SHAPE;
     const long long HW = (long long)H * W, n = (long long)B * HW;
+    if (MODE == MODE_VARIANCE && HW % 4 == 0 && aligned16(vol) && aligned16(disp) && aligned16(out)) {
+        hipLaunchKernelGGL(variance_lookup_vec_kernel, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(stream), vol, disp,
+                           out, D, W, HW, n / 4, param, S, consider_valid);
+        STEREO_LAUNCH_CHECK();
+        return STEREO_OK;
+    }
     hipLaunchKernelGGL(lookup_kernel<MODE>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), vol, disp, bounds, out,
                        D, W, HW, n, param, S, consider_valid);
     STEREO_LAUNCH_CHECK();

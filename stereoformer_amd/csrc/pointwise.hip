@@ -14,11 +14,16 @@ __global__ __launch_bounds__(256) void gru_reset_kernel(const float *__restrict_
 {
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nvec;
          t += (long long)gridDim.x * blockDim.x) {
+        if (V == 4) {  // 16 B per lane on every stream
+            const f32x4 hv = ld4(h + t * 4), rv = ld4(rc + t * 4);
+            const f32x4 bv = cr ? ld4(cr + t * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 o;
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            const long long e = t * V + i;
-            const float r = sigmoidf_(rc[e] + (cr ? cr[e] : 0.0f));
-            out[e] = r * h[e];
+            for (int i = 0; i < 4; ++i) o[i] = sigmoidf_(rv[i] + bv[i]) * hv[i];
+            st4(out + t * 4, o);
+        } else {
+            const float r = sigmoidf_(rc[t] + (cr ? cr[t] : 0.0f));
+            out[t] = r * h[t];
         }
     }
 }
@@ -31,13 +36,24 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict_
 {
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nvec;
          t += (long long)gridDim.x * blockDim.x) {
+        if (V == 4) {
+            const f32x4 hv = ld4(h + t * 4), zv = ld4(zc + t * 4), qv = ld4(qc + t * 4);
+            const f32x4 bz = cz ? ld4(cz + t * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const f32x4 bq = cq ? ld4(cq + t * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 o;
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-            const long long e = t * V + i;
-            const float z = sigmoidf_(zc[e] + (cz ? cz[e] : 0.0f));
-            const float qx = qc[e] + (cq ? cq[e] : 0.0f);
+            for (int i = 0; i < 4; ++i) {
+                const float z = sigmoidf_(zv[i] + bz[i]);
+                const float qx = qv[i] + bq[i];
+                const float q = SOFTSIGN ? qx / (1.0f + fabsf(qx)) : tanhf(qx);
+                o[i] = (1.0f - z) * hv[i] + z * q;
+            }
+            st4(out + t * 4, o);
+        } else {
+            const float z = sigmoidf_(zc[t] + (cz ? cz[t] : 0.0f));
+            const float qx = qc[t] + (cq ? cq[t] : 0.0f);
             const float q = SOFTSIGN ? qx / (1.0f + fabsf(qx)) : tanhf(qx);
-            out[e] = (1.0f - z) * h[e] + z * q;
+            out[t] = (1.0f - z) * h[t] + z * q;
         }
     }
 }
@@ -61,7 +77,7 @@ extern "C" int stereo_gru_reset_f32(const float *h, const float *rc, const float
     STEREO_REQUIRE_PTR(h);
     STEREO_REQUIRE_PTR(rc);
     STEREO_REQUIRE_PTR(out);
-    if (n % 4 == 0)
+    if (n % 4 == 0 && aligned16(h) && aligned16(rc) && aligned16(out) && (cr == nullptr || aligned16(cr)))
         hipLaunchKernelGGL(gru_reset_kernel<4>, dim3(grid_for(n / 4)), dim3(256), 0, as_stream(stream), h, rc, cr, out,
                            n / 4);
     else
@@ -80,7 +96,8 @@ extern "C" int stereo_gru_blend_f32(const float *h, const float *zc, const float
     STEREO_REQUIRE_PTR(qc);
     STEREO_REQUIRE_PTR(out);
     hipStream_t st = as_stream(stream);
-    const bool v4 = n % 4 == 0;
+    const bool v4 = n % 4 == 0 && aligned16(h) && aligned16(zc) && aligned16(qc) && aligned16(out) &&
+                    (cz == nullptr || aligned16(cz)) && (cq == nullptr || aligned16(cq));
     const long long nv = v4 ? n / 4 : n;
 #define BLEND(V, S) hipLaunchKernelGGL((gru_blend_kernel<V, S>), dim3(grid_for(nv)), dim3(256), 0, st, h, zc, qc, cz, cq, out, nv)
     if (v4 && softsign) BLEND(4, true);

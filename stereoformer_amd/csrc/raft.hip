@@ -8,6 +8,8 @@
 // low-precision split).  A <-> fmap1 (rows = w1), B <-> fmap2 (cols = w2): both
 // operands are read straight from the [C][W] layout, 32 consecutive pixels per
 // half-wave, and every accumulator register stores a 128-B row segment.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -67,6 +69,126 @@ __global__ __launch_bounds__(256) void allpairs_kernel(const float *__restrict__
             if (vb0) obase[(size_t)w1b * W2 + jb0] = acc10[r] / sqrt_c;
             if (vb1) obase[(size_t)w1b * W2 + jb1] = acc11[r] / sqrt_c;
         }
+    }
+}
+
+// LDS-staged, software-pipelined version (fast path: W1 % 4 == 0, W2 % 4 == 0, 16-B aligned).
+// WG tile 128 (w1) x 128 (w2); the K = C loop runs in chunks of KC = 16 channels: the [KC][128] slices
+// of both feature rows are fetched with 16-byte loads (each lane 2 + 2 quads), held in registers while
+// the previous chunk is on the matrix cores, then committed to the other LDS buffer: one barrier per
+// chunk.  MFMA operands are conflict-free ds_read_b32 (lanes along w).
+constexpr int AP_KC = 16;
+constexpr int AP_MAX_FUSED = 5;  // pooled levels produced inside a 32-column MFMA tile (2^5 = 32)
+// Measured on MI355X at [8,256,136,240], 4 levels: pooling in the epilogue (cross-lane adds + narrow
+// strided stores) 0.631 ms vs all-pairs + 4 streaming pool launches 0.583 ms -> the fused form is kept
+// (bit-identical, covered by tests through STEREO_FUSE_PYRAMID=1) but is not the default.
+static bool fuse_pyramid()
+{
+    const char *e = getenv("STEREO_FUSE_PYRAMID");
+    return e && e[0] == '1';
+}
+#define AP_FUSE_PYRAMID fuse_pyramid()
+
+struct PyrOut {
+    float *p[STEREO_MAX_LEVELS];
+    int w[STEREO_MAX_LEVELS];
+    int nfused;  // levels 1..nfused are written by the all-pairs epilogue
+};
+
+__global__ __launch_bounds__(256) void allpairs_lds_kernel(const float *__restrict__ f1, const float *__restrict__ f2,
+                                                           PyrOut pyr, int C, int H, int W1, int W2, float sqrt_c)
+{
+    float *__restrict__ out = pyr.p[0];
+    __shared__ float As[2][AP_KC][128];
+    __shared__ float Bs[2][AP_KC][128];
+    const int bh = blockIdx.z;
+    const int b = bh / H, h = bh - b * H;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int M0 = blockIdx.y * 128, N0 = blockIdx.x * 128;
+    const int mw = (wave >> 1) * 64, nw = (wave & 1) * 64;  // wave origin inside the tile
+
+    const size_t HW1 = (size_t)H * W1, HW2 = (size_t)H * W2;
+    const float *a_base = f1 + (size_t)b * C * HW1 + (size_t)h * W1;
+    const float *b_base = f2 + (size_t)b * C * HW2 + (size_t)h * W2;
+
+    // staging slots: quad q = tid + k*256 of a [16][32 quads] slice
+    int sc[2], sx[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int q = tid + k * 256;
+        sc[k] = q >> 5;
+        sx[k] = (q & 31) * 4;
+    }
+    f32x4 pa[2], pb[2];
+    auto issue = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int c = c0 + sc[k];
+            const bool oka = c < C && M0 + sx[k] + 3 < W1;  // W % 4 == 0: a quad is all-in or all-out
+            const bool okb = c < C && N0 + sx[k] + 3 < W2;
+            pa[k] = ld4(a_base + (oka ? (size_t)c * HW1 + M0 + sx[k] : 0));
+            pb[k] = ld4(b_base + (okb ? (size_t)c * HW2 + N0 + sx[k] : 0));
+            if (!oka) pa[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (!okb) pb[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            *reinterpret_cast<f32x4 *>(&As[buf][sc[k]][sx[k]]) = pa[k];
+            *reinterpret_cast<f32x4 *>(&Bs[buf][sc[k]][sx[k]]) = pb[k];
+        }
+    };
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    const int nchunk = (C + AP_KC - 1) / AP_KC;
+    issue(0);
+    commit(0);
+    if (nchunk > 1) issue(AP_KC);
+    __syncthreads();
+    for (int ck = 0; ck < nchunk; ++ck) {
+        const int buf = ck & 1;
+        if (ck + 1 < nchunk) commit(buf ^ 1);           // its last readers passed the previous barrier
+        if (ck + 2 < nchunk) issue((ck + 2) * AP_KC);   // in flight during this chunk's MFMAs
+#pragma unroll
+        for (int s = 0; s < AP_KC / 2; ++s) {
+            const int c = 2 * s + half;
+            const float a0 = As[buf][c][mw + l31], a1 = As[buf][c][mw + 32 + l31];
+            const float b0 = Bs[buf][c][nw + l31], b1 = Bs[buf][c][nw + 32 + l31];
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: level 0 plus the first pooled levels.  Level l+1 = mean of adjacent pairs of level l
+    // (corr.py:70-76): adjacent columns are adjacent lanes, so each level is one cross-lane add on the
+    // already rounded level-l value -- bit-identical to pooling the stored level.
+    const size_t rowbase = (size_t)bh * W1;
+    const int jb0 = N0 + nw + l31, jb1 = jb0 + 32;
+    auto emit = [&](float v, int w1, int jb) {
+        if (w1 < W1 && jb < W2) out[(rowbase + w1) * W2 + jb] = v;
+        float cur = v;
+#pragma unroll
+        for (int l = 1; l <= AP_MAX_FUSED; ++l) {
+            if (l <= pyr.nfused) {  // uniform
+                const float other = __shfl_xor(cur, 1 << (l - 1));
+                cur = (cur + other) * 0.5f;
+                const int j = jb >> l;
+                if ((l31 & ((1 << l) - 1)) == 0 && w1 < W1 && j < pyr.w[l]) pyr.p[l][(rowbase + w1) * pyr.w[l] + j] = cur;
+            }
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int w1a = M0 + mw + row, w1b = w1a + 32;
+        emit(acc00[r] / sqrt_c, w1a, jb0);
+        emit(acc01[r] / sqrt_c, w1a, jb1);
+        emit(acc10[r] / sqrt_c, w1b, jb0);
+        emit(acc11[r] / sqrt_c, w1b, jb1);
     }
 }
 
@@ -183,17 +305,33 @@ extern "C" int stereo_allpairs_pyramid_f32(const float *fmap1, const float *fmap
     if (!fits_grid_yz((long long)B * H) || !fits_grid_yz((W1 + 127) / 128)) return STEREO_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);
     dim3 grid((W2 + 127) / 128, (W1 + 127) / 128, (unsigned)(B * H));
-    hipLaunchKernelGGL(allpairs_kernel, grid, dim3(256), 0, st, fmap1, fmap2, levels[0], C, H, W1, W2,
-                       sqrtf((float)C));
+    int first_unpooled = 1;  // first level still to be produced by the pooling kernel
+    if (W1 % 4 == 0 && W2 % 4 == 0 && aligned16(fmap1) && aligned16(fmap2)) {
+        PyrOut pyr;
+        pyr.nfused = 0;
+        for (int i = 0, w = W2; i <= num_levels && i < STEREO_MAX_LEVELS; ++i, w /= 2) {
+            pyr.p[i] = levels[i];
+            pyr.w[i] = w;
+            if (AP_FUSE_PYRAMID && i >= 1 && i <= AP_MAX_FUSED && w > 0) pyr.nfused = i;
+        }
+        first_unpooled = pyr.nfused + 1;
+        hipLaunchKernelGGL(allpairs_lds_kernel, grid, dim3(256), 0, st, fmap1, fmap2, pyr, C, H, W1, W2,
+                           sqrtf((float)C));
+    } else {
+        hipLaunchKernelGGL(allpairs_kernel, grid, dim3(256), 0, st, fmap1, fmap2, levels[0], C, H, W1, W2,
+                           sqrtf((float)C));
+    }
     STEREO_LAUNCH_CHECK();
     const long long rows = (long long)B * H * W1;
     for (int i = 1, w = W2; i <= num_levels; ++i) {
         const int wo = w / 2;
         if (wo == 0) break;
-        const long long nout = rows * wo;
-        hipLaunchKernelGGL(avgpool_w2_kernel, dim3(grid_for(nout)), dim3(256), 0, st, levels[i - 1], levels[i], w, wo,
-                           nout);
-        STEREO_LAUNCH_CHECK();
+        if (i >= first_unpooled) {
+            const long long nout = rows * wo;
+            hipLaunchKernelGGL(avgpool_w2_kernel, dim3(grid_for(nout)), dim3(256), 0, st, levels[i - 1], levels[i], w, wo,
+                               nout);
+            STEREO_LAUNCH_CHECK();
+        }
         w = wo;
     }
     return STEREO_OK;

@@ -322,11 +322,15 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
                     win[4 * q + 2] = t[2];
                     win[4 * q + 3] = t[3];
                 }
+#ifdef STEREO_ABLATE_FMA  // timing experiment: keep the loads alive, drop the FMA block
+                asm volatile("" ::"v"(lv[0]), "v"(win[0]), "v"(win[DC + 3]));
+#else
 #pragma unroll
                 for (int dd = 0; dd < DC; ++dd) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[dd][i] = fmaf(lv[i], win[DC + i - dd], acc[dd][i]);
                 }
+#endif
             }
         }
         if (ck == nchunk - 1 && active) {  // group finished: epilogue
@@ -470,15 +474,18 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pk_kernel(const float *__
     };
     auto commit = [&](int buf) {
         float *rs = S0 + buf * BUF, *ls = rs + CP * RS * 2;
+        // layout [pair][plane][quad][4]: plane 0 = pixels (4q, 4q+1) x 2 channels, plane 1 = pixels (4q+2, 4q+3):
+        // every ds_read_b128 of a wave then has a 16-byte lane stride (conflict-free); a 32-byte stride
+        // ([x][2] interleave) costs a 2-way bank conflict on each read.
         if (rcp < CP) {
-            float *d = rs + (rcp * RS + rx) * 2;
+            float *d = rs + rcp * 2 * RS + rx;  // quad rx/4 -> float offset rx
             *reinterpret_cast<f32x4 *>(d) = (f32x4){pr0[0], pr1[0], pr0[1], pr1[1]};
-            *reinterpret_cast<f32x4 *>(d + 4) = (f32x4){pr0[2], pr1[2], pr0[3], pr1[3]};
+            *reinterpret_cast<f32x4 *>(d + RS) = (f32x4){pr0[2], pr1[2], pr0[3], pr1[3]};
         }
         if (lcp < CP) {
-            float *d = ls + (lcp * TW + lx) * 2;
+            float *d = ls + lcp * 2 * TW + lx;
             *reinterpret_cast<f32x4 *>(d) = (f32x4){pl0[0], pl1[0], pl0[1], pl1[1]};
-            *reinterpret_cast<f32x4 *>(d + 4) = (f32x4){pl0[2], pl1[2], pl0[3], pl1[3]};
+            *reinterpret_cast<f32x4 *>(d + TW) = (f32x4){pl0[2], pl1[2], pl0[3], pl1[3]};
         }
     };
 
@@ -522,23 +529,26 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pk_kernel(const float *__
         if (it + 2 < nitems) item_loads(it + 2);
         const float *Rcur = S0 + (it & 1) * BUF, *Lcur = Rcur + CP * RS * 2;
         if (active) {
-            const float *rwin = Rcur + (Dpad + wl - d0 - DC) * 2;  // window origin, pixel units -> float2
-            const float *lwin = Lcur + wl * 2;
+            const float *rwin = Rcur + (Dpad + wl - d0 - DC);  // window origin (quad-aligned pixel index = float offset)
+            const float *lwin = Lcur + wl;
             for (int cp = 0; cp < npair; ++cp) {
                 f32x2 lv[4], win[DC + 4];
                 {
-                    const f32x4 t0 = *reinterpret_cast<const f32x4 *>(lwin + cp * TW * 2);
-                    const f32x4 t1 = *reinterpret_cast<const f32x4 *>(lwin + cp * TW * 2 + 4);
+                    const f32x4 t0 = *reinterpret_cast<const f32x4 *>(lwin + cp * 2 * TW);
+                    const f32x4 t1 = *reinterpret_cast<const f32x4 *>(lwin + cp * 2 * TW + TW);
                     lv[0] = (f32x2){t0[0], t0[1]};
                     lv[1] = (f32x2){t0[2], t0[3]};
                     lv[2] = (f32x2){t1[0], t1[1]};
                     lv[3] = (f32x2){t1[2], t1[3]};
                 }
 #pragma unroll
-                for (int q = 0; q < (DC + 4) / 2; ++q) {
-                    const f32x4 t = *reinterpret_cast<const f32x4 *>(rwin + cp * RS * 2 + 4 * q);
-                    win[2 * q] = (f32x2){t[0], t[1]};
-                    win[2 * q + 1] = (f32x2){t[2], t[3]};
+                for (int q = 0; q < (DC + 4) / 4; ++q) {
+                    const f32x4 t0 = *reinterpret_cast<const f32x4 *>(rwin + cp * 2 * RS + 4 * q);
+                    const f32x4 t1 = *reinterpret_cast<const f32x4 *>(rwin + cp * 2 * RS + RS + 4 * q);
+                    win[4 * q + 0] = (f32x2){t0[0], t0[1]};
+                    win[4 * q + 1] = (f32x2){t0[2], t0[3]};
+                    win[4 * q + 2] = (f32x2){t1[0], t1[1]};
+                    win[4 * q + 3] = (f32x2){t1[2], t1[3]};
                 }
 #pragma unroll
                 for (int dd = 0; dd < DC; ++dd) {
@@ -760,7 +770,7 @@ int gwc_dispatch(const float *L, const float *R, float *vol, int B, int C, int H
 template <bool CONCAT>
 __global__ __launch_bounds__(256) void shift_volume_kernel(const float *__restrict__ L, const float *__restrict__ R,
                                                            float *__restrict__ vol, int C, int H, int W, int D,
-                                                           long long nquads)
+                                                           long long nquads, int vec_ok)
 {
     const int Wq = (W + 3) / 4;
     const int Cout = CONCAT ? 2 * C : C;
@@ -779,18 +789,24 @@ __global__ __launch_bounds__(256) void shift_volume_kernel(const float *__restri
         const int cs = (CONCAT && c >= C) ? c - C : c;
         const float *lrow = L + (((size_t)b * C + cs) * H + h) * (size_t)W;
         const float *rrow = R + (((size_t)b * C + cs) * H + h) * (size_t)W;
+        f32x4 o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (w + i < W) {
-                float v = 0.0f;
-                if (w + i >= d) {
-                    if (CONCAT)
-                        v = (c < C) ? lrow[w + i] : rrow[w + i - d];
-                    else
-                        v = lrow[w + i] - rrow[w + i - d];
-                }
-                dst[i] = v;
+            float v = 0.0f;
+            if (w + i < W && w + i >= d) {
+                if (CONCAT)
+                    v = (c < C) ? lrow[w + i] : rrow[w + i - d];
+                else
+                    v = lrow[w + i] - rrow[w + i - d];
             }
+            o[i] = v;
+        }
+        if (vec_ok && w + 3 < W) {
+            st4(dst, o);  // 16-B W-contiguous store
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (w + i < W) dst[i] = o[i];
         }
     }
 }
@@ -807,7 +823,7 @@ int shift_dispatch(const float *L, const float *R, float *vol, int B, int C, int
     long long blocks = (nquads + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(shift_volume_kernel<CONCAT>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), L, R, vol,
-                       C, H, W, D, nquads);
+                       C, H, W, D, nquads, (W % 4 == 0 && aligned16(vol)) ? 1 : 0);
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }

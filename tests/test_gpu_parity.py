@@ -229,8 +229,10 @@ def test_raft_corr_golden(S, golden):
         S.AlternateCorrBlock(f1, f2)
 
 
-@pytest.mark.parametrize("shape", [(1, 256, 3, 240), (2, 31, 2, 150), (1, 64, 1, 33)])
-def test_allpairs_vs_oracle(S, oracle, shape):
+@pytest.mark.parametrize("shape", [(1, 256, 3, 240), (2, 31, 2, 150), (1, 64, 1, 33), (1, 40, 2, 312), (1, 7, 1, 128)])
+@pytest.mark.parametrize("fuse", ["0", "1"])
+def test_allpairs_vs_oracle(S, oracle, shape, fuse, monkeypatch):
+    monkeypatch.setenv("STEREO_FUSE_PYRAMID", fuse)   # pooled levels from the MFMA epilogue vs the pooling kernel
     B, C, H, W = shape
     rng = np.random.default_rng(19)
     f1 = rng.standard_normal(shape, dtype=np.float32)
