@@ -322,15 +322,11 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
                     win[4 * q + 2] = t[2];
                     win[4 * q + 3] = t[3];
                 }
-#ifdef STEREO_ABLATE_FMA  // timing experiment: keep the loads alive, drop the FMA block
-                asm volatile("" ::"v"(lv[0]), "v"(win[0]), "v"(win[DC + 3]));
-#else
 #pragma unroll
                 for (int dd = 0; dd < DC; ++dd) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[dd][i] = fmaf(lv[i], win[DC + i - dd], acc[dd][i]);
                 }
-#endif
             }
         }
         if (ck == nchunk - 1 && active) {  // group finished: epilogue
