@@ -181,7 +181,10 @@ def main():
         traffic = None  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
-            traffic = pmc["kernels"]["gwc_volume_kernel<24, true, 0>"]["hbm_bytes_per_launch"]
+            # the store variant of the volume builder (template tail ", 0>" = EPI_STORE) at G=8
+            cands = [v for k, v in pmc["kernels"].items() if k.startswith("gwc_volume") and k.endswith(", 0>")
+                     and v.get("hbm_write_bytes", 0) > 2e10]
+            traffic = cands[0]["hbm_bytes_per_launch"] if cands else None
         except Exception:
             pass
         achieved = gwc_bytes / (build_ms * 1e-3) / 1e9
@@ -203,7 +206,7 @@ def main():
             "config": {"workload": "cfg-2: SceneFlow 960x540 D=192 group-wise (G=8,C=32) LocalCostVolume + soft-argmin, "
                                    "batch=8 per GPU, all reference-API intermediates materialised",
                        "pairs_per_gpu": B_PER_GPU, "parallelism": f"pairs sharded over {world} GPU(s), no data collective"},
-            "roofline": {"bound": "hbm", "kernel": "gwc_volume_kernel (A3 build)", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": "gwc_volume_pipe_kernel<16,12,EPI_STORE> (A3 group-wise volume build)", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "algorithmic_bytes": gwc_bytes, "avg_launch_ms": round(build_ms, 4)},
             "kernels_ms": {"gwc_build": round(build_ms, 4), "group_mean_soft_argmin": round(read_ms, 4),

@@ -369,3 +369,52 @@ def test_cfg2_full_size_identities(S, oracle):
     assert torch.isfinite(d2).all()
     close(d2[0:1, :, rows], oracle.local_lookup(host(corr[0:1, :, rows]), host(disp[0:1, None, rows]), 2.0, 20, True),
           **DISP_TOL)
+
+
+# ------------------------------------------------------------------ edge cases across the whole surface
+def test_empty_and_degenerate_inputs(S):
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    # zero-sized batches launch nothing and return correctly shaped outputs
+    assert S.DisparityEstimation(4)(z(0, 4, 3, 8)).shape == (0, 3, 8)
+    d, p = S.DisparityEstimationWithProb(4)(z(0, 4, 3, 8))
+    assert d.shape == (0, 3, 8) and p.shape == (0, 4, 3, 8)
+    assert S.LocalCostVolume(2, 5)(z(0, 4, 3, 8), z(0, 1, 3, 8)).shape == (0, 1, 3, 8)
+    assert S.Variance_Based_Local_Cost_Volume(1, 5)(z(0, 4, 3, 8), z(0, 1, 3, 8), True).shape == (0, 1, 3, 8)
+    assert S.upsample_convex8(z(0, 1, 3, 4), z(0, 576, 3, 4)).shape == (0, 1, 24, 32)
+    assert S.disp_warp(z(0, 3, 4, 5), z(0, 1, 4, 5))[0].shape == (0, 3, 4, 5)
+    o, dd = S.CrossAttentionCostVolume(4)(z(0, 8, 3, 8), z(0, 8, 3, 8))
+    assert o.shape == (0, 8, 3, 8) and dd.shape == (0, 3, 8)
+    assert S.group_mean_soft_argmin(z(0, 2, 4, 3, 8)).shape == (0, 3, 8)
+    assert S.gru_blend(z(0, 4, 2, 2), z(0, 4, 2, 2), z(0, 4, 2, 2)).shape == (0, 4, 2, 2)
+    # a single disparity plane: softmax over one element -> disparity 0 everywhere
+    v1 = torch.randn(2, 1, 3, 8, device="cuda")
+    assert S.DisparityEstimation(1)(v1).abs().max().item() == 0.0
+    # H == 1, W == 1 volumes
+    L = torch.randn(1, 4, 1, 1, device="cuda")
+    assert torch.allclose(S.CostVolume(1)(L, L), (L * L).mean(1, keepdim=True))
+    # an all-equal volume gives the mean candidate
+    v = torch.zeros(1, 9, 2, 4, device="cuda")
+    assert torch.allclose(S.DisparityEstimation(9)(v), torch.full((1, 2, 4), 4.0, device="cuda"), atol=1e-5)
+    # shape errors are raised on the host, before any launch
+    with pytest.raises(ValueError):
+        S.LocalCostVolume(2, 5)(v, torch.zeros(1, 1, 2, 5, device="cuda"))
+    with pytest.raises(RuntimeError):
+        S.upsample_convex8(torch.zeros(1, 1, 2, 2, device="cuda"), torch.zeros(1, 100, 2, 2, device="cuda"))
+    with pytest.raises(RuntimeError, match="forward-only"):
+        S.CostVolume(2)(torch.randn(1, 2, 2, 4, device="cuda", requires_grad=True), torch.randn(1, 2, 2, 4, device="cuda"))
+
+
+def test_streams_and_determinism(S):
+    """Launches go to the caller's current stream and results are bit-reproducible."""
+    L = torch.randn(2, 32, 9, 300, device="cuda")
+    R = torch.randn(2, 32, 9, 300, device="cuda")
+    ref = S.build_gwc_volume(L, R, 64, 8)
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        out = S.build_gwc_volume(L, R, 64, 8)
+        d1 = S.group_mean_soft_argmin(out)
+    st.synchronize()
+    assert torch.equal(out, ref)
+    assert torch.equal(d1, S.group_mean_soft_argmin(ref))
+    assert torch.equal(S.corr_soft_argmin(L, R, 64), S.corr_soft_argmin(L, R, 64))
