@@ -668,7 +668,11 @@ int launch_pipe(const float *L, const float *R, float *vol, int B, int C, int H,
     while (RB > 1 && (long long)((H + RB - 1) / RB) * ((W + TW - 1) / TW) * B * ((D + NWV * DC - 1) / (NWV * DC)) < 2048)
         RB >>= 1;                                                                // keep >= 8 workgroups per CU
     const int nparts = (D + NWV * DC - 1) / (NWV * DC);
-    if (Dpad > 256 || lds > 64 * 1024 || !fits_grid_yz((long long)B * nparts) || (EPI == EPI_ARGMIN && nparts != 1))
+    if (Dpad > 256 || lds > 160 * 1024 || !fits_grid_yz((long long)B * nparts) || (EPI == EPI_ARGMIN && nparts != 1))
+        return STEREO_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(gwc_volume_pipe_kernel<DC, NWV, EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return STEREO_ERR_UNSUPPORTED;
     const bool pow2 = (CPG & (CPG - 1)) == 0;
     int nt = 0;
