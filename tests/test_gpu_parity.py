@@ -282,8 +282,11 @@ def test_resize_vs_oracle(S, oracle, golden):
 
 # ------------------------------------------------------------------ cross-attention (A7, build-defined)
 @pytest.mark.parametrize("cfg", [(2, 16, 5, 40, 12), (1, 32, 3, 200, 192), (1, 48, 2, 70, 33), (1, 40, 2, 300, 230),
-                                 (1, 256, 2, 312, 64), (1, 8, 1, 64, 1), (1, 32, 1, 130, 352), (1, 20, 1, 96, 32)])
-def test_cross_attention(S, oracle, cfg):
+                                 (1, 256, 2, 312, 64), (1, 8, 1, 64, 1), (1, 32, 1, 130, 352), (1, 20, 1, 96, 32),
+                                 (2, 32, 3, 960, 192), (1, 24, 2, 516, 250)])
+@pytest.mark.parametrize("force_v2", ["0", "1"])
+def test_cross_attention(S, oracle, cfg, force_v2, monkeypatch):
+    monkeypatch.setenv("STEREO_ATT_V2", force_v2)   # "1": per-tile MFMA kernel; "0": row-pipelined MFMA kernel when eligible
     B, C, H, W, D = cfg
     rng = np.random.default_rng(29)
     L = rng.standard_normal((B, C, H, W), dtype=np.float32)
