@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void group_mean_soft_argmin_kernel(const float
                                                                      float *__restrict__ vol_mean,
                                                                      float *__restrict__ disp, int G, int D,
                                                                      long long HW, long long ncols, float sgn,
-                                                                     float inv_g, int exact_div)
+                                                                     float inv_g, int exact_div, int nt_store)
 {
     const long long HWv = HW / V;
     const size_t gstride = (size_t)D * HW;
@@ -157,7 +157,13 @@ __global__ __launch_bounds__(256) void group_mean_soft_argmin_kernel(const float
                         mv[i] = exact_div ? x[u][i] / (float)G : x[u][i] * inv_g;
                         x[u][i] = sgn * mv[i];
                     }
-                    if (WRITE_MEAN) Vec<V>::store(vol_mean + (size_t)b * gstride + (size_t)(d0 + u) * HW + p, mv);
+                    if (WRITE_MEAN) {
+                        float *dst = vol_mean + (size_t)b * gstride + (size_t)(d0 + u) * HW + p;
+                        if (NT && nt_store)
+                            __builtin_nontemporal_store(mv, reinterpret_cast<typename Vec<V>::T *>(dst));
+                        else
+                            Vec<V>::store(dst, mv);
+                    }
                 }
             }
             st.template absorb<U>(x, d0, nv);
@@ -252,10 +258,11 @@ extern "C" int stereo_group_mean_soft_argmin_f32(const float *volg, float *vol_m
     const bool vec =
         (HW % 4 == 0) && aligned16(volg) && aligned16(disp) && (vol_mean == nullptr || aligned16(vol_mean));
     int cfg_u = 1, cfg_nt = 1, cfg_cap = 1 << 20;  // measured best on MI355X (tools/gm_sweep.sh): 1 plane x G loads, nt
-    if (const char *e = getenv("STEREO_GM_CFG")) sscanf(e, "%d,%d,%d", &cfg_u, &cfg_nt, &cfg_cap);  // dev tuning knob
+    int cfg_nts = 0;
+    if (const char *e = getenv("STEREO_GM_CFG")) sscanf(e, "%d,%d,%d,%d", &cfg_u, &cfg_nt, &cfg_cap, &cfg_nts);  // dev tuning knob
 #define GM_LAUNCH(V, U, WM, NTV)                                                                                      \
     hipLaunchKernelGGL((group_mean_soft_argmin_kernel<V, U, WM, NTV>), dim3(gm_grid), dim3(256), 0, st, volg, vol_mean, \
-                       disp, G, D, HW, n, sgn, 1.0f / (float)G, pow2 ? 0 : 1)
+                       disp, G, D, HW, n, sgn, 1.0f / (float)G, pow2 ? 0 : 1, cfg_nts)
     if (vec) {
         const long long n = (long long)B * (HW / 4);
         long long gb = (n + 255) / 256;

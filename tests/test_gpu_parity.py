@@ -421,3 +421,49 @@ def test_streams_and_determinism(S):
     assert torch.equal(out, ref)
     assert torch.equal(d1, S.group_mean_soft_argmin(ref))
     assert torch.equal(S.corr_soft_argmin(L, R, 64), S.corr_soft_argmin(L, R, 64))
+
+
+def test_cfg3_full_size_identity(S, oracle):
+    """configs[2] at full size (B=8, 960x540, D=192, C=32): the MFMA cross-attention against identity I3
+    (mask='zero', scale='mean' == correlation volume + soft-argmin) and against the oracle on two rows."""
+    B, C, H, W, D = 8, 32, 540, 960, 192
+    g = torch.Generator(device="cuda").manual_seed(3)
+    L = torch.randn(B, C, H, W, device="cuda", generator=g)
+    R = torch.randn(B, C, H, W, device="cuda", generator=g)
+    out, disp = S.CrossAttentionCostVolume(D, "zero", "mean")(L, R)
+    fused = S.corr_soft_argmin(L, R, D)
+    assert (disp - fused).abs().max().item() < 1e-3 and (disp - fused).abs().mean().item() < 1e-4
+    rows = [0, 377]
+    for b in (0, 5):
+        Ls, Rs = host(L[b:b + 1, :, rows]), host(R[b:b + 1, :, rows])
+        oo, od = oracle.cross_attention(Ls, Rs, None, D, "zero", "mean")
+        close(disp[b:b + 1, rows], od, **DISP_TOL)
+        close(out[b:b + 1, :, rows], oo, rtol=1e-4, atol=5e-5)
+    _, dn = S.CrossAttentionCostVolume(D, "neginf", "sqrt_c")(L, R, need_out=False)
+    assert (dn <= torch.arange(W, device="cuda").view(1, 1, W) + 1e-3).all()   # mass only on in-image keys
+
+
+def test_cfg5_kitti_shapes(S, oracle):
+    """configs[4] geometry: KITTI 375x1242 padded to 384x1248 (divis_by=32), D=256 at full resolution and the
+    1/4-scale attention [4,256,96,312] with a 64-disparity band."""
+    pad = S.InputPadder((375, 1242), mode="kitti", divis_by=32)
+    (img,) = pad.pad(torch.randn(1, 3, 375, 1242, device="cuda"))
+    assert img.shape[-2:] == (384, 1248) and pad.unpad(img).shape[-2:] == (375, 1242)
+    rng = np.random.default_rng(41)
+    L = rng.standard_normal((1, 32, 3, 1248), dtype=np.float32)
+    R = rng.standard_normal((1, 32, 3, 1248), dtype=np.float32)
+    ref = oracle.corr_volume(L, R, 256)
+    close(S.CostVolume(256)(dev(L), dev(R)), ref, **VOL_TOL)
+    close(S.build_gwc_volume(dev(L), dev(R), 256, 8), oracle.gwc_volume(L, R, 256, 8), **VOL_TOL)
+    close(S.corr_soft_argmin(dev(L), dev(R), 256), oracle.soft_argmin(ref), rtol=0, atol=1e-3, mean_atol=3.5e-4)
+    f1 = rng.standard_normal((1, 256, 3, 312), dtype=np.float32)
+    f2 = rng.standard_normal((1, 256, 3, 312), dtype=np.float32)
+    o, d = S.CrossAttentionCostVolume(64, "neginf", "sqrt_c")(dev(f1), dev(f2))
+    oo, od = oracle.cross_attention(f1, f2, None, 64, "neginf", "sqrt_c")
+    close(o, oo, rtol=1e-4, atol=1e-4)
+    close(d, od, **DISP_TOL)
+    # flow_init from the attention disparity feeds the RAFT loop as (-disp, 0) (raft_stereo.py:163-164)
+    blk = S.CorrBlock1D(dev(f1), dev(f2), 4, 4)
+    coords = S.coords_grid(1, 3, 312, device="cuda")
+    coords[:, :1] -= d.unsqueeze(1)
+    assert blk(coords.contiguous()).shape == (1, 36, 3, 312)
