@@ -421,25 +421,29 @@ __global__ __launch_bounds__(A2_NT) void cross_attention_pipe_kernel(const float
     }
     const int qrow = tid >> 4, qxq = tid & 15;       // Q tile: 32 rows x 16 quads = 512 slots
     f32x4 rk[NSK], rq;
+    unsigned kmask = 0, qmask = 0;  // validity, applied at COMMIT time: a select on the loaded value at issue time
+                                    // would make the compiler wait for the load right there
     auto issue_tile = [&](const float *__restrict__ src, int nch, int w0) {  // -> rk (rows = channels)
         const float *base = src + (size_t)b * nch * HW + (size_t)h * W;
+        kmask = 0;
 #pragma unroll
         for (int k = 0; k < NSK; ++k) {
             const int w = w0 - Dk + 4 * sxq[k];
             const bool ok = srow[k] < nch && srow[k] < A2_CK && w >= 0 && w + 3 < W;
             rk[k] = ld4(base + (ok ? (size_t)srow[k] * HW + w : 0));
-            if (!ok) rk[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            kmask |= ok ? (1u << k) : 0u;
         }
     };
     auto commit_tile = [&]() {
 #pragma unroll
         for (int k = 0; k < NSK; ++k) {
             if (srow[k] < A2_CK) {
+                const bool ok = (kmask >> k) & 1u;
                 float *d = Ks + srow[k] * KS + 4 * sxq[k];
-                d[0] = rk[k][0];
-                d[1] = rk[k][1];
-                d[2] = rk[k][2];
-                d[3] = rk[k][3];
+                d[0] = ok ? rk[k][0] : 0.0f;
+                d[1] = ok ? rk[k][1] : 0.0f;
+                d[2] = ok ? rk[k][2] : 0.0f;
+                d[3] = ok ? rk[k][3] : 0.0f;
             }
         }
     };
@@ -447,9 +451,11 @@ __global__ __launch_bounds__(A2_NT) void cross_attention_pipe_kernel(const float
         const int w = w0 + 4 * qxq;
         const bool ok = qrow < C && w + 3 < W;
         rq = ld4(L + (size_t)b * C * HW + (size_t)h * W + (ok ? (size_t)qrow * HW + w : 0));
-        if (!ok) rq = (f32x4){0.f, 0.f, 0.f, 0.f};
+        qmask = ok ? 1u : 0u;
     };
-    auto commit_q = [&]() { *reinterpret_cast<f32x4 *>(Qs + qrow * A2_TQ + 4 * qxq) = rq; };
+    auto commit_q = [&]() {
+        *reinterpret_cast<f32x4 *>(Qs + qrow * A2_TQ + 4 * qxq) = qmask ? rq : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
 
     if (t_begin >= t_end) return;
     issue_tile(R, C, t_begin * A2_TQ);

@@ -121,7 +121,9 @@ __global__ __launch_bounds__(256) void allpairs_lds_kernel(const float *__restri
         sx[k] = (q & 31) * 4;
     }
     f32x4 pa[2], pb[2];
+    unsigned okmask = 0;  // applied at commit time so that the loads stay in flight during the MFMA block
     auto issue = [&](int c0) {
+        okmask = 0;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int c = c0 + sc[k];
@@ -129,15 +131,15 @@ __global__ __launch_bounds__(256) void allpairs_lds_kernel(const float *__restri
             const bool okb = c < C && N0 + sx[k] + 3 < W2;
             pa[k] = ld4(a_base + (oka ? (size_t)c * HW1 + M0 + sx[k] : 0));
             pb[k] = ld4(b_base + (okb ? (size_t)c * HW2 + N0 + sx[k] : 0));
-            if (!oka) pa[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (!okb) pb[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            okmask |= (oka ? (1u << k) : 0u) | (okb ? (4u << k) : 0u);
         }
     };
     auto commit = [&](int buf) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            *reinterpret_cast<f32x4 *>(&As[buf][sc[k]][sx[k]]) = pa[k];
-            *reinterpret_cast<f32x4 *>(&Bs[buf][sc[k]][sx[k]]) = pb[k];
+            *reinterpret_cast<f32x4 *>(&As[buf][sc[k]][sx[k]]) = (okmask >> k) & 1u ? pa[k] : zero;
+            *reinterpret_cast<f32x4 *>(&Bs[buf][sc[k]][sx[k]]) = (okmask >> (2 + k)) & 1u ? pb[k] : zero;
         }
     };
 

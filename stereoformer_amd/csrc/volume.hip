@@ -245,22 +245,42 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
         lx[k] = (q - lc[k] * lq) * 4;
     }
 
+    // Per-slot 32-bit element offsets inside one (batch, row-0, chunk-0) frame, computed ONCE: every item's
+    // address is then a wave-uniform base (row, chunk) + this per-lane offset, i.e. the SGPR-base form of
+    // global_load with no per-item 64-bit VALU address arithmetic.
+    unsigned roff[NSR], loff[NSL], wmask = 0;
+#pragma unroll
+    for (int k = 0; k < NSR; ++k) {
+        const int w = w0 - Dpad + rx[k];
+        const bool okw = rc[k] < CC && w >= 0 && w + 3 < W;
+        roff[k] = okw ? (unsigned)rc[k] * (unsigned)HW + (unsigned)w : 0u;
+        wmask |= okw ? (1u << k) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < NSL; ++k) {
+        const int w = w0 + lx[k];
+        const bool okw = lc[k] < CC && w + 3 < W;
+        loff[k] = okw ? (unsigned)lc[k] * (unsigned)HW + (unsigned)w : 0u;
+        wmask |= okw ? (1u << (8 + k)) : 0u;
+    }
     f32x4 pr[NSR], pl[NSL];
+    unsigned okmask = 0;  // validity of the prefetched quads; applied at COMMIT time so that the loads stay
+                          // in flight (a select on the loaded value right here would force an immediate vmcnt wait)
     auto issue_loads = [&](int h, int cbase, int ncc) {  // channels cbase .. cbase+ncc-1 of row h
-        const float *Rrow = Rb + (size_t)h * W, *Lrow = Lb + (size_t)h * W;
+        const float *Rrow = Rb + ((size_t)h * W + (size_t)cbase * HW);  // wave-uniform
+        const float *Lrow = Lb + ((size_t)h * W + (size_t)cbase * HW);
+        okmask = wmask;
 #pragma unroll
         for (int k = 0; k < NSR; ++k) {
-            const int w = w0 - Dpad + rx[k];
-            const bool ok = rc[k] < ncc && w >= 0 && w + 3 < W;
-            pr[k] = ld4(Rrow + (size_t)(cbase + (ok ? rc[k] : 0)) * HW + (ok ? w : 0));
-            if (!ok) pr[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bool okc = rc[k] < ncc;  // only the tail chunk of a group can fail this
+            pr[k] = ld4(Rrow + (okc ? roff[k] : 0u));
+            if (!okc) okmask &= ~(1u << k);
         }
 #pragma unroll
         for (int k = 0; k < NSL; ++k) {
-            const int w = w0 + lx[k];
-            const bool ok = lc[k] < ncc && w + 3 < W;
-            pl[k] = ld4(Lrow + (size_t)(cbase + (ok ? lc[k] : 0)) * HW + (ok ? w : 0));
-            if (!ok) pl[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bool okc = lc[k] < ncc;
+            pl[k] = ld4(Lrow + (okc ? loff[k] : 0u));
+            if (!okc) okmask &= ~(1u << (8 + k));
         }
     };
 
@@ -281,12 +301,14 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
     };
     auto commit = [&](int buf) {  // prefetched registers -> LDS buffer `buf`
         float *rs = Rs + buf * BUF, *ls = Ls + buf * BUF;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < NSR; ++k)
-            if (rc[k] < CC) *reinterpret_cast<f32x4 *>(rs + rc[k] * RS + rx[k]) = pr[k];
+            if (rc[k] < CC) *reinterpret_cast<f32x4 *>(rs + rc[k] * RS + rx[k]) = (okmask >> k) & 1u ? pr[k] : zero;
 #pragma unroll
         for (int k = 0; k < NSL; ++k)
-            if (lc[k] < CC) *reinterpret_cast<f32x4 *>(ls + lc[k] * TW + lx[k]) = pl[k];
+            if (lc[k] < CC)
+                *reinterpret_cast<f32x4 *>(ls + lc[k] * TW + lx[k]) = (okmask >> (8 + k)) & 1u ? pl[k] : zero;
     };
     item_loads(0);
     commit(0);
@@ -304,10 +326,6 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
 #pragma unroll
             for (int i = 0; i < DC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        // item it+1 (in registers since the previous iteration) -> the other buffer: its last readers
-        // (item it-1) passed the barrier that ended the previous iteration.
-        if (it + 1 < nitems) commit((it + 1) & 1);
-        if (it + 2 < nitems) item_loads(it + 2);  // in flight during this item's math and stores
         const float *Rcur = Rs + (it & 1) * BUF, *Lcur = Ls + (it & 1) * BUF;
         if (active) {
             const float *rwin = Rcur + (Dpad + wl - d0 - DC);
@@ -329,6 +347,13 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
                 }
             }
         }
+        // Item it+1 (in registers since the previous iteration) -> the other LDS buffer (its last readers, item
+        // it-1, passed the barrier that ended the previous iteration), then item it+2's loads are issued.
+        // Placed AFTER this item's math and BEFORE its stores: the commit's vmcnt wait then only has to cover
+        // loads issued a whole item ago and the PREVIOUS group's stores, which had this item's math to drain
+        // (vmcnt counts loads and stores in one in-order queue).
+        if (it + 1 < nitems) commit((it + 1) & 1);
+        if (it + 2 < nitems) item_loads(it + 2);
         if (ck == nchunk - 1 && active) {  // group finished: epilogue
             const int w = w0 + wl;
             if (EPI == EPI_STORE) {
@@ -447,6 +472,7 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pk_kernel(const float *__
     const int rcp = tid / rq, rx = (tid - rcp * rq) * 4;
     const int lcp = tid / lq, lx = (tid - lcp * lq) * 4;
     f32x4 pr0, pr1, pl0, pl1;  // even / odd channel of the pair
+    unsigned okmask = 0;       // applied at commit time: keeps the loads in flight
     auto issue_loads = [&](int h, int cbase, int ncc) {
         const float *Rrow = Rb + (size_t)h * W, *Lrow = Lb + (size_t)h * W;
         {
@@ -455,8 +481,7 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pk_kernel(const float *__
             const bool ok0 = okw && c < ncc, ok1 = okw && c + 1 < ncc;
             pr0 = ld4(Rrow + (size_t)(cbase + (ok0 ? c : 0)) * HW + (ok0 ? w : 0));
             pr1 = ld4(Rrow + (size_t)(cbase + (ok1 ? c + 1 : 0)) * HW + (ok1 ? w : 0));
-            if (!ok0) pr0 = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (!ok1) pr1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            okmask = (ok0 ? 1u : 0u) | (ok1 ? 2u : 0u);
         }
         {
             const int w = w0 + lx, c = 2 * lcp;
@@ -464,12 +489,16 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pk_kernel(const float *__
             const bool ok0 = okw && c < ncc, ok1 = okw && c + 1 < ncc;
             pl0 = ld4(Lrow + (size_t)(cbase + (ok0 ? c : 0)) * HW + (ok0 ? w : 0));
             pl1 = ld4(Lrow + (size_t)(cbase + (ok1 ? c + 1 : 0)) * HW + (ok1 ? w : 0));
-            if (!ok0) pl0 = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (!ok1) pl1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            okmask |= (ok0 ? 4u : 0u) | (ok1 ? 8u : 0u);
         }
     };
     auto commit = [&](int buf) {
         float *rs = S0 + buf * BUF, *ls = rs + CP * RS * 2;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        if (!(okmask & 1u)) pr0 = zero;
+        if (!(okmask & 2u)) pr1 = zero;
+        if (!(okmask & 4u)) pl0 = zero;
+        if (!(okmask & 8u)) pl1 = zero;
         // layout [pair][plane][quad][4]: plane 0 = pixels (4q, 4q+1) x 2 channels, plane 1 = pixels (4q+2, 4q+3):
         // every ds_read_b128 of a wave then has a 16-byte lane stride (conflict-free); a 32-byte stride
         // ([x][2] interleave) costs a 2-way bank conflict on each read.
@@ -521,8 +550,6 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pk_kernel(const float *__
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[dd][i] = (f32x2){0.f, 0.f};
         }
-        if (it + 1 < nitems) commit((it + 1) & 1);
-        if (it + 2 < nitems) item_loads(it + 2);
         const float *Rcur = S0 + (it & 1) * BUF, *Lcur = Rcur + CP * RS * 2;
         if (active) {
             const float *rwin = Rcur + (Dpad + wl - d0 - DC);  // window origin (quad-aligned pixel index = float offset)
@@ -554,6 +581,8 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pk_kernel(const float *__
                 }
             }
         }
+        if (it + 1 < nitems) commit((it + 1) & 1);  // after the math, before the stores (see the kernel above)
+        if (it + 2 < nitems) item_loads(it + 2);
         if (ck == nchunk - 1 && active) {  // group finished for this pass: epilogue
             const int w = w0 + wl;
             if (EPI == EPI_STORE) {
@@ -670,6 +699,7 @@ int launch_pipe(const float *L, const float *R, float *vol, int B, int C, int H,
     const int nparts = (D + NWV * DC - 1) / (NWV * DC);
     if (Dpad > 256 || lds > 160 * 1024 || !fits_grid_yz((long long)B * nparts) || (EPI == EPI_ARGMIN && nparts != 1))
         return STEREO_ERR_UNSUPPORTED;
+    if ((long long)CCMAX * H * W + W >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;  // 32-bit per-slot offsets
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(gwc_volume_pipe_kernel<DC, NWV, EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
