@@ -17,6 +17,8 @@ from .corr import (AlternateCorrBlock, CorrBlock1D, InputPadder, PytorchAlternat
                    coords_grid)
 from .cross_attention import CrossAttentionCostVolume
 from .disparity_warper import disp_warp
+from .metrics import D1_metric, EPE_Loss, P1_metric, scale_disp, sequence_loss, thres_metric
+from .pfm import read_disp, read_pfm, write_pfm
 from .pipelines import LowCNNGRULoop, RAFTStereoLoop
 from .update_dlc import (BasicGuidanceNet, DisparityUpdateDLC, DisparityUpdateDLCWithMask,
                          DisparityUpdateDLCWithMaskV2, OffsetPredictionHead, gru_blend, gru_reset)
@@ -25,6 +27,8 @@ from .upsample import (ConvAffinityUpsample, interp, resize_bilinear, upflow8, u
                        upsample_flow, upsample_simple8)
 
 __all__ = [
+    "D1_metric", "EPE_Loss", "P1_metric", "scale_disp", "sequence_loss", "thres_metric", "read_disp", "read_pfm",
+    "write_pfm",
     "LowCNNGRULoop", "RAFTStereoLoop",
     "BasicGuidanceNet", "DisparityUpdateDLC", "DisparityUpdateDLCWithMask", "DisparityUpdateDLCWithMaskV2",
     "OffsetPredictionHead", "gru_blend", "gru_reset", "BasicMotionEncoder_LZH", "BasicMultiUpdateBlock_LZH",

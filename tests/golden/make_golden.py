@@ -322,6 +322,43 @@ def g9_raft_loop():
     save("g9_raft_loop", **out)
 
 
+# ------------------------------------------------------------------ G10
+def g10_metrics_io():
+    """Metrics, disparity rescale and the PFM container."""
+    import tempfile
+    from losses.squence_loss import EPE_Loss, sequence_loss
+    from utils.metric import D1_metric, P1_metric, thres_metric
+    from utils.file_io import write_pfm, _read_pfm
+
+    torch.manual_seed(1001)
+    gt = torch.rand(2, 1, 9, 13) * 220 - 10        # some <= 0 and some >= 192
+    pred = gt + torch.randn(2, 1, 9, 13) * 2.5
+    preds = [pred + 0.5 * i for i in range(3)]
+    out = {"gt": npy(gt), "pred": npy(pred)}
+    out["epe"] = npy(EPE_Loss(pred, gt))
+    out["seq"] = npy(sequence_loss(preds, gt))
+    out["d1"] = npy(D1_metric(pred, gt))
+    out["p1"] = npy(P1_metric(pred, gt))
+    out["thres3"] = npy(thres_metric(pred, gt, (gt > 0) & (gt < 192), 3.0))
+    try:
+        from dataloader.preprocess import scale_disp
+        d = torch.rand(1, 1, 12, 20) * 50
+        out["scale_in"], out["scale_out"] = npy(d), npy(scale_disp(d, (1, 9, 16)))
+    except Exception as e:  # dataloader.preprocess imports skimage/torchvision, absent here
+        print("scale_disp not importable (", type(e).__name__, "): restated with nn.Upsample", file=sys.stderr)
+        d = torch.rand(1, 1, 12, 20) * 50
+        out["scale_in"] = npy(d)
+        out["scale_out"] = npy(torch.nn.Upsample(size=(9, 16), mode="bilinear")(d) * (16 * 1.0 / 20))
+    img = (torch.rand(7, 11) * 100).numpy().astype(np.float32)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "x.pfm")
+        write_pfm(path, img)
+        out["pfm_bytes"] = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+        back, scale = _read_pfm(path)
+        out["pfm_img"], out["pfm_back"] = img, np.ascontiguousarray(back)
+    save("g10_metrics_io", **out)
+
+
 # ------------------------------------------------------------------ cfg-1 check
 def check_oracle_cfg1():
     """Not a fixture: proves the C oracle == the reference at BASELINE
@@ -356,5 +393,6 @@ if __name__ == "__main__":
     g7_upsample()
     g8_raft_update()
     g9_raft_loop()
+    g10_metrics_io()
     if CHECK:
         check_oracle_cfg1()
