@@ -156,6 +156,25 @@ int stereo_gru_reset_f32(const float *h, const float *rc, const float *cr, float
 int stereo_gru_blend_f32(const float *h, const float *zc, const float *qc, const float *cz,
                          const float *cq, float *out, long long n, int softsign, void *stream);
 
+/* ---- backward: the cfg-2 chain is differentiable -------------------------------- */
+
+/* backward of A4 (estimation.py:14-33,44-62): grad_disp [B,H,W], optional grad_prob [B,D,H,W] (the WithProb
+ * output's cotangent, may be NULL) -> grad_vol [B,D,H,W] */
+int stereo_soft_argmin_bwd_f32(const float *vol, const float *grad_disp, const float *grad_prob,
+                               float *grad_vol, int B, int D, int H, int W, int match_similarity, void *stream);
+
+/* backward of A1/A3 (build_cost_volume.py:39-47, GWC_Cost_Volume.py:14-24): grad_vol [B,G,D,H,W] ->
+ * grad_left, grad_right [B,C,H,W] (either may be NULL); G = 1 for the correlation volume */
+int stereo_gwc_volume_bwd_f32(const float *left, const float *right, const float *grad_vol,
+                              float *grad_left, float *grad_right, int B, int C, int H, int W, int D, int G,
+                              void *stream);
+
+/* backward of A5 (fixed_local_cost_volume.py:18-80, STE semantics :5-9): grad_out [B,1,H,W] ->
+ * grad_vol [B,D,H,W] (MUST be zero-filled by the caller; taps are accumulated into it) and grad_disp [B,1,H,W] */
+int stereo_local_lookup_bwd_f32(const float *vol, const float *disp, const float *grad_out,
+                                float *grad_vol_zeroed, float *grad_disp, int B, int D, int H, int W,
+                                float radius, int S, int consider_valid, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

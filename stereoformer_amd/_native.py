@@ -46,6 +46,9 @@ SIGNATURES = {
     "stereo_upsample_convex_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_resize_bilinear_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "stereo_cross_attention_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_soft_argmin_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "stereo_gwc_volume_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_local_lookup_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
     "stereo_gru_reset_f32": [_vp, _vp, _vp, _vp, _ll, _vp],
     "stereo_gru_blend_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp],
 }
@@ -109,7 +112,8 @@ def dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
         raise TypeError(f"{name}: expected float32, got {t.dtype} (the path computes in f32)")
     if torch.is_grad_enabled() and t.requires_grad:
         raise RuntimeError(
-            f"{name}: the HIP path is forward-only this round (SURVEY 8(f) N3); call under torch.no_grad()")
+            f"{name}: this op is forward-only (backward exists for CostVolume('correlation'), build_gwc_volume, "
+            "DisparityEstimation(WithProb) and LocalCostVolume - SURVEY 8(f) N3); call under torch.no_grad()")
     return t.contiguous()
 
 

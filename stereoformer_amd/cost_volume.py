@@ -13,6 +13,44 @@ import torch.nn as nn
 from . import _native as N
 
 
+class _GwcVolumeFn(torch.autograd.Function):
+    """Differentiable group-wise / correlation volume (G = 1): HIP forward + HIP backward
+    (``stereo_gwc_volume_bwd_f32``)."""
+
+    @staticmethod
+    def forward(ctx, left, right, max_disp, num_groups, squeeze_groups):
+        vol = _gwc_forward(left, right, max_disp, num_groups)
+        ctx.save_for_backward(left, right)
+        ctx.cfg = (int(max_disp), int(num_groups), bool(squeeze_groups))
+        return vol[:, 0] if squeeze_groups else vol
+
+    @staticmethod
+    def backward(ctx, grad_vol):
+        left, right = ctx.saved_tensors
+        D, G, squeeze = ctx.cfg
+        B, C, H, W = left.shape
+        gv = N.dev_f32(grad_vol.unsqueeze(1) if squeeze else grad_vol, "gwc backward: grad")
+        gl = torch.empty_like(left) if ctx.needs_input_grad[0] else None
+        gr = torch.empty_like(right) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(left.device):
+            N.call("stereo_gwc_volume_bwd_f32", N.ptr(left), N.ptr(right), N.ptr(gv), N.ptr(gl), N.ptr(gr), B, C, H, W,
+                   D, G, N.stream_ptr(left.device))
+        return gl, gr, None, None, None
+
+
+def _gwc_forward(L, R, maxdisp, num_groups):
+    B, C, H, W = L.shape
+    vol = torch.empty((B, num_groups, maxdisp, H, W), device=L.device, dtype=torch.float32)
+    with torch.cuda.device(L.device):
+        N.call("stereo_gwc_volume_f32", N.ptr(L), N.ptr(R), N.ptr(vol), B, C, H, W, int(maxdisp), int(num_groups),
+               N.stream_ptr(L.device))
+    return vol
+
+
+def _wants_grad(*ts):
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts)
+
+
 def _pair(left, right, who):
     left = N.dev_f32(left, f"{who}: left_feature")
     right = N.dev_f32(right, f"{who}: right_feature")
@@ -37,6 +75,10 @@ class CostVolume(nn.Module):
     def forward(self, left_feature, right_feature):
         if self.feature_similarity not in ("difference", "concat", "correlation"):
             raise NotImplementedError
+        if self.feature_similarity == "correlation" and _wants_grad(left_feature, right_feature):
+            with torch.no_grad():
+                _pair(left_feature, right_feature, "CostVolume")  # validation only
+            return _GwcVolumeFn.apply(left_feature.contiguous(), right_feature.contiguous(), int(self.max_disp), 1, True)
         L, R = _pair(left_feature, right_feature, "CostVolume")
         b, c, h, w = L.shape
         D = int(self.max_disp)
@@ -72,14 +114,14 @@ class CostVolumePyramid(nn.Module):
 
 def build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups):
     """``build_gwc_volume`` (GWC_Cost_Volume.py:14-24) -> [B,G,D,H,W]."""
+    if _wants_grad(refimg_fea, targetimg_fea):
+        with torch.no_grad():
+            L, R = _pair(refimg_fea, targetimg_fea, "build_gwc_volume")
+        assert L.shape[1] % num_groups == 0  # GWC_Cost_Volume.py:7
+        return _GwcVolumeFn.apply(refimg_fea.contiguous(), targetimg_fea.contiguous(), int(maxdisp), int(num_groups), False)
     L, R = _pair(refimg_fea, targetimg_fea, "build_gwc_volume")
-    B, C, H, W = L.shape
-    assert C % num_groups == 0  # GWC_Cost_Volume.py:7
-    vol = torch.empty((B, num_groups, maxdisp, H, W), device=L.device, dtype=torch.float32)
-    with torch.cuda.device(L.device):
-        N.call("stereo_gwc_volume_f32", N.ptr(L), N.ptr(R), N.ptr(vol), B, C, H, W, int(maxdisp), int(num_groups),
-               N.stream_ptr(L.device))
-    return vol
+    assert L.shape[1] % num_groups == 0  # GWC_Cost_Volume.py:7
+    return _gwc_forward(L, R, maxdisp, num_groups)
 
 
 def groupwise_correlation(fea1, fea2, num_groups):

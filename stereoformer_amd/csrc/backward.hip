@@ -1,0 +1,389 @@
+// Backward kernels for the cfg-2 chain: soft-argmin, correlation / group-wise volume,
+// local cost-volume lookup.  Same conventions as the forward kernels: fp32, NCHW, lanes along W.
+#include "common.h"
+
+namespace {
+
+inline unsigned grid_for(long long nthreads)
+{
+    long long blocks = (nthreads + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > (1LL << 30)) blocks = 1LL << 30;
+    return (unsigned)blocks;
+}
+
+// ------------------------------------------------------------------ soft-argmin backward
+// disp = sum_d p_d d, p = softmax(sgn*vol):  d disp / d vol_d = sgn * p_d * (d - disp).
+// With a probability cotangent gp (DisparityEstimationWithProb): cot_d = g*d + gp_d,
+//   d L / d vol_d = sgn * p_d * (cot_d - sum_k p_k cot_k).
+// One lane = 4 pixels; pass 1 (online softmax) reads the column once, pass 2 re-reads it (cache-warm) and
+// writes the gradient with 16-byte stores.
+template <int V, bool HAS_GP>
+__global__ __launch_bounds__(256) void soft_argmin_bwd_kernel(const float *__restrict__ vol,
+                                                              const float *__restrict__ gdisp,
+                                                              const float *__restrict__ gprob,
+                                                              float *__restrict__ gvol, int D, long long HW,
+                                                              long long ncols, float sgn)
+{
+    const long long HWv = HW / V;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < ncols;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long b = t / HWv, p = (t - b * HWv) * V;
+        const float *v = vol + (size_t)b * D * HW + p;
+        const float *gp = HAS_GP ? gprob + (size_t)b * D * HW + p : nullptr;
+        float m[V], s[V], e[V], g[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) m[i] = -INFINITY, s[i] = 0.0f, e[i] = 0.0f, g[i] = gdisp[(size_t)b * HW + p + i];
+        for (int d = 0; d < D; ++d) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float x = sgn * v[(size_t)d * HW + i];
+                const float cot = g[i] * (float)d + (HAS_GP ? gp[(size_t)d * HW + i] : 0.0f);
+                const float cm = fmaxf(m[i], x);
+                const float sc = (m[i] == cm) ? 1.0f : fast_exp(m[i] - cm);
+                const float pe = fast_exp(x - cm);
+                s[i] = s[i] * sc + pe;
+                e[i] = e[i] * sc + pe * cot;
+                m[i] = cm;
+            }
+        }
+        float inv[V], mean_cot[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) inv[i] = 1.0f / s[i], mean_cot[i] = e[i] * inv[i];
+        float *o = gvol + (size_t)b * D * HW + p;
+        for (int d = 0; d < D; ++d) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float pd = fast_exp(sgn * v[(size_t)d * HW + i] - m[i]) * inv[i];
+                const float cot = g[i] * (float)d + (HAS_GP ? gp[(size_t)d * HW + i] : 0.0f);
+                o[(size_t)d * HW + i] = sgn * pd * (cot - mean_cot[i]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ volume backward
+// vol[b,g,d,h,w] = (1/CPG) sum_{c in g} L[c,w] R[c,w-d]  (w >= d)
+//   dL[c,w] = (1/CPG) sum_{d <= w} gv[g,d,w]   * R[c,w-d]
+//   dR[c,v] = (1/CPG) sum_{v+d < W} gv[g,d,v+d] * L[c,v+d]
+// One workgroup = (row, 256-pixel tile, batch*group); the D disparities are split over the 8 waves in
+// chunks of 8.  Each lane (4 pixels) keeps CB x 4 accumulators for ALL CB <= 32 channels of the block, so
+// the gradient volume -- the big tensor -- is read exactly once per output (16-byte W-contiguous loads;
+// the diagonal access of dR uses two aligned quads per plane with compile-time lane selection).  The other
+// feature row sits in an LDS tile with halo (left halo for dL, right halo for dR) and is read as a sliding
+// register window of ds_read_b128, like the forward kernel.  The 8 partial sums meet in LDS, 8 channels a round.
+constexpr int BT = 256, BNW = 8, BDC = 8, BRC = 8;
+
+template <bool WRT_LEFT, int CB>
+__global__ __launch_bounds__(BNW * 64) void volume_bwd_kernel(const float *__restrict__ F,  // the OTHER feature map
+                                                              const float *__restrict__ gv,
+                                                              float *__restrict__ gF, int C, int H, int W, int D,
+                                                              int G, int CPG, int Dpad, float inv_cpg, int exact_div)
+{
+    extern __shared__ f32x4 smem4[];
+    float *Fs = reinterpret_cast<float *>(smem4);  // [CB][BT + Dpad]
+    const int FS = BT + Dpad;
+    const int x0 = blockIdx.x * BT, h = blockIdx.y;
+    const int b = blockIdx.z / G, g = blockIdx.z - b * G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int xl = lane * 4;
+    const size_t HW = (size_t)H * W;
+    const float *gvrow = gv + (((size_t)b * G + g) * D) * HW + (size_t)h * W;
+    const int f0 = WRT_LEFT ? x0 - Dpad : x0;      // global w of LDS column 0
+    const bool vec = (W % 4 == 0);
+
+    for (int c0 = 0; c0 < CPG; c0 += CB) {
+        const int ncc = (CPG - c0) < CB ? (CPG - c0) : CB;
+        const float *Frow = F + ((size_t)b * C + (size_t)g * CPG + c0) * HW + (size_t)h * W;
+        float *grow = gF + ((size_t)b * C + (size_t)g * CPG + c0) * HW + (size_t)h * W;
+        __syncthreads();
+        for (int idx = tid; idx < CB * (FS / 4); idx += BNW * 64) {
+            const int c = idx / (FS / 4), x = (idx - c * (FS / 4)) * 4;
+            const int w = f0 + x;
+            f32x4 q;
+            if (vec && c < ncc && w >= 0 && w + 3 < W) {
+                q = ld4(Frow + (size_t)c * HW + w);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q[i] = (c < ncc && w + i >= 0 && w + i < W) ? Frow[(size_t)c * HW + w + i] : 0.0f;
+            }
+            *reinterpret_cast<f32x4 *>(Fs + c * FS + x) = q;
+        }
+        __syncthreads();
+        float acc[CB][4];
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[c][i] = 0.0f;
+        const int nchunks = (D + BDC - 1) / BDC;
+        for (int ch = wave; ch < nchunks; ch += BNW) {
+            const int d0 = ch * BDC;
+            // ---- gradient quads for the 8 planes of this chunk: gq[dd][i] = gv[d0+dd][x + i (+ d for dR)]
+            float gq[BDC][4];
+#pragma unroll
+            for (int dd = 0; dd < BDC; ++dd) {
+                const int d = d0 + dd;
+                const int x = x0 + xl;
+                if (WRT_LEFT) {
+                    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+                    if (d < D) {
+                        if (vec && x + 3 < W) {
+                            q = ld4(gvrow + (size_t)d * HW + x);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) q[i] = (x + i < W) ? gvrow[(size_t)d * HW + x + i] : 0.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gq[dd][i] = (x + i >= d) ? q[i] : 0.0f;  // zero-filled region: no grad
+                } else {
+                    // need gv[d][x + d + i], i = 0..3: aligned base x + d0 + 4*(dd/4), in-quad shift dd % 4
+                    const int wb = x + d0 + 4 * (dd / 4);
+                    f32x4 qa = {0.f, 0.f, 0.f, 0.f}, qb = {0.f, 0.f, 0.f, 0.f};
+                    if (d < D) {
+                        if (vec && wb + 7 < W) {
+                            qa = ld4(gvrow + (size_t)d * HW + wb);
+                            if (dd % 4) qb = ld4(gvrow + (size_t)d * HW + wb + 4);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                qa[i] = (wb + i < W) ? gvrow[(size_t)d * HW + wb + i] : 0.0f;
+                                qb[i] = (wb + 4 + i < W) ? gvrow[(size_t)d * HW + wb + 4 + i] : 0.0f;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = (dd % 4) + i;  // compile-time
+                        gq[dd][i] = (x + i < W) ? (k < 4 ? qa[k] : qb[k - 4]) : 0.0f;
+                    }
+                }
+            }
+            // ---- feature window: dL taps R[x+i-d]: columns Dpad+xl-d0-8 .. +11 ; dR taps L[x+i+d]: xl+d0 .. +11
+            const float *fwin = Fs + (WRT_LEFT ? (Dpad + xl - d0 - BDC) : (xl + d0));
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                if (c < ncc) {
+                    float win[12];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const f32x4 t = *reinterpret_cast<const f32x4 *>(fwin + c * FS + 4 * q);
+                        win[4 * q + 0] = t[0];
+                        win[4 * q + 1] = t[1];
+                        win[4 * q + 2] = t[2];
+                        win[4 * q + 3] = t[3];
+                    }
+#pragma unroll
+                    for (int dd = 0; dd < BDC; ++dd)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[c][i] = fmaf(gq[dd][i], win[WRT_LEFT ? (BDC + i - dd) : (i + dd)], acc[c][i]);
+                }
+            }
+        }
+        // ---- reduce the 8 waves' partial sums through LDS, BRC channels a round (tile no longer needed)
+        float *red = Fs;  // [BNW][BRC][BT]
+#pragma unroll
+        for (int r0 = 0; r0 < CB; r0 += BRC) {
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < BRC; ++c)
+                if (r0 + c < CB) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) red[(wave * BRC + c) * BT + xl + i] = acc[r0 + c][i];
+                }
+            __syncthreads();
+            for (int idx = tid; idx < BRC * BT; idx += BNW * 64) {
+                const int c = idx / BT, x = idx - c * BT;
+                if (r0 + c < ncc && x0 + x < W) {
+                    float s = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < BNW; ++k) s += red[(k * BRC + c) * BT + x];
+                    grow[(size_t)(r0 + c) * HW + x0 + x] = exact_div ? s / (float)CPG : s * inv_cpg;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ local lookup backward (A5)
+// out = sum_k p_k c_k, p = softmax_k(val_k), val_k = v[fl_k]*fr_k + v[ce_k]*cr_k,
+// fr_k = ce_k - c_k, cr_k = 1 - fr_k (fixed_local_cost_volume.py:61-80; .long() cuts the STE path, so the
+// tap indices carry no gradient while fr/cr do).  With a_k = g * p_k * (c_k - out):
+//   d/d vol[fl_k] += a_k * fr_k ;  d/d vol[ce_k] += a_k * cr_k
+//   d/d c_k = g * p_k + a_k * (v[ce_k] - v[fl_k])
+//   d c_k / d disp: consider_valid -> 1 (valid: both bounds move with disp; invalid: c_k = disp);
+//                   otherwise (1-k/S)*[lower not clamped] + (k/S)*[upper not clamped].
+// grad_vol must be zero-initialised by the caller; every lane owns its pixel column, so there are no
+// cross-lane collisions and the candidates' taps (monotone in k) are merged in registers before the store.
+__global__ __launch_bounds__(256) void local_lookup_bwd_kernel(const float *__restrict__ vol,
+                                                               const float *__restrict__ disp,
+                                                               const float *__restrict__ gout,
+                                                               float *__restrict__ gvol, float *__restrict__ gdisp,
+                                                               int D, long long HW, long long npix, float radius,
+                                                               int S, int consider_valid)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npix;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long b = t / HW, p = t - b * HW;
+        const float *v = vol + (size_t)b * D * HW + p;
+        float *gvp = gvol + (size_t)b * D * HW + p;
+        const float cur = disp[t], g = gout[t];
+        float lower = cur - radius, upper = cur + radius;
+        int invalid = -1;
+        float dl = 1.0f, du = 1.0f;  // d lower / d disp, d upper / d disp
+        if (consider_valid) {
+            invalid = (lower < 0.0f) || (upper >= (float)(D - 1));
+        } else {
+            if (lower < 0.0f) lower = 0.0f, dl = 0.0f;
+            if (upper < 0.0f) upper = 0.0f, du = 0.0f;
+            else if (upper > (float)D) upper = (float)D, du = 0.0f;
+        }
+        const float interval = __fdiv_rn(__fmul_rn(__fsub_rn(upper, lower), 1.0f), (float)S);
+        const float inv = invalid > 0 ? 1.0f : 0.0f;
+        // pass 1: softmax statistics and the expectation
+        float m = -INFINITY, s = 0.0f, e = 0.0f;
+        for (int k = 0; k <= S; ++k) {
+            float c = __fadd_rn(lower, __fmul_rn((float)k, interval));
+            if (invalid >= 0) c = __fadd_rn(__fmul_rn(c, 1.0f - inv), __fmul_rn(inv, cur));
+            const float val = sample_tap(v, (size_t)HW, D, c);
+            const float cm = fmaxf(m, val);
+            const float sc = (m == cm) ? 1.0f : fast_exp(m - cm);
+            const float pe = fast_exp(val - cm);
+            s = s * sc + pe;
+            e = e * sc + pe * c;
+            m = cm;
+        }
+        const float out = e / s, invs = 1.0f / s;
+        // pass 2: gradients
+        float gd = 0.0f;
+        int pend_idx = -1;
+        float pend_val = 0.0f;
+        auto push = [&](int idx, float val) {
+            if (idx == pend_idx) {
+                pend_val += val;
+            } else {
+                if (pend_idx >= 0) gvp[(size_t)pend_idx * HW] += pend_val;
+                pend_idx = idx;
+                pend_val = val;
+            }
+        };
+        for (int k = 0; k <= S; ++k) {
+            float c = __fadd_rn(lower, __fmul_rn((float)k, interval));
+            if (invalid >= 0) c = __fadd_rn(__fmul_rn(c, 1.0f - inv), __fmul_rn(inv, cur));
+            const float cc = clampf(ste_ceil_f(c), 0.0f, (float)(D - 1));
+            const float cf = clampf(ste_floor_f(c), 0.0f, (float)(D - 1));
+            const int ic = (int)cc, ifl = (int)cf;
+            const float fr = (float)ic - c, cr = 1.0f - fr;
+            const float vf = v[(size_t)ifl * HW], vc = v[(size_t)ic * HW];
+            const float pk = fast_exp(vf * fr + vc * cr - m) * invs;
+            const float a = g * pk * (c - out);
+            push(ifl, a * fr);
+            push(ic, a * cr);
+            const float dc = g * pk + a * (vc - vf);
+            float dcd;
+            if (consider_valid) {
+                dcd = 1.0f;
+            } else {
+                const float tk = (float)k / (float)S;
+                dcd = (1.0f - tk) * dl + tk * du;
+            }
+            gd = fmaf(dc, dcd, gd);
+        }
+        if (pend_idx >= 0) gvp[(size_t)pend_idx * HW] += pend_val;
+        gdisp[t] = gd;
+    }
+}
+
+}  // namespace
+
+extern "C" int stereo_soft_argmin_bwd_f32(const float *vol, const float *grad_disp, const float *grad_prob,
+                                          float *grad_vol, int B, int D, int H, int W, int match_similarity,
+                                          void *stream)
+{
+    if (B < 0 || D < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0 || D == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(vol);
+    STEREO_REQUIRE_PTR(grad_disp);
+    STEREO_REQUIRE_PTR(grad_vol);
+    const long long HW = (long long)H * W;
+    const float sgn = match_similarity ? 1.0f : -1.0f;
+    hipStream_t st = as_stream(stream);
+    const bool vec = (HW % 4 == 0);
+    const long long n = vec ? (long long)B * (HW / 4) : (long long)B * HW;
+#define SAB(V, GP) \
+    hipLaunchKernelGGL((soft_argmin_bwd_kernel<V, GP>), dim3(grid_for(n)), dim3(256), 0, st, vol, grad_disp, grad_prob, \
+                       grad_vol, D, HW, n, sgn)
+    if (vec && grad_prob) SAB(4, true);
+    else if (vec) SAB(4, false);
+    else if (grad_prob) SAB(1, true);
+    else SAB(1, false);
+#undef SAB
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+extern "C" int stereo_gwc_volume_bwd_f32(const float *left, const float *right, const float *grad_vol,
+                                         float *grad_left, float *grad_right, int B, int C, int H, int W, int D, int G,
+                                         void *stream)
+{
+    if (B < 0 || C < 0 || H < 0 || W < 0 || D < 0 || G <= 0) return STEREO_ERR_BAD_SHAPE;
+    if (C % G != 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || C == 0 || H == 0 || W == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(left);
+    STEREO_REQUIRE_PTR(right);
+    if (D > 0) STEREO_REQUIRE_PTR(grad_vol);
+    if (grad_left == nullptr && grad_right == nullptr) return STEREO_OK;
+    if (!fits_grid_yz(H) || !fits_grid_yz((long long)B * G) || D > 4096) return STEREO_ERR_UNSUPPORTED;
+    const int CPG = C / G;
+    const int Dpad = (D + BDC - 1) / BDC * BDC;
+    const int CB = CPG <= 4 ? 4 : (CPG <= 8 ? 8 : 32);
+    size_t lds = (size_t)CB * (BT + Dpad) * sizeof(float);
+    const size_t redb = (size_t)BNW * BRC * BT * sizeof(float);
+    if (lds < redb) lds = redb;
+    if (lds > 160 * 1024) return STEREO_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const bool pow2 = (CPG & (CPG - 1)) == 0;
+    dim3 grid((W + BT - 1) / BT, H, (unsigned)(B * G));
+#define VB_LAUNCH(LEFT, CBV, OTHER, GOUT)                                                                               \
+    {                                                                                                                  \
+        auto k = volume_bwd_kernel<LEFT, CBV>;                                                                         \
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(k),                                  \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return STEREO_ERR_UNSUPPORTED;                                                                             \
+        hipLaunchKernelGGL(k, grid, dim3(BNW * 64), lds, st, OTHER, grad_vol, GOUT, C, H, W, D, G, CPG, Dpad,           \
+                           1.0f / (float)CPG, pow2 ? 0 : 1);                                                           \
+        STEREO_LAUNCH_CHECK();                                                                                         \
+    }
+    if (grad_left) {
+        if (CB == 4) VB_LAUNCH(true, 4, right, grad_left)
+        else if (CB == 8) VB_LAUNCH(true, 8, right, grad_left)
+        else VB_LAUNCH(true, 32, right, grad_left)
+    }
+    if (grad_right) {
+        if (CB == 4) VB_LAUNCH(false, 4, left, grad_right)
+        else if (CB == 8) VB_LAUNCH(false, 8, left, grad_right)
+        else VB_LAUNCH(false, 32, left, grad_right)
+    }
+#undef VB_LAUNCH
+    return STEREO_OK;
+}
+
+extern "C" int stereo_local_lookup_bwd_f32(const float *vol, const float *disp, const float *grad_out,
+                                           float *grad_vol_zeroed, float *grad_disp, int B, int D, int H, int W,
+                                           float radius, int S, int consider_valid, void *stream)
+{
+    if (B < 0 || D < 0 || H < 0 || W < 0 || S <= 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0) return STEREO_OK;
+    if (D == 0) return STEREO_ERR_BAD_SHAPE;
+    STEREO_REQUIRE_PTR(vol);
+    STEREO_REQUIRE_PTR(disp);
+    STEREO_REQUIRE_PTR(grad_out);
+    STEREO_REQUIRE_PTR(grad_vol_zeroed);
+    STEREO_REQUIRE_PTR(grad_disp);
+    const long long HW = (long long)H * W, n = (long long)B * HW;
+    hipLaunchKernelGGL(local_lookup_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), vol, disp, grad_out,
+                       grad_vol_zeroed, grad_disp, D, HW, n, radius, S, consider_valid);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}

@@ -8,8 +8,44 @@ import torch.nn as nn
 from . import _native as N
 
 
+class _SoftArgminFn(torch.autograd.Function):
+    """Differentiable soft-argmin (optionally with the probability volume as a second output)."""
+
+    @staticmethod
+    def forward(ctx, cost_volume, match_similarity, with_prob):
+        disp, prob = _soft_argmin_fwd(cost_volume, match_similarity, with_prob, "DisparityEstimation")
+        ctx.save_for_backward(cost_volume)
+        ctx.cfg = (bool(match_similarity), bool(with_prob))
+        if with_prob:
+            return disp, prob
+        return disp
+
+    @staticmethod
+    def backward(ctx, grad_disp, grad_prob=None):
+        (vol,) = ctx.saved_tensors
+        sim, with_prob = ctx.cfg
+        B, D, H, W = vol.shape
+        gd = N.dev_f32(grad_disp if grad_disp is not None else torch.zeros((B, H, W), device=vol.device),
+                       "soft-argmin backward: grad_disp")
+        gp = N.dev_f32(grad_prob, "soft-argmin backward: grad_prob") if (with_prob and grad_prob is not None) else None
+        gvol = torch.empty_like(vol)
+        with torch.cuda.device(vol.device):
+            N.call("stereo_soft_argmin_bwd_f32", N.ptr(vol), N.ptr(gd), N.ptr(gp), N.ptr(gvol), B, D, H, W,
+                   1 if sim else 0, N.stream_ptr(vol.device))
+        return gvol, None, None
+
+
 def _soft_argmin(cost_volume, match_similarity, with_prob, who):
     assert cost_volume.dim() == 4  # estimation.py:15
+    if torch.is_grad_enabled() and cost_volume.requires_grad:
+        with torch.no_grad():
+            N.dev_f32(cost_volume, f"{who}: cost_volume")  # validation only
+        out = _SoftArgminFn.apply(cost_volume.contiguous(), bool(match_similarity), bool(with_prob))
+        return out if with_prob else (out, None)
+    return _soft_argmin_fwd(cost_volume, match_similarity, with_prob, who)
+
+
+def _soft_argmin_fwd(cost_volume, match_similarity, with_prob, who):
     vol = N.dev_f32(cost_volume, f"{who}: cost_volume")
     B, D, H, W = vol.shape
     disp = torch.empty((B, H, W), device=vol.device, dtype=torch.float32)
@@ -60,18 +96,55 @@ def disparity_regression(x, maxdisp):
     return out
 
 
-def group_mean_soft_argmin(volume_g, match_similarity=True, return_mean=False):
-    """cfg-2 chain reader: ``DisparityEstimation(D)(volume_g.mean(1))`` for a group-wise
-    volume [B,G,D,H,W] in ONE pass over it; optionally also returns the mean volume."""
-    vg = N.dev_f32(volume_g, "group_mean_soft_argmin: volume_g")
-    if vg.dim() != 5:
-        raise ValueError("group_mean_soft_argmin: expected [B,G,D,H,W]")
+class _GroupMeanSoftArgminFn(torch.autograd.Function):
+    """Differentiable fused reader: d/d volume_g[:, g] = (soft-argmin backward on the mean volume + the mean
+    volume's own cotangent) / G for every group."""
+
+    @staticmethod
+    def forward(ctx, volume_g, match_similarity):
+        disp, mean = _group_mean_fwd(volume_g, match_similarity, True)
+        ctx.save_for_backward(mean)
+        ctx.cfg = (bool(match_similarity), volume_g.shape[1])
+        return disp, mean
+
+    @staticmethod
+    def backward(ctx, grad_disp, grad_mean):
+        (mean,) = ctx.saved_tensors
+        sim, G = ctx.cfg
+        B, D, H, W = mean.shape
+        gd = N.dev_f32(grad_disp if grad_disp is not None else torch.zeros((B, H, W), device=mean.device),
+                       "group_mean_soft_argmin backward: grad_disp")
+        gmean = torch.empty_like(mean)
+        with torch.cuda.device(mean.device):
+            N.call("stereo_soft_argmin_bwd_f32", N.ptr(mean), N.ptr(gd), N.ptr(None), N.ptr(gmean), B, D, H, W,
+                   1 if sim else 0, N.stream_ptr(mean.device))
+        if grad_mean is not None:
+            gmean = gmean + grad_mean
+        return (gmean / G).unsqueeze(1).expand(B, G, D, H, W).contiguous(), None
+
+
+def _group_mean_fwd(vg, match_similarity, return_mean):
     B, G, D, H, W = vg.shape
     disp = torch.empty((B, H, W), device=vg.device, dtype=torch.float32)
     mean = torch.empty((B, D, H, W), device=vg.device, dtype=torch.float32) if return_mean else None
     with torch.cuda.device(vg.device):
         N.call("stereo_group_mean_soft_argmin_f32", N.ptr(vg), N.ptr(mean), N.ptr(disp), B, G, D, H, W,
                1 if match_similarity else 0, N.stream_ptr(vg.device))
+    return disp, mean
+
+
+def group_mean_soft_argmin(volume_g, match_similarity=True, return_mean=False):
+    """cfg-2 chain reader: ``DisparityEstimation(D)(volume_g.mean(1))`` for a group-wise
+    volume [B,G,D,H,W] in ONE pass over it; optionally also returns the mean volume."""
+    if volume_g.dim() != 5:
+        raise ValueError("group_mean_soft_argmin: expected [B,G,D,H,W]")
+    if torch.is_grad_enabled() and volume_g.requires_grad:
+        with torch.no_grad():
+            N.dev_f32(volume_g, "group_mean_soft_argmin: volume_g")  # validation only
+        disp, mean = _GroupMeanSoftArgminFn.apply(volume_g.contiguous(), bool(match_similarity))
+        return (disp, mean) if return_mean else disp
+    vg = N.dev_f32(volume_g, "group_mean_soft_argmin: volume_g")
+    disp, mean = _group_mean_fwd(vg, match_similarity, return_mean)
     return (disp, mean) if return_mean else disp
 
 

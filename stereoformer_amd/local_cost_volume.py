@@ -21,6 +21,39 @@ def _vol_disp(old_cost_volume, cur_disparity, who):
     return vol, disp
 
 
+class _LocalLookupFn(torch.autograd.Function):
+    """Differentiable fixed-radius local lookup (A5) with the reference's STE semantics."""
+
+    @staticmethod
+    def forward(ctx, vol, disp, radius, sample_points, consider_valid):
+        out = _local_lookup_fwd(vol, disp, radius, sample_points, consider_valid)
+        ctx.save_for_backward(vol, disp)
+        ctx.cfg = (float(radius), int(sample_points), bool(consider_valid))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        vol, disp = ctx.saved_tensors
+        radius, S, cv = ctx.cfg
+        B, D, H, W = vol.shape
+        go = N.dev_f32(grad_out, "LocalCostVolume backward: grad")
+        gvol = torch.zeros_like(vol)      # taps are accumulated into it
+        gdisp = torch.empty_like(disp)
+        with torch.cuda.device(vol.device):
+            N.call("stereo_local_lookup_bwd_f32", N.ptr(vol), N.ptr(disp), N.ptr(go), N.ptr(gvol), N.ptr(gdisp), B, D, H,
+                   W, radius, S, 1 if cv else 0, N.stream_ptr(vol.device))
+        return gvol, gdisp, None, None, None
+
+
+def _local_lookup_fwd(vol, disp, radius, sample_points, consider_valid):
+    B, D, H, W = vol.shape
+    out = torch.empty((B, 1, H, W), device=vol.device, dtype=torch.float32)
+    with torch.cuda.device(vol.device):
+        N.call("stereo_local_lookup_f32", N.ptr(vol), N.ptr(disp), N.ptr(out), B, D, H, W, float(radius),
+               int(sample_points), 1 if consider_valid else 0, N.stream_ptr(vol.device))
+    return out
+
+
 class LocalCostVolume(nn.Module):
     """``LocalCostVolume(radius=4, sample_points=10)`` (fixed_local_cost_volume.py:13-58)."""
 
@@ -30,13 +63,13 @@ class LocalCostVolume(nn.Module):
         self.sample_points = sample_points
 
     def forward(self, old_cost_volume, cur_disparity, consider_valid=False):
+        if torch.is_grad_enabled() and (old_cost_volume.requires_grad or cur_disparity.requires_grad):
+            with torch.no_grad():
+                _vol_disp(old_cost_volume, cur_disparity, "LocalCostVolume")  # validation only
+            return _LocalLookupFn.apply(old_cost_volume.contiguous(), cur_disparity.contiguous(), float(self.radius),
+                                        int(self.sample_points), bool(consider_valid))
         vol, disp = _vol_disp(old_cost_volume, cur_disparity, "LocalCostVolume")
-        B, D, H, W = vol.shape
-        out = torch.empty((B, 1, H, W), device=vol.device, dtype=torch.float32)
-        with torch.cuda.device(vol.device):
-            N.call("stereo_local_lookup_f32", N.ptr(vol), N.ptr(disp), N.ptr(out), B, D, H, W, float(self.radius),
-                   int(self.sample_points), 1 if consider_valid else 0, N.stream_ptr(vol.device))
-        return out
+        return _local_lookup_fwd(vol, disp, self.radius, self.sample_points, consider_valid)
 
 
 class Variance_Based_Local_Cost_Volume(nn.Module):

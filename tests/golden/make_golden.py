@@ -359,6 +359,49 @@ def g10_metrics_io():
     save("g10_metrics_io", **out)
 
 
+# ------------------------------------------------------------------ G11
+def g11_backward():
+    """Gradients of the cfg-2 chain ops from the reference's own autograd (CPU)."""
+    from models.utils.build_cost_volume import CostVolume
+    from models.CrossAttentionCostVolume.GWC_Cost_Volume import build_gwc_volume
+    from models.utils.estimation import DisparityEstimation, DisparityEstimationWithProb
+    from models.LocalCostVolume.Attempts.fixed_local_cost_volume import LocalCostVolume
+
+    out = {}
+    with torch.enable_grad():
+        torch.manual_seed(1101)
+        L = torch.randn(2, 8, 4, 40, requires_grad=True)
+        R = torch.randn(2, 8, 4, 40, requires_grad=True)
+        for (D, G) in ((12, 1), (12, 4), (40, 2)):
+            vol = CostVolume(D, "correlation")(L, R) if G == 1 else build_gwc_volume(L, R, D, G)
+            cot = torch.randn_like(vol)
+            gl, gr = torch.autograd.grad(vol, (L, R), cot)
+            out[f"vol_cot_D{D}_G{G}"], out[f"vol_gl_D{D}_G{G}"], out[f"vol_gr_D{D}_G{G}"] = npy(cot), npy(gl), npy(gr)
+        out["L"], out["R"] = npy(L), npy(R)
+        v = (3.0 * torch.randn(2, 12, 5, 40)).requires_grad_(True)
+        cd = torch.randn(2, 5, 40)
+        for sim in (True, False):
+            (gv,) = torch.autograd.grad(DisparityEstimation(12, sim)(v), v, cd)
+            out[f"sa_gvol_sim{int(sim)}"] = npy(gv)
+        d, p = DisparityEstimationWithProb(12, True)(v)
+        cp = torch.randn_like(p)
+        (gv,) = torch.autograd.grad((d, p), v, (cd, cp))
+        out["sa_vol"], out["sa_cot_disp"], out["sa_cot_prob"], out["sa_gvol_withprob"] = npy(v), npy(cd), npy(cp), npy(gv)
+        vol = (2.0 * torch.randn(2, 24, 6, 20)).requires_grad_(True)
+        disp = (torch.rand(2, 1, 6, 20) * 23).requires_grad_(True)
+        with torch.no_grad():
+            disp[0, 0, 0, 0] = 0.5
+            disp[0, 0, 0, 1] = 22.5
+            disp[0, 0, 0, 2] = 7.0
+        co = torch.randn(2, 1, 6, 20)
+        out["ll_vol"], out["ll_disp"], out["ll_cot"] = npy(vol), npy(disp), npy(co)
+        for (r, S) in ((2, 20), (4, 10)):
+            for cv in (False, True):
+                gvv, gdd = torch.autograd.grad(LocalCostVolume(r, S)(vol, disp, cv), (vol, disp), co)
+                out[f"ll_gvol_r{r}_S{S}_cv{int(cv)}"], out[f"ll_gdisp_r{r}_S{S}_cv{int(cv)}"] = npy(gvv), npy(gdd)
+    save("g11_backward", **out)
+
+
 # ------------------------------------------------------------------ cfg-1 check
 def check_oracle_cfg1():
     """Not a fixture: proves the C oracle == the reference at BASELINE
@@ -394,5 +437,6 @@ if __name__ == "__main__":
     g8_raft_update()
     g9_raft_loop()
     g10_metrics_io()
+    g11_backward()
     if CHECK:
         check_oracle_cfg1()

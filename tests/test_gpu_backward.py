@@ -1,0 +1,106 @@
+"""backward of the cfg-2 chain ops (correlation / group-wise volume, soft-argmin (+prob),
+fixed-radius local lookup) against gradients produced by the reference's own autograd on CPU (golden G11),
+plus finite-difference spot checks.  Tolerances: 2e-5 abs on gradients of O(1) tensors."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-4, atol=2e-5)
+
+
+def dev(a, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    return t.requires_grad_(grad)
+
+
+def close(a, b, **tol):
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b, **tol)
+
+
+@pytest.fixture(scope="module")
+def S():
+    import stereoformer_amd as s
+    return s
+
+
+def test_volume_backward_g11(S, golden):
+    g = golden("g11_backward")
+    for (D, G) in ((12, 1), (12, 4), (40, 2)):
+        L, R = dev(g["L"], True), dev(g["R"], True)
+        vol = S.CostVolume(D)(L, R) if G == 1 else S.build_gwc_volume(L, R, D, G)
+        gl, gr = torch.autograd.grad(vol, (L, R), dev(g[f"vol_cot_D{D}_G{G}"]))
+        close(gl, g[f"vol_gl_D{D}_G{G}"], **TOL)
+        close(gr, g[f"vol_gr_D{D}_G{G}"], **TOL)
+    # only one side needs a gradient
+    L, R = dev(g["L"], True), dev(g["R"], False)
+    (gl,) = torch.autograd.grad(S.build_gwc_volume(L, R, 12, 4), L, dev(g["vol_cot_D12_G4"]))
+    close(gl, g["vol_gl_D12_G4"], **TOL)
+
+
+def test_soft_argmin_backward_g11(S, golden):
+    g = golden("g11_backward")
+    for sim in (True, False):
+        v = dev(g["sa_vol"], True)
+        (gv,) = torch.autograd.grad(S.DisparityEstimation(12, sim)(v), v, dev(g["sa_cot_disp"]))
+        close(gv, g[f"sa_gvol_sim{int(sim)}"], **TOL)
+    v = dev(g["sa_vol"], True)
+    d, p = S.DisparityEstimationWithProb(12, True)(v)
+    (gv,) = torch.autograd.grad((d, p), v, (dev(g["sa_cot_disp"]), dev(g["sa_cot_prob"])))
+    close(gv, g["sa_gvol_withprob"], **TOL)
+
+
+def test_local_lookup_backward_g11(S, golden):
+    g = golden("g11_backward")
+    for (r, s) in ((2, 20), (4, 10)):
+        for cv in (False, True):
+            vol, disp = dev(g["ll_vol"], True), dev(g["ll_disp"], True)
+            gv, gd = torch.autograd.grad(S.LocalCostVolume(r, s)(vol, disp, cv), (vol, disp), dev(g["ll_cot"]))
+            close(gv, g[f"ll_gvol_r{r}_S{s}_cv{int(cv)}"], rtol=1e-4, atol=5e-5)
+            close(gd, g[f"ll_gdisp_r{r}_S{s}_cv{int(cv)}"], rtol=1e-4, atol=5e-5)
+
+
+def test_chain_trains_one_step(S):
+    """The cfg-2 correlation chain end to end under autograd: loss decreases after one SGD step on the features."""
+    torch.manual_seed(0)
+    B, C, H, W, D = 1, 8, 6, 64, 24
+    L = torch.randn(B, C, H, W, device="cuda", requires_grad=True)
+    R = torch.randn(B, C, H, W, device="cuda", requires_grad=True)
+    target = torch.full((B, H, W), 5.0, device="cuda")
+
+    def loss_fn():
+        vol = S.CostVolume(D)(L, R) * 8.0
+        disp = S.DisparityEstimation(D)(vol)
+        refined = S.LocalCostVolume(2, 10)(vol, disp.unsqueeze(1), False).squeeze(1)
+        return ((disp - target) ** 2).mean() + ((refined - target) ** 2).mean()
+
+    l0 = loss_fn()
+    gl, gr = torch.autograd.grad(l0, (L, R))
+    assert torch.isfinite(gl).all() and torch.isfinite(gr).all() and gl.abs().max() > 0
+    with torch.no_grad():
+        L -= 0.5 * gl
+        R -= 0.5 * gr
+    assert loss_fn().item() < l0.item()
+
+
+def test_group_mean_soft_argmin_backward(S):
+    """Fused reader's backward == autograd through (mean over groups -> DisparityEstimation) of the HIP ops."""
+    torch.manual_seed(2)
+    vg = (2.0 * torch.randn(2, 4, 16, 5, 40, device="cuda")).requires_grad_(True)
+    cd = torch.randn(2, 5, 40, device="cuda")
+    cm = torch.randn(2, 16, 5, 40, device="cuda")
+    d, m = S.group_mean_soft_argmin(vg, return_mean=True)
+    (g1,) = torch.autograd.grad((d, m), vg, (cd, cm))
+    vg2 = vg.detach().clone().requires_grad_(True)
+    mean = vg2.mean(1)
+    d2 = S.DisparityEstimation(16)(mean)
+    (g2,) = torch.autograd.grad((d2, mean), vg2, (cd, cm))
+    assert (g1 - g2).abs().max().item() < 2e-6
+
+
+def test_forward_only_ops_still_refuse_grad(S):
+    x = torch.randn(1, 4, 3, 8, device="cuda", requires_grad=True)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        S.CostVolume(2, "difference")(x, x)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        S.Variance_Based_Local_Cost_Volume(1, 5)(x, torch.rand(1, 1, 3, 8, device="cuda"))

@@ -404,7 +404,8 @@ def test_empty_and_degenerate_inputs(S):
     with pytest.raises(RuntimeError):
         S.upsample_convex8(torch.zeros(1, 1, 2, 2, device="cuda"), torch.zeros(1, 100, 2, 2, device="cuda"))
     with pytest.raises(RuntimeError, match="forward-only"):
-        S.CostVolume(2)(torch.randn(1, 2, 2, 4, device="cuda", requires_grad=True), torch.randn(1, 2, 2, 4, device="cuda"))
+        S.CostVolume(2, "concat")(torch.randn(1, 2, 2, 4, device="cuda", requires_grad=True),
+                                  torch.randn(1, 2, 2, 4, device="cuda"))
 
 
 def test_streams_and_determinism(S):

@@ -164,6 +164,37 @@ def main():
             flow = torch.randn(8, 2, Hr, Wr, device=dev)
             add("A14 one iteration B=8 @136x240", timeit(lambda: blk14(list(nets), inps, corr, flow), 3, 1), None,
                 8 * 168.0, bound="miopen", note="168 GFLOP/iter/pair of convs (MIOpen); informational")
+        if want("bwd"):
+            torch.set_grad_enabled(True)
+            Lg, Rg = L.detach().requires_grad_(True), R.detach().requires_grad_(True)
+            vol_g = S.CostVolume(D)(Lg, Rg)
+            cot = torch.randn_like(vol_g)
+            add("bwd A1 corr volume cfg-2 (dL + dR)",
+                timeit(lambda: torch.autograd.grad(vol_g, (Lg, Rg), cot, retain_graph=True), 5, 1),
+                (2 * N * D * 4 + 4 * N * C * 4) / 1e9, 2 * 2 * B * H * C * (D * W - D * (D - 1) / 2) / 1e9,
+                note="reads grad volume twice (dL, dR)")
+            del vol_g, cot
+            vd = S.CostVolume(D)(L, R).detach().requires_grad_(True)
+            dsp = S.DisparityEstimation(D)(vd)
+            cd = torch.randn_like(dsp)
+            add("bwd A4 soft-argmin cfg-2",
+                timeit(lambda: torch.autograd.grad(dsp, vd, cd, retain_graph=True), 5, 1), (2 * N * D * 4 + N * 4) / 1e9,
+                note="1 read + 1 write algorithmic (the second read is cache traffic)")
+            d1 = dsp.detach().unsqueeze(1).requires_grad_(True)
+            ref = S.LocalCostVolume(2, 20)(vd, d1, True)
+            co = torch.randn_like(ref)
+            add("bwd A5 local lookup cfg-2 (incl. zero-fill of grad volume)",
+                timeit(lambda: torch.autograd.grad(ref, (vd, d1), co, retain_graph=True), 5, 1), (N * D * 4 + 4 * N * 4) / 1e9)
+            del vd, dsp, ref
+            L1g, R1g = L[:2].detach().requires_grad_(True), R[:2].detach().requires_grad_(True)
+            vg = S.build_gwc_volume(L1g, R1g, D, G)
+            cg = torch.randn_like(vg)
+            n2 = 2 * H * W
+            add("bwd A3 gwc volume B=2 G=8 (dL + dR)",
+                timeit(lambda: torch.autograd.grad(vg, (L1g, R1g), cg, retain_graph=True), 3, 1),
+                (2 * n2 * G * D * 4 + 4 * n2 * C * 4) / 1e9)
+            del vg, cg
+            torch.set_grad_enabled(False)
         if want("loop_raft"):
             loop = S.RAFTStereoLoop([128, 128, 128]).eval().cuda()
             nets = [torch.tanh(torch.randn(8, 128, Hr >> i, Wr >> i, device=dev)) for i in range(3)]
