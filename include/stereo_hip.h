@@ -175,6 +175,12 @@ int stereo_local_lookup_bwd_f32(const float *vol, const float *disp, const float
                                 float *grad_vol_zeroed, float *grad_disp, int B, int D, int H, int W,
                                 float radius, int S, int consider_valid, void *stream);
 
+/* backward of A13 (upsample.py:22-38, raft_stereo.py:110-122), f in {4, 8}: grad_out [N,Cd,fH,fW] ->
+ * grad_disp [N,Cd,H,W] (MUST be zero-filled by the caller) and grad_mask [N,9*f*f,H,W] */
+int stereo_upsample_convex_bwd_f32(const float *disp, const float *mask, const float *grad_out,
+                                   float *grad_disp_zeroed, float *grad_mask, int N, int Cd, int H, int W,
+                                   int f, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -295,6 +295,120 @@ __global__ __launch_bounds__(256) void local_lookup_bwd_kernel(const float *__re
     }
 }
 
+// ------------------------------------------------------------------ convex upsampling backward (A13)
+// out[c, f*y+i, f*x+j] = sum_k p_k(i,j,y,x) * f * disp[c, y+k/3-1, x+k%3-1],  p = softmax_k(mask[k,i,j,y,x])
+//   d mask[k,i,j,y,x] = sum_c go_c * p_k * (f*nb_k,c - out_c)
+//   d disp[c, y', x'] = f * sum over the 9 coarse pixels (y,x) that see (y',x') as neighbour k, and all (i,j):
+//                       go[c, f*y+i, f*x+j] * p_k(i,j,y,x)
+// One workgroup = 64 coarse pixels of one coarse row: the f x 64f slab of the output gradient is staged in LDS
+// with W-contiguous loads, mask planes are read and mask gradients written with lanes along x, and the
+// per-pixel 3x3 neighbour contributions are combined in LDS before one float atomic per touched coarse pixel
+// (grad_disp must be zero-filled by the caller).
+template <int F, int CDT>
+__global__ __launch_bounds__(256) void upsample_convex_bwd_kernel(const float *__restrict__ disp,
+                                                                  const float *__restrict__ mask,
+                                                                  const float *__restrict__ gout,
+                                                                  float *__restrict__ gdisp, float *__restrict__ gmask,
+                                                                  int Cd, int H, int W)
+{
+    constexpr int F2 = F * F, XT = 64;
+    __shared__ float nb[CDT][3][XT + 2];
+    __shared__ float gt[CDT][F][XT * F + 4];   // output-gradient slab
+    __shared__ float dacc[CDT][3][XT + 2];     // d disp contributions of this workgroup
+    const int x0 = blockIdx.x * XT, y = blockIdx.y, n = blockIdx.z;
+    const int tid = threadIdx.x;
+    const size_t HW = (size_t)H * W;
+    const int xl = tid % XT, sub0 = tid / XT;
+    const int x = x0 + xl;
+    const int rowlen = ((W - x0) < XT ? (W - x0) : XT) * F;
+
+    for (int c0 = 0; c0 < Cd; c0 += CDT) {
+        const int nc = (Cd - c0) < CDT ? (Cd - c0) : CDT;
+        __syncthreads();
+        for (int idx = tid; idx < nc * 3 * (XT + 2); idx += 256) {
+            const int c = idx / (3 * (XT + 2)), rem = idx - c * 3 * (XT + 2);
+            const int r = rem / (XT + 2), xx = x0 - 1 + (rem - r * (XT + 2)), yy = y - 1 + r;
+            nb[c][r][rem - r * (XT + 2)] = (yy >= 0 && yy < H && xx >= 0 && xx < W)
+                                               ? (float)F * disp[((size_t)n * Cd + c0 + c) * HW + (size_t)yy * W + xx]
+                                               : 0.0f;
+            dacc[c][r][rem - r * (XT + 2)] = 0.0f;
+        }
+        for (int c = 0; c < nc; ++c) {
+            const float *gp = gout + (((size_t)n * Cd + c0 + c) * (size_t)(F * H) + (size_t)F * y) * (size_t)(F * W) +
+                              (size_t)F * x0;
+            for (int idx = tid; idx < F * (XT * F); idx += 256) {
+                const int i = idx / (XT * F), col = idx - i * (XT * F);
+                gt[c][i][col] = (col < rowlen) ? gp[(size_t)i * (F * W) + col] : 0.0f;
+            }
+        }
+        __syncthreads();
+        float dn[CDT][9];  // this lane's neighbour contributions, summed over its (i,j) sub-positions
+#pragma unroll
+        for (int c = 0; c < CDT; ++c)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) dn[c][k] = 0.0f;
+        for (int ij = sub0; ij < F2; ij += 256 / XT) {
+            const int i = ij / F, j = ij - i * F;
+            float p[9], gm[9];
+            if (x < W) {
+                float mx = -INFINITY, sum = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    p[k] = mask[((size_t)n * 9 * F2 + (size_t)(k * F2 + ij)) * HW + (size_t)y * W + x];
+                    mx = fmaxf(mx, p[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    p[k] = fast_exp(p[k] - mx);
+                    sum += p[k];
+                }
+                const float inv = 1.0f / sum;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) p[k] *= inv, gm[k] = 0.0f;
+#pragma unroll
+                for (int c = 0; c < CDT; ++c) {
+                    if (c < nc) {
+                        const float go = gt[c][i][xl * F + j];
+                        float outc = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) outc = fmaf(p[k], nb[c][k / 3][xl + k % 3], outc);
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) {
+                            gm[k] = fmaf(go * p[k], nb[c][k / 3][xl + k % 3] - outc, gm[k]);
+                            dn[c][k] = fmaf(go, p[k], dn[c][k]);
+                        }
+                    }
+                }
+                if (c0 == 0) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k)
+                        gmask[((size_t)n * 9 * F2 + (size_t)(k * F2 + ij)) * HW + (size_t)y * W + x] = gm[k];
+                } else {  // later channel blocks accumulate (Cd > CDT only)
+#pragma unroll
+                    for (int k = 0; k < 9; ++k)
+                        gmask[((size_t)n * 9 * F2 + (size_t)(k * F2 + ij)) * HW + (size_t)y * W + x] += gm[k];
+                }
+            }
+        }
+        if (x < W) {
+#pragma unroll
+            for (int c = 0; c < CDT; ++c)
+                if (c < nc) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) atomicAdd(&dacc[c][k / 3][xl + k % 3], (float)F * dn[c][k]);
+                }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < nc * 3 * (XT + 2); idx += 256) {
+            const int c = idx / (3 * (XT + 2)), rem = idx - c * 3 * (XT + 2);
+            const int r = rem / (XT + 2), xx = x0 - 1 + (rem - r * (XT + 2)), yy = y - 1 + r;
+            const float v = dacc[c][r][rem - r * (XT + 2)];
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W && v != 0.0f)
+                atomicAdd(gdisp + ((size_t)n * Cd + c0 + c) * HW + (size_t)yy * W + xx, v);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int stereo_soft_argmin_bwd_f32(const float *vol, const float *grad_disp, const float *grad_prob,
@@ -384,6 +498,38 @@ extern "C" int stereo_local_lookup_bwd_f32(const float *vol, const float *disp, 
     const long long HW = (long long)H * W, n = (long long)B * HW;
     hipLaunchKernelGGL(local_lookup_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), vol, disp, grad_out,
                        grad_vol_zeroed, grad_disp, D, HW, n, radius, S, consider_valid);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+extern "C" int stereo_upsample_convex_bwd_f32(const float *disp, const float *mask, const float *grad_out,
+                                              float *grad_disp_zeroed, float *grad_mask, int N, int Cd, int H, int W,
+                                              int f, void *stream)
+{
+    if (N < 0 || Cd < 0 || H < 0 || W < 0 || f <= 0) return STEREO_ERR_BAD_SHAPE;
+    if (N == 0 || Cd == 0 || H == 0 || W == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(disp);
+    STEREO_REQUIRE_PTR(mask);
+    STEREO_REQUIRE_PTR(grad_out);
+    STEREO_REQUIRE_PTR(grad_disp_zeroed);
+    STEREO_REQUIRE_PTR(grad_mask);
+    if (!fits_grid_yz(H) || !fits_grid_yz(N)) return STEREO_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    dim3 grid((W + 63) / 64, H, N);
+    if (f == 8 && Cd == 1)
+        hipLaunchKernelGGL((upsample_convex_bwd_kernel<8, 1>), grid, dim3(256), 0, st, disp, mask, grad_out,
+                           grad_disp_zeroed, grad_mask, Cd, H, W);
+    else if (f == 8)
+        hipLaunchKernelGGL((upsample_convex_bwd_kernel<8, 2>), grid, dim3(256), 0, st, disp, mask, grad_out,
+                           grad_disp_zeroed, grad_mask, Cd, H, W);
+    else if (f == 4 && Cd == 1)
+        hipLaunchKernelGGL((upsample_convex_bwd_kernel<4, 1>), grid, dim3(256), 0, st, disp, mask, grad_out,
+                           grad_disp_zeroed, grad_mask, Cd, H, W);
+    else if (f == 4)
+        hipLaunchKernelGGL((upsample_convex_bwd_kernel<4, 2>), grid, dim3(256), 0, st, disp, mask, grad_out,
+                           grad_disp_zeroed, grad_mask, Cd, H, W);
+    else
+        return STEREO_ERR_UNSUPPORTED;  // backward is built for the factors the reference uses (8 and 4)
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }

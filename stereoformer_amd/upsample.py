@@ -23,8 +23,35 @@ class ConvAffinityUpsample(nn.Module):
         return .25 * self.upsample_mask(feature)
 
 
+class _UpsampleConvexFn(torch.autograd.Function):
+    """Differentiable convex upsampling (factors 4 and 8): HIP forward + HIP backward."""
+
+    @staticmethod
+    def forward(ctx, disp, mask, factor):
+        out = upsample_convex(disp, mask, factor)
+        ctx.save_for_backward(disp, mask)
+        ctx.factor = int(factor)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        disp, mask = ctx.saved_tensors
+        n, cd, h, w = disp.shape
+        go = N.dev_f32(grad_out, "upsample_convex backward: grad")
+        gdisp = torch.zeros_like(disp)       # neighbour contributions are accumulated into it
+        gmask = torch.empty_like(mask)
+        with torch.cuda.device(disp.device):
+            N.call("stereo_upsample_convex_bwd_f32", N.ptr(disp), N.ptr(mask), N.ptr(go), N.ptr(gdisp), N.ptr(gmask), n,
+                   cd, h, w, ctx.factor, N.stream_ptr(disp.device))
+        return gdisp, gmask, None
+
+
 def upsample_convex(disp, mask, factor):
     """Convex-combination upsampling by ``factor``: disp [N,Cd,H,W], mask [N,9*f*f,H,W]."""
+    if torch.is_grad_enabled() and (disp.requires_grad or mask.requires_grad):
+        if factor not in (4, 8):
+            raise RuntimeError("upsample_convex: backward is built for factors 4 and 8 only")
+        return _UpsampleConvexFn.apply(disp.contiguous(), mask.contiguous(), int(factor))
     disp = N.dev_f32(disp, "upsample_convex: disp")
     mask = N.dev_f32(mask, "upsample_convex: mask")
     n, cd, h, w = disp.shape

@@ -399,6 +399,27 @@ def g11_backward():
             for cv in (False, True):
                 gvv, gdd = torch.autograd.grad(LocalCostVolume(r, S)(vol, disp, cv), (vol, disp), co)
                 out[f"ll_gvol_r{r}_S{S}_cv{int(cv)}"], out[f"ll_gdisp_r{r}_S{S}_cv{int(cv)}"] = npy(gvv), npy(gdd)
+        # convex upsampling (A13): f=8 single channel and the RAFT flavour f=4 with two flow channels
+        from models.utils.upsample import upsample_convex8
+        d8 = (torch.rand(1, 1, 3, 70) * 20).requires_grad_(True)
+        m8 = torch.randn(1, 576, 3, 70, requires_grad=True)
+        up = upsample_convex8(d8, m8)
+        cu = torch.randn_like(up)
+        g_d8, g_m8 = torch.autograd.grad(up, (d8, m8), cu)
+        out["up8_disp"], out["up8_mask"], out["up8_cot"] = npy(d8), npy(m8), npy(cu)
+        out["up8_gdisp"], out["up8_gmask_sub"] = npy(g_d8), npy(g_m8[:, ::31])
+        import types
+        t = types.ModuleType("turtle"); t.left = t.right = None; sys.modules["turtle"] = t
+        sys.argv = ["x"]
+        with contextlib.redirect_stdout(io.StringIO()):
+            from models.IterativeLocalCostVolume.raft_stereo import RAFT_Stereo
+        fl = torch.randn(1, 2, 6, 9, requires_grad=True)
+        m4 = torch.randn(1, 144, 6, 9, requires_grad=True)
+        up4 = RAFT_Stereo.upsample_flow(types.SimpleNamespace(downsample=2), fl, m4)
+        c4 = torch.randn_like(up4)
+        g_fl, g_m4 = torch.autograd.grad(up4, (fl, m4), c4)
+        out["up4_flow"], out["up4_mask"], out["up4_cot"] = npy(fl), npy(m4), npy(c4)
+        out["up4_gflow"], out["up4_gmask"] = npy(g_fl), npy(g_m4)
     save("g11_backward", **out)
 
 

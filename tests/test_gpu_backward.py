@@ -60,6 +60,46 @@ def test_local_lookup_backward_g11(S, golden):
             close(gd, g[f"ll_gdisp_r{r}_S{s}_cv{int(cv)}"], rtol=1e-4, atol=5e-5)
 
 
+def test_upsample_convex_backward_g11(S, golden):
+    g = golden("g11_backward")
+    d8, m8 = dev(g["up8_disp"], True), dev(g["up8_mask"], True)
+    gd, gm = torch.autograd.grad(S.upsample_convex8(d8, m8), (d8, m8), dev(g["up8_cot"]))
+    close(gd, g["up8_gdisp"], rtol=1e-4, atol=5e-5)
+    close(gm[:, ::31], g["up8_gmask_sub"], rtol=1e-4, atol=5e-5)
+    fl, m4 = dev(g["up4_flow"], True), dev(g["up4_mask"], True)
+    gf, gm4 = torch.autograd.grad(S.upsample_flow(fl, m4, 2), (fl, m4), dev(g["up4_cot"]))
+    close(gf, g["up4_gflow"], rtol=1e-4, atol=5e-5)
+    close(gm4, g["up4_gmask"], rtol=1e-4, atol=5e-5)
+
+
+def test_lowcnn_style_head_trains(S):
+    """The reference's fixed-radius LowCNN head (baseline.py:114-135: CostVolume -> aggregation convs ->
+    DisparityEstimation -> LocalCostVolume -> ConvAffinityUpsample -> upsample_convex8) trains end to end on
+    the HIP path: every custom op on it has a HIP backward."""
+    torch.manual_seed(0)
+    B, C, h, w, D = 1, 16, 8, 16, 24
+    fl = torch.randn(B, C, h, w, device="cuda")
+    fr = torch.randn(B, C, h, w, device="cuda")
+    agg = torch.nn.Conv2d(D, D, 3, padding=1).cuda()
+    up = S.ConvAffinityUpsample(C, 32).cuda()
+    params = list(agg.parameters()) + list(up.parameters())
+    opt = torch.optim.SGD(params, lr=1e-2)
+    gt = torch.full((B, 1, 8 * h, 8 * w), 40.0, device="cuda")
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        cost = agg(S.CostVolume(D)(fl, fr) * 4.0)
+        disp = S.DisparityEstimation(D)(cost).unsqueeze(1)
+        disp = S.LocalCostVolume(2, 10)(cost, disp, True)
+        pred = S.upsample_convex8(disp, up(fl))
+        loss = (pred - gt).abs().mean()
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]
+
+
 def test_chain_trains_one_step(S):
     """The cfg-2 correlation chain end to end under autograd: loss decreases after one SGD step on the features."""
     torch.manual_seed(0)
