@@ -181,6 +181,23 @@ int stereo_upsample_convex_bwd_f32(const float *disp, const float *mask, const f
                                    float *grad_disp_zeroed, float *grad_mask, int N, int Cd, int H, int W,
                                    int f, void *stream);
 
+/* backward of the A11 / A14 pointwise pieces (Attempts/update.py:41-48,71-86,279-313; update/update.py:28-32;
+ * utils/disparity_warper.py:83-106).  The bias cotangents equal the pre-activation cotangents. */
+int stereo_gru_reset_bwd_f32(const float *h, const float *rc, const float *cr, const float *grad_out,
+                             float *grad_h, float *grad_rc, long long n, void *stream);
+int stereo_gru_blend_bwd_f32(const float *h, const float *zc, const float *qc, const float *cz, const float *cq,
+                             const float *grad_out, float *grad_h, float *grad_zc, float *grad_qc, long long n,
+                             int softsign, void *stream);
+int stereo_uncertainty_volume_bwd_f32(const float *vol, const float *disp, const float *grad_u,
+                                      float *grad_vol, float *grad_disp, int B, int D, int H, int W, void *stream);
+/* gradient of the warped image w.r.t. the disparity only (the image is an input of the model) */
+int stereo_disp_warp_bwd_disp_f32(const float *img, const float *disp, const float *grad_warped,
+                                  float *grad_disp, int B, int Ci, int H, int W, int padding_border, void *stream);
+/* grad_vol must be zero-filled; grad_bounds [B,2,H,W] */
+int stereo_bounds_lookup_bwd_f32(const float *vol, const float *disp, const float *bounds, const float *grad_out,
+                                 float *grad_vol_zeroed, float *grad_disp, float *grad_bounds,
+                                 int B, int D, int H, int W, int S, int consider_valid, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

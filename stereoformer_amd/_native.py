@@ -50,6 +50,11 @@ SIGNATURES = {
     "stereo_gwc_volume_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_local_lookup_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
     "stereo_upsample_convex_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "stereo_gru_reset_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp],
+    "stereo_gru_blend_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp],
+    "stereo_uncertainty_volume_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "stereo_disp_warp_bwd_disp_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "stereo_bounds_lookup_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_gru_reset_f32": [_vp, _vp, _vp, _vp, _ll, _vp],
     "stereo_gru_blend_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp],
 }

@@ -409,6 +409,216 @@ __global__ __launch_bounds__(256) void upsample_convex_bwd_kernel(const float *_
     }
 }
 
+// ------------------------------------------------------------------ GRU gate math backward
+// reset: out = sigmoid(rc + cr) * h        -> gh = g*r ; grc = g*h*r*(1-r)            (gcr == grc)
+// blend: out = (1-z)*h + z*q, z = sigmoid(zc+cz), q = act(qc+cq)
+//        -> gh = g*(1-z) ; gzc = g*(q-h)*z*(1-z) ; gqc = g*z*act'(.)                   (gcz == gzc, gcq == gqc)
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void gru_reset_bwd_kernel(const float *__restrict__ h, const float *__restrict__ rc,
+                                                            const float *__restrict__ cr, const float *__restrict__ g,
+                                                            float *__restrict__ gh, float *__restrict__ grc, long long n)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const float r = sigm(rc[t] + (cr ? cr[t] : 0.0f));
+        gh[t] = g[t] * r;
+        grc[t] = g[t] * h[t] * r * (1.0f - r);
+    }
+}
+
+__global__ __launch_bounds__(256) void gru_blend_bwd_kernel(const float *__restrict__ h, const float *__restrict__ zc,
+                                                            const float *__restrict__ qc, const float *__restrict__ cz,
+                                                            const float *__restrict__ cq, const float *__restrict__ g,
+                                                            float *__restrict__ gh, float *__restrict__ gzc,
+                                                            float *__restrict__ gqc, long long n, int softsign)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const float z = sigm(zc[t] + (cz ? cz[t] : 0.0f));
+        const float qx = qc[t] + (cq ? cq[t] : 0.0f);
+        float q, dq;
+        if (softsign) {
+            const float den = 1.0f + fabsf(qx);
+            q = qx / den;
+            dq = 1.0f / (den * den);
+        } else {
+            q = tanhf(qx);
+            dq = 1.0f - q * q;
+        }
+        gh[t] = g[t] * (1.0f - z);
+        gzc[t] = g[t] * (q - h[t]) * z * (1.0f - z);
+        gqc[t] = g[t] * z * dq;
+    }
+}
+
+// ------------------------------------------------------------------ uncertainty volume backward (A11)
+// U_d = p_d * d * (d - disp)^2, p = softmax(vol).  With a_d = gU_d * d * (d - disp)^2:
+//   gvol_k = p_k * (a_k - sum_d p_d a_d) ;  gdisp = -2 * sum_d gU_d * p_d * d * (d - disp)
+__global__ __launch_bounds__(256) void uncertainty_bwd_kernel(const float *__restrict__ vol,
+                                                              const float *__restrict__ disp,
+                                                              const float *__restrict__ gU, float *__restrict__ gvol,
+                                                              float *__restrict__ gdisp, int D, long long HW,
+                                                              long long npix)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npix;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long b = t / HW, p = t - b * HW;
+        const float *v = vol + (size_t)b * D * HW + p;
+        const float *gu = gU + (size_t)b * D * HW + p;
+        float *gv = gvol + (size_t)b * D * HW + p;
+        const float cur = disp[t];
+        float m = -INFINITY, s = 0.0f, sa = 0.0f, sd = 0.0f;
+        for (int d = 0; d < D; ++d) {
+            const float x = v[(size_t)d * HW];
+            const float e = (float)d - cur;
+            const float a = gu[(size_t)d * HW] * (float)d * e * e;
+            const float cm = fmaxf(m, x);
+            const float sc = (m == cm) ? 1.0f : fast_exp(m - cm);
+            const float pe = fast_exp(x - cm);
+            s = s * sc + pe;
+            sa = sa * sc + pe * a;
+            sd = sd * sc + pe * gu[(size_t)d * HW] * (float)d * e;
+            m = cm;
+        }
+        const float inv = 1.0f / s, mean_a = sa * inv;
+        for (int d = 0; d < D; ++d) {
+            const float e = (float)d - cur;
+            const float a = gu[(size_t)d * HW] * (float)d * e * e;
+            gv[(size_t)d * HW] = fast_exp(v[(size_t)d * HW] - m) * inv * (a - mean_a);
+        }
+        gdisp[t] = -2.0f * sd * inv;
+    }
+}
+
+// ------------------------------------------------------------------ disp_warp backward w.r.t. disp (A12)
+// warped[c] = bilinear(img[c]; sx, sy), sx = clip(ux), ux = (x - disp) * W/(W-1) - 0.5  (align_corners=False
+// un-normalisation of a grid normalised with (W-1), disparity_warper.py:55-56,100).
+//   d warped[c] / d disp = -(W/(W-1)) * [ux not clipped] * d bilinear / d sx
+// (grid_sample zeroes the coordinate gradient where border clipping is active).
+__global__ __launch_bounds__(256) void disp_warp_bwd_kernel(const float *__restrict__ img, const float *__restrict__ disp,
+                                                            const float *__restrict__ gw, float *__restrict__ gdisp,
+                                                            int Ci, int H, int W, long long npix, int padding_border)
+{
+    const long long HW = (long long)H * W;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npix;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long b = t / HW, p = t - b * HW;
+        const int y = (int)(p / W), x = (int)(p - (long long)y * W);
+        const float gx = (float)x + (-disp[t]);
+        const float nx = __fsub_rn(__fmul_rn(2.0f, __fdiv_rn(gx, (float)(W - 1))), 1.0f);
+        const float ny = __fsub_rn(__fmul_rn(2.0f, __fdiv_rn((float)y, (float)(H - 1))), 1.0f);
+        float sx = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(nx, 1.0f), (float)W), 1.0f), 2.0f);
+        float sy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(ny, 1.0f), (float)H), 1.0f), 2.0f);
+        float live = 1.0f;
+        if (padding_border) {
+            if (sx <= 0.0f || sx >= (float)(W - 1)) live = 0.0f;  // clip_coordinates_set_grad: zero outside (0, W-1)
+            sx = clampf(sx, 0.0f, (float)(W - 1));
+            sy = clampf(sy, 0.0f, (float)(H - 1));
+        }
+        const float fx = floorf(sx), fy = floorf(sy);
+        const float ay = sy - fy;
+        const int ix = (int)fx, iy = (int)fy;
+        const bool x0 = ix >= 0 && ix <= W - 1, x1 = ix + 1 >= 0 && ix + 1 <= W - 1;
+        const bool y0 = iy >= 0 && iy <= H - 1, y1 = iy + 1 >= 0 && iy + 1 <= H - 1;
+        float acc = 0.0f;
+        for (int c = 0; c < Ci; ++c) {
+            const float *im = img + ((size_t)b * Ci + c) * HW;
+            const float v00 = (y0 && x0) ? im[(size_t)iy * W + ix] : 0.0f;
+            const float v01 = (y0 && x1) ? im[(size_t)iy * W + ix + 1] : 0.0f;
+            const float v10 = (y1 && x0) ? im[(size_t)(iy + 1) * W + ix] : 0.0f;
+            const float v11 = (y1 && x1) ? im[(size_t)(iy + 1) * W + ix + 1] : 0.0f;
+            const float dsdx = (v01 - v00) * (1.0f - ay) + (v11 - v10) * ay;
+            acc = fmaf(gw[((size_t)b * Ci + c) * HW + p], dsdx, acc);
+        }
+        // d ux / d disp = -(2/(W-1)) * (W/2)
+        gdisp[t] = -acc * live * ((float)W / (float)(W - 1));
+    }
+}
+
+// ------------------------------------------------------------------ learned-bounds lookup backward (A11 sampler)
+// lower = cur - b0, upper = cur + b1, c_k = lower + k*(upper-lower)/S  (update.py:279-313), then as A5.
+//   d c_k / d cur = 1 ; d c_k / d b0 = -(1 - k/S) ; d c_k / d b1 = k/S   (valid pixels, consider_valid)
+//   invalid pixels: c_k = cur -> only d/d cur = 1.  consider_valid = 0: clamps cut the respective paths.
+__global__ __launch_bounds__(256) void bounds_lookup_bwd_kernel(const float *__restrict__ vol,
+                                                                const float *__restrict__ disp,
+                                                                const float *__restrict__ bounds,
+                                                                const float *__restrict__ gout, float *__restrict__ gvol,
+                                                                float *__restrict__ gdisp, float *__restrict__ gbounds,
+                                                                int D, long long HW, long long npix, int S,
+                                                                int consider_valid)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npix;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long b = t / HW, p = t - b * HW;
+        const float *v = vol + (size_t)b * D * HW + p;
+        float *gvp = gvol + (size_t)b * D * HW + p;
+        const float cur = disp[t], g = gout[t];
+        float lower = cur - bounds[(size_t)b * 2 * HW + p], upper = cur + bounds[(size_t)b * 2 * HW + HW + p];
+        int invalid = -1;
+        float dl = 1.0f, du = 1.0f;  // are lower / upper still functions of their inputs?
+        if (consider_valid) {
+            invalid = (lower < 0.0f) || (upper >= (float)(D - 1));
+        } else {
+            if (lower < 0.0f) lower = 0.0f, dl = 0.0f;
+            if (upper < 0.0f) upper = 0.0f, du = 0.0f;
+            else if (upper > (float)D) upper = (float)D, du = 0.0f;
+        }
+        const float interval = __fdiv_rn(__fmul_rn(__fsub_rn(upper, lower), 1.0f), (float)S);
+        const float inv = invalid > 0 ? 1.0f : 0.0f;
+        float m = -INFINITY, s = 0.0f, e = 0.0f;
+        for (int k = 0; k <= S; ++k) {
+            float c = __fadd_rn(lower, __fmul_rn((float)k, interval));
+            if (invalid >= 0) c = __fadd_rn(__fmul_rn(c, 1.0f - inv), __fmul_rn(inv, cur));
+            const float val = sample_tap(v, (size_t)HW, D, c);
+            const float cm = fmaxf(m, val);
+            const float sc = (m == cm) ? 1.0f : fast_exp(m - cm);
+            const float pe = fast_exp(val - cm);
+            s = s * sc + pe;
+            e = e * sc + pe * c;
+            m = cm;
+        }
+        const float out = e / s, invs = 1.0f / s;
+        float gd = 0.0f, gb0 = 0.0f, gb1 = 0.0f;
+        int pend_idx = -1;
+        float pend_val = 0.0f;
+        auto push = [&](int idx, float val) {
+            if (idx == pend_idx) {
+                pend_val += val;
+            } else {
+                if (pend_idx >= 0) gvp[(size_t)pend_idx * HW] += pend_val;
+                pend_idx = idx;
+                pend_val = val;
+            }
+        };
+        for (int k = 0; k <= S; ++k) {
+            float c = __fadd_rn(lower, __fmul_rn((float)k, interval));
+            if (invalid >= 0) c = __fadd_rn(__fmul_rn(c, 1.0f - inv), __fmul_rn(inv, cur));
+            const float cc = clampf(ste_ceil_f(c), 0.0f, (float)(D - 1));
+            const float cf = clampf(ste_floor_f(c), 0.0f, (float)(D - 1));
+            const int ic = (int)cc, ifl = (int)cf;
+            const float fr = (float)ic - c, cr = 1.0f - fr;
+            const float vf = v[(size_t)ifl * HW], vc = v[(size_t)ic * HW];
+            const float pk = fast_exp(vf * fr + vc * cr - m) * invs;
+            const float a = g * pk * (c - out);
+            push(ifl, a * fr);
+            push(ic, a * cr);
+            const float dc = g * pk + a * (vc - vf);
+            const float tk = (float)k / (float)S;
+            if (invalid > 0) {
+                gd += dc;                               // c_k = cur
+            } else {
+                const float wl = (1.0f - tk) * dl, wu = tk * du;   // c_k = (1-tk)*lower + tk*upper
+                gd = fmaf(dc, wl + wu, gd);
+                gb0 = fmaf(-dc, wl, gb0);
+                gb1 = fmaf(dc, wu, gb1);
+            }
+        }
+        if (pend_idx >= 0) gvp[(size_t)pend_idx * HW] += pend_val;
+        gdisp[t] = gd;
+        gbounds[(size_t)b * 2 * HW + p] = gb0;
+        gbounds[(size_t)b * 2 * HW + HW + p] = gb1;
+    }
+}
+
 }  // namespace
 
 extern "C" int stereo_soft_argmin_bwd_f32(const float *vol, const float *grad_disp, const float *grad_prob,
@@ -530,6 +740,98 @@ extern "C" int stereo_upsample_convex_bwd_f32(const float *disp, const float *ma
                            grad_disp_zeroed, grad_mask, Cd, H, W);
     else
         return STEREO_ERR_UNSUPPORTED;  // backward is built for the factors the reference uses (8 and 4)
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+extern "C" int stereo_gru_reset_bwd_f32(const float *h, const float *rc, const float *cr, const float *grad_out,
+                                        float *grad_h, float *grad_rc, long long n, void *stream)
+{
+    if (n < 0) return STEREO_ERR_BAD_SHAPE;
+    if (n == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(h);
+    STEREO_REQUIRE_PTR(rc);
+    STEREO_REQUIRE_PTR(grad_out);
+    STEREO_REQUIRE_PTR(grad_h);
+    STEREO_REQUIRE_PTR(grad_rc);
+    hipLaunchKernelGGL(gru_reset_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), h, rc, cr, grad_out,
+                       grad_h, grad_rc, n);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+extern "C" int stereo_gru_blend_bwd_f32(const float *h, const float *zc, const float *qc, const float *cz,
+                                        const float *cq, const float *grad_out, float *grad_h, float *grad_zc,
+                                        float *grad_qc, long long n, int softsign, void *stream)
+{
+    if (n < 0) return STEREO_ERR_BAD_SHAPE;
+    if (n == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(h);
+    STEREO_REQUIRE_PTR(zc);
+    STEREO_REQUIRE_PTR(qc);
+    STEREO_REQUIRE_PTR(grad_out);
+    STEREO_REQUIRE_PTR(grad_h);
+    STEREO_REQUIRE_PTR(grad_zc);
+    STEREO_REQUIRE_PTR(grad_qc);
+    hipLaunchKernelGGL(gru_blend_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), h, zc, qc, cz, cq,
+                       grad_out, grad_h, grad_zc, grad_qc, n, softsign);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+extern "C" int stereo_uncertainty_volume_bwd_f32(const float *vol, const float *disp, const float *grad_u,
+                                                 float *grad_vol, float *grad_disp, int B, int D, int H, int W,
+                                                 void *stream)
+{
+    if (B < 0 || D < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0 || D == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(vol);
+    STEREO_REQUIRE_PTR(disp);
+    STEREO_REQUIRE_PTR(grad_u);
+    STEREO_REQUIRE_PTR(grad_vol);
+    STEREO_REQUIRE_PTR(grad_disp);
+    const long long HW = (long long)H * W, n = (long long)B * HW;
+    hipLaunchKernelGGL(uncertainty_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), vol, disp, grad_u,
+                       grad_vol, grad_disp, D, HW, n);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+extern "C" int stereo_disp_warp_bwd_disp_f32(const float *img, const float *disp, const float *grad_warped,
+                                             float *grad_disp, int B, int Ci, int H, int W, int padding_border,
+                                             void *stream)
+{
+    if (B < 0 || Ci < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(img);
+    STEREO_REQUIRE_PTR(disp);
+    STEREO_REQUIRE_PTR(grad_warped);
+    STEREO_REQUIRE_PTR(grad_disp);
+    const long long n = (long long)B * H * W;
+    hipLaunchKernelGGL(disp_warp_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), img, disp, grad_warped,
+                       grad_disp, Ci, H, W, n, padding_border);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+extern "C" int stereo_bounds_lookup_bwd_f32(const float *vol, const float *disp, const float *bounds,
+                                            const float *grad_out, float *grad_vol_zeroed, float *grad_disp,
+                                            float *grad_bounds, int B, int D, int H, int W, int S, int consider_valid,
+                                            void *stream)
+{
+    if (B < 0 || D < 0 || H < 0 || W < 0 || S <= 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0) return STEREO_OK;
+    if (D == 0) return STEREO_ERR_BAD_SHAPE;
+    STEREO_REQUIRE_PTR(vol);
+    STEREO_REQUIRE_PTR(disp);
+    STEREO_REQUIRE_PTR(bounds);
+    STEREO_REQUIRE_PTR(grad_out);
+    STEREO_REQUIRE_PTR(grad_vol_zeroed);
+    STEREO_REQUIRE_PTR(grad_disp);
+    STEREO_REQUIRE_PTR(grad_bounds);
+    const long long HW = (long long)H * W, n = (long long)B * HW;
+    hipLaunchKernelGGL(bounds_lookup_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), vol, disp, bounds,
+                       grad_out, grad_vol_zeroed, grad_disp, grad_bounds, D, HW, n, S, consider_valid);
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }

@@ -106,9 +106,50 @@ def build_cost_volume_from_volume(old_volume, sampling_candidates):
     return out
 
 
+class _BoundsLookupFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vol, disp, bounds, sample_points, consider_valid):
+        ctx.save_for_backward(vol, disp, bounds)
+        ctx.cfg = (int(sample_points), bool(consider_valid))
+        return bounds_lookup(vol, disp, bounds, sample_points, consider_valid)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        vol, disp, bounds = ctx.saved_tensors
+        S, cv = ctx.cfg
+        B, D, H, W = vol.shape
+        go = N.dev_f32(grad_out, "bounds_lookup backward: grad")
+        gvol, gdisp, gb = torch.zeros_like(vol), torch.empty_like(disp), torch.empty_like(bounds)
+        with torch.cuda.device(vol.device):
+            N.call("stereo_bounds_lookup_bwd_f32", N.ptr(vol), N.ptr(disp), N.ptr(bounds), N.ptr(go), N.ptr(gvol),
+                   N.ptr(gdisp), N.ptr(gb), B, D, H, W, S, 1 if cv else 0, N.stream_ptr(vol.device))
+        return gvol, gdisp, gb, None, None
+
+
+class _UncertaintyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vol, disp):
+        ctx.save_for_backward(vol, disp)
+        return uncertainty_volume(vol, disp)
+
+    @staticmethod
+    def backward(ctx, grad_u):
+        vol, disp = ctx.saved_tensors
+        B, D, H, W = vol.shape
+        gu = N.dev_f32(grad_u, "uncertainty_volume backward: grad")
+        gvol, gdisp = torch.empty_like(vol), torch.empty_like(disp)
+        with torch.cuda.device(vol.device):
+            N.call("stereo_uncertainty_volume_bwd_f32", N.ptr(vol), N.ptr(disp), N.ptr(gu), N.ptr(gvol), N.ptr(gdisp), B,
+                   D, H, W, N.stream_ptr(vol.device))
+        return gvol, gdisp
+
+
 def bounds_lookup(old_cost_volume, cur_disp, bounds, sample_points, consider_valid=True):
     """The A11 sampler (``Attempts/update.py:279-313``): ``bounds`` [B,2,H,W] are the
     non-negative (lower, upper) offsets predicted by OffsetPredictionHead."""
+    if torch.is_grad_enabled() and (old_cost_volume.requires_grad or cur_disp.requires_grad or bounds.requires_grad):
+        return _BoundsLookupFn.apply(old_cost_volume.contiguous(), cur_disp.contiguous(), bounds.contiguous(),
+                                     int(sample_points), bool(consider_valid))
     vol, disp = _vol_disp(old_cost_volume, cur_disp, "bounds_lookup")
     bounds = N.dev_f32(bounds, "bounds_lookup: bounds")
     B, D, H, W = vol.shape
@@ -123,6 +164,8 @@ def bounds_lookup(old_cost_volume, cur_disp, bounds, sample_points, consider_val
 
 def uncertainty_volume(old_cost_volume, cur_disp):
     """``softmax(vol,1) * d * (d-disp)^2`` (``Attempts/update.py:71-72,86``) in one kernel."""
+    if torch.is_grad_enabled() and (old_cost_volume.requires_grad or cur_disp.requires_grad):
+        return _UncertaintyFn.apply(old_cost_volume.contiguous(), cur_disp.contiguous())
     vol, disp = _vol_disp(old_cost_volume, cur_disp, "uncertainty_volume")
     B, D, H, W = vol.shape
     out = torch.empty_like(vol)

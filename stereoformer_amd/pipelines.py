@@ -132,13 +132,16 @@ class LowCNNGRULoop(nn.Module):
                                                  sample_points=sample_points)
         self._graphs = _GraphCache()
 
-    @torch.no_grad()
     def forward(self, cost_volume, disp, left_image, right_image, iters=12, use_graph=False):
         """cost_volume [B,D,h,w] (1/8 scale), disp [B,1,h,w] -> list of full-resolution disparities
-        (one per iteration, like the reference), or only the last one when ``use_graph``."""
+        (one per iteration, like the reference), or only the last one when ``use_graph``.  Differentiable
+        in grad mode (every custom op on the path has a HIP backward); the graph replay is inference-only."""
         B, D, h, w = cost_volume.shape
         hidden = torch.zeros(B, 2 * self.update.hidden_dim, h, w, device=cost_volume.device)
         if use_graph:
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                raise RuntimeError("LowCNNGRULoop: use_graph=True is an inference path; call it under torch.no_grad()")
+
             def fn(ts):
                 d, hid = ts[1], torch.zeros_like(hidden)
                 for _ in range(iters):

@@ -5,7 +5,8 @@ The 3x3 convolutions / BatchNorm stay with the host framework (MIOpen); everythi
 else on the iteration path is a HIP kernel: image resize, ``disp_warp``, the uncertainty
 volume (softmax * d * (d-disp)^2 in one pass), the GRU gate math, and the learned-bounds
 sampler.  Parameter names (including the reference's aliased ``conv_zz.0`` etc.) match the
-reference so its ``state_dict``s load unchanged.  No host sync inside ``forward``.
+reference so its ``state_dict``s load unchanged.  No host sync inside ``forward``.  Trainable: every custom op on
+the path has a HIP backward (call under ``torch.no_grad()`` for inference).
 """
 from __future__ import annotations
 
@@ -18,8 +19,54 @@ from .local_cost_volume import bounds_lookup, uncertainty_volume
 from .upsample import resize_bilinear
 
 
+def _wants_grad(*ts):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+class _GruResetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, rc, cr):
+        ctx.save_for_backward(h, rc, cr if cr is not None else h.new_empty(0))
+        ctx.has_cr = cr is not None
+        return gru_reset(h, rc, cr)
+
+    @staticmethod
+    def backward(ctx, g):
+        h, rc, cr = ctx.saved_tensors
+        cr = cr if ctx.has_cr else None
+        g = N.dev_f32(g, "gru_reset backward: grad")
+        gh, grc = torch.empty_like(h), torch.empty_like(h)
+        with torch.cuda.device(h.device):
+            N.call("stereo_gru_reset_bwd_f32", N.ptr(h), N.ptr(rc), N.ptr(cr), N.ptr(g), N.ptr(gh), N.ptr(grc), h.numel(),
+                   N.stream_ptr(h.device))
+        return gh, grc, (grc if ctx.has_cr else None)
+
+
+class _GruBlendFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, zc, qc, cz, cq, softsign):
+        e = h.new_empty(0)
+        ctx.save_for_backward(h, zc, qc, cz if cz is not None else e, cq if cq is not None else e)
+        ctx.flags = (cz is not None, cq is not None, bool(softsign))
+        return gru_blend(h, zc, qc, cz, cq, softsign)
+
+    @staticmethod
+    def backward(ctx, g):
+        h, zc, qc, cz, cq = ctx.saved_tensors
+        has_cz, has_cq, softsign = ctx.flags
+        g = N.dev_f32(g, "gru_blend backward: grad")
+        gh, gz, gq = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+        with torch.cuda.device(h.device):
+            N.call("stereo_gru_blend_bwd_f32", N.ptr(h), N.ptr(zc), N.ptr(qc), N.ptr(cz if has_cz else None),
+                   N.ptr(cq if has_cq else None), N.ptr(g), N.ptr(gh), N.ptr(gz), N.ptr(gq), h.numel(),
+                   1 if softsign else 0, N.stream_ptr(h.device))
+        return gh, gz, gq, (gz if has_cz else None), (gq if has_cq else None), None
+
+
 def gru_reset(h, rc, cr=None):
-    """``sigmoid(rc + cr) * h`` in one kernel."""
+    """``sigmoid(rc + cr) * h`` in one kernel (differentiable: HIP backward)."""
+    if _wants_grad(h, rc, cr):
+        return _GruResetFn.apply(h.contiguous(), rc.contiguous(), None if cr is None else cr.contiguous())
     h = N.dev_f32(h, "gru_reset: h")
     rc = N.dev_f32(rc, "gru_reset: rc")
     cr = None if cr is None else N.dev_f32(cr, "gru_reset: cr")
@@ -32,7 +79,10 @@ def gru_reset(h, rc, cr=None):
 
 
 def gru_blend(h, zc, qc, cz=None, cq=None, softsign=False):
-    """``(1-z)*h + z*act(qc+cq)`` with ``z = sigmoid(zc+cz)`` in one kernel."""
+    """``(1-z)*h + z*act(qc+cq)`` with ``z = sigmoid(zc+cz)`` in one kernel (differentiable: HIP backward)."""
+    if _wants_grad(h, zc, qc, cz, cq):
+        c = lambda t: None if t is None else t.contiguous()
+        return _GruBlendFn.apply(h.contiguous(), zc.contiguous(), qc.contiguous(), c(cz), c(cq), bool(softsign))
     h = N.dev_f32(h, "gru_blend: h")
     zc = N.dev_f32(zc, "gru_blend: zc")
     qc = N.dev_f32(qc, "gru_blend: qc")
@@ -138,11 +188,10 @@ class DisparityUpdateDLC(nn.Module):
         self.offset = OffsetPredictionHead(input_dim=32, hidden_dim=64)
 
     def forward(self, old_cost_volume, cur_disp, left_image, right_image, hidden_state=None, consider_valid=True):
-        with torch.no_grad():
-            offset_features = self.encoder(old_cost_volume, cur_disp, left_image, right_image)
-            hidden_state = self.gru(offset_features, hidden_state)
-            bounds = self.offset(hidden_state)
-            disp = bounds_lookup(old_cost_volume, cur_disp, bounds, self.sample_points, consider_valid)
+        offset_features = self.encoder(old_cost_volume, cur_disp, left_image, right_image)
+        hidden_state = self.gru(offset_features, hidden_state)
+        bounds = self.offset(hidden_state)
+        disp = bounds_lookup(old_cost_volume, cur_disp, bounds, self.sample_points, consider_valid)
         return disp, hidden_state
 
 
@@ -162,12 +211,11 @@ class DisparityUpdateDLCWithMask(nn.Module):
             nn.Conv2d(256, 64 * 9, 1, padding=0))
 
     def forward(self, old_cost_volume, cur_disp, left_image, right_image, hidden_state=None, consider_valid=True):
-        with torch.no_grad():
-            offset_features = self.encoder(old_cost_volume, cur_disp, left_image, right_image)
-            hidden_state = self.gru(offset_features, hidden_state)
-            mask = .25 * self.mask(hidden_state)
-            bounds = self.offset(hidden_state)          # [B,2,h,w]: (lower offset, upper offset)
-            disp = bounds_lookup(old_cost_volume, cur_disp, bounds, self.sample_points, consider_valid)
+        offset_features = self.encoder(old_cost_volume, cur_disp, left_image, right_image)
+        hidden_state = self.gru(offset_features, hidden_state)
+        mask = .25 * self.mask(hidden_state)
+        bounds = self.offset(hidden_state)          # [B,2,h,w]: (lower offset, upper offset)
+        disp = bounds_lookup(old_cost_volume, cur_disp, bounds, self.sample_points, consider_valid)
         return disp, hidden_state, mask
 
 
@@ -192,11 +240,10 @@ class DisparityUpdateDLCWithMaskV2(nn.Module):
 
     def forward(self, old_cost_volume, cur_disp, left_image, right_image, hidden_state=None, left_feature=None,
                 consider_valid=True):
-        with torch.no_grad():
-            offset_features = self.encoder(old_cost_volume, cur_disp, left_image, right_image)
-            input_features = torch.cat((offset_features, self.feature_encode(left_feature)), dim=1)
-            hidden_state = self.gru(input_features, hidden_state)
-            mask = .25 * self.mask(hidden_state)
-            bounds = self.offset(hidden_state)
-            disp = bounds_lookup(old_cost_volume, cur_disp, bounds, self.sample_points, consider_valid)
+        offset_features = self.encoder(old_cost_volume, cur_disp, left_image, right_image)
+        input_features = torch.cat((offset_features, self.feature_encode(left_feature)), dim=1)
+        hidden_state = self.gru(input_features, hidden_state)
+        mask = .25 * self.mask(hidden_state)
+        bounds = self.offset(hidden_state)
+        disp = bounds_lookup(old_cost_volume, cur_disp, bounds, self.sample_points, consider_valid)
         return disp, hidden_state, mask

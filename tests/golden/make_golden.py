@@ -420,6 +420,29 @@ def g11_backward():
         g_fl, g_m4 = torch.autograd.grad(up4, (fl, m4), c4)
         out["up4_flow"], out["up4_mask"], out["up4_cot"] = npy(fl), npy(m4), npy(c4)
         out["up4_gflow"], out["up4_gmask"] = npy(g_fl), npy(g_m4)
+        # A11 module: two iterations, gradients w.r.t. inputs and every parameter
+        from models.LocalCostVolume.Attempts.update import DisparityUpdateDLCWithMask
+        Dm, hh, ww = 24, 8, 16
+        net = DisparityUpdateDLCWithMask(input_channels=Dm, hidden_dim=8, sample_points=20).eval()
+        fill_state_dict_(net, seed=0.5)
+        volm = torch.randn(1, Dm, hh, ww, requires_grad=True)
+        d0 = (torch.rand(1, 1, hh, ww) * (Dm - 1)).requires_grad_(True)
+        lim, rim = torch.randn(1, 3, 8 * hh, 8 * ww), torch.randn(1, 3, 8 * hh, 8 * ww)
+        hid = torch.zeros(1, 16, hh, ww)
+        dd, hidn, mk = net(volm, d0, lim, rim, hid, True)
+        dd2, hidn2, mk2 = net(volm, dd, lim, rim, hidn, True)
+        cdd, cmk, chid = torch.randn_like(dd2), torch.randn_like(mk2), torch.randn_like(hidn2)
+        loss = (dd2 * cdd).sum() + (mk2 * cmk).sum() * 0.01 + (hidn2 * chid).sum() + (dd * cdd).sum()
+        names = [n for n, _ in net.named_parameters()]
+        grads = torch.autograd.grad(loss, [volm, d0] + [p for _, p in net.named_parameters()])
+        out["dlc_vol"], out["dlc_disp0"], out["dlc_left"], out["dlc_right"] = npy(volm), npy(d0), npy(lim), npy(rim)
+        out["dlc_cdd"], out["dlc_cmk_sub"], out["dlc_chid"] = npy(cdd), npy(cmk[:, ::37]), npy(chid)
+        out["dlc_cmk_seed"] = np.array([0])
+        out["dlc_gvol"], out["dlc_gdisp0"] = npy(grads[0]), npy(grads[1])
+        out["dlc_param_names"] = np.array(names)
+        for n_, g_ in zip(names, grads[2:]):
+            out["dlc_gp_" + n_] = npy(g_) if g_.numel() < 20000 else npy(g_.flatten()[::17])
+        out["dlc_cmk_full"] = npy(cmk)
     save("g11_backward", **out)
 
 

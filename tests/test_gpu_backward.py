@@ -144,3 +144,35 @@ def test_forward_only_ops_still_refuse_grad(S):
         S.CostVolume(2, "difference")(x, x)
     with pytest.raises(RuntimeError, match="forward-only"):
         S.Variance_Based_Local_Cost_Volume(1, 5)(x, torch.rand(1, 1, 3, 8, device="cuda"))
+
+
+def test_dlc_updater_module_gradients_g11(S, golden):
+    """DisparityUpdateDLCWithMask, two chained iterations: gradients w.r.t. the cost volume, the input disparity and
+    EVERY parameter against the reference's autograd (convs / BN in MIOpen, all custom ops HIP backward)."""
+    from _weights import fill_state_dict_
+    g = golden("g11_backward")
+    torch.backends.cudnn.allow_tf32 = False
+    net = S.DisparityUpdateDLCWithMask(input_channels=24, hidden_dim=8, sample_points=20).eval()
+    fill_state_dict_(net, seed=0.5)
+    net = net.cuda()
+    vol, d0 = dev(g["dlc_vol"], True), dev(g["dlc_disp0"], True)
+    left, right = dev(g["dlc_left"]), dev(g["dlc_right"])
+    hid = torch.zeros(1, 16, 8, 16, device="cuda")
+    dd, hidn, mk = net(vol, d0, left, right, hid, True)
+    dd2, hidn2, mk2 = net(vol, dd, left, right, hidn, True)
+    cdd, cmk, chid = dev(g["dlc_cdd"]), dev(g["dlc_cmk_full"]), dev(g["dlc_chid"])
+    loss = (dd2 * cdd).sum() + (mk2 * cmk).sum() * 0.01 + (hidn2 * chid).sum() + (dd * cdd).sum()
+    names = [n for n, _ in net.named_parameters()]
+    assert names == list(g["dlc_param_names"])
+    grads = torch.autograd.grad(loss, [vol, d0] + [p for _, p in net.named_parameters()])
+
+    def rel(a, b):
+        a = a.detach().cpu().numpy()
+        return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+    assert rel(grads[0], g["dlc_gvol"]) < 2e-3
+    assert rel(grads[1], g["dlc_gdisp0"]) < 2e-3
+    for n_, g_ in zip(names, grads[2:]):
+        ref = g["dlc_gp_" + n_]
+        got = g_ if g_.numel() < 20000 else g_.flatten()[::17]
+        assert rel(got, ref) < 2e-3, (n_, rel(got, ref))

@@ -152,7 +152,14 @@ def test_lowcnn_gru_loop_graph_matches_eager(S):
     left = torch.randn(B, 3, 8 * h, 8 * w, device="cuda")
     right = torch.randn(B, 3, 8 * h, 8 * w, device="cuda")
     disp = S.DisparityEstimation(D)(vol).unsqueeze(1)
-    eager = loop(vol, disp, left, right, iters=6)
-    graphed = loop(vol, disp, left, right, iters=6, use_graph=True)
+    with torch.no_grad():
+        eager = loop(vol, disp, left, right, iters=6)
+        graphed = loop(vol, disp, left, right, iters=6, use_graph=True)
+    with pytest.raises(RuntimeError, match="inference path"):
+        loop(vol, disp, left, right, iters=6, use_graph=True)
+    # and the same loop is trainable in grad mode
+    outs = loop(vol, disp, left, right, iters=2)
+    outs[-1].mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in loop.parameters())
     assert len(eager) == 6 and len(graphed) == 1
     assert (eager[-1] - graphed[0]).abs().max().item() < 1e-4
