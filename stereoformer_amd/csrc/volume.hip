@@ -732,6 +732,7 @@ int pipe_dispatch(const float *L, const float *R, float *vol, int B, int C, int 
     PK_CASE(12, 8);
     PK_CASE(12, 16);
     PK_CASE(16, 12);
+    PK_CASE(16, 8);
 #undef PK_CASE
 #define PIPE_CASE(DCV, NWVV) \
     if (dc == DCV && nw == NWVV) return launch_pipe<DCV, NWVV, EPI>(L, R, vol, B, C, H, W, D, G, sgn, st)
