@@ -198,6 +198,23 @@ int stereo_bounds_lookup_bwd_f32(const float *vol, const float *disp, const floa
                                  float *grad_vol_zeroed, float *grad_disp, float *grad_bounds,
                                  int B, int D, int H, int W, int S, int consider_valid, void *stream);
 
+/* backward of A9 (corr.py:78-101): grad_out [B, L*(2r+1), H, W1] scattered onto the two taps of each level;
+ * grad_levels_zeroed[i] [B*H*W1, W2>>i] must be zero-filled.  No gradient w.r.t. coords (detached in the
+ * reference, raft_stereo.py:171). */
+int stereo_corr_lookup_bwd_f32(float *const *grad_levels_zeroed, const float *coords, const float *grad_out,
+                               int B, int H, int W1, int W2, int num_levels, int radius, void *stream);
+
+/* backward of A8 (corr.py:55-76,103-111): the level cotangents grad_levels[0..num_levels] are folded coarse to
+ * fine INTO grad_levels[0] (modified), then grad_fmap1 = G0 F2^T / sqrt(C), grad_fmap2 = G0^T F1 / sqrt(C)
+ * on the f32 matrix cores; either output may be NULL */
+int stereo_allpairs_pyramid_bwd_f32(const float *fmap1, const float *fmap2, float *const *grad_levels,
+                                    float *grad_fmap1, float *grad_fmap2, int B, int C, int H, int W1, int W2,
+                                    int num_levels, void *stream);
+
+/* backward of the bilinear resize; grad_in must be zero-filled */
+int stereo_resize_bilinear_bwd_f32(const float *grad_out, float *grad_in_zeroed, int NC, int Hi, int Wi, int Ho, int Wo,
+                                   int align_corners, float scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,9 @@ SIGNATURES = {
     "stereo_uncertainty_volume_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "stereo_disp_warp_bwd_disp_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_bounds_lookup_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_corr_lookup_bwd_f32": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_allpairs_pyramid_bwd_f32": [_vp, _vp, ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_resize_bilinear_bwd_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "stereo_gru_reset_f32": [_vp, _vp, _vp, _vp, _ll, _vp],
     "stereo_gru_blend_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp],
 }

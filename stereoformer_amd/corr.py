@@ -16,6 +16,79 @@ def _level_array(tensors):
     return arr
 
 
+def _pyramid_forward(fmap1, fmap2, num_levels):
+    B, C, H, W1 = fmap1.shape
+    W2 = fmap2.shape[3]
+    rows = B * H * W1
+    levels = [torch.empty((rows, 1, 1, W2 >> i), device=fmap1.device, dtype=torch.float32) for i in range(num_levels + 1)]
+    with torch.cuda.device(fmap1.device):
+        N.call("stereo_allpairs_pyramid_f32", N.ptr(fmap1), N.ptr(fmap2), _level_array(levels), B, C, H, W1, W2,
+               num_levels, N.stream_ptr(fmap1.device))
+    return levels
+
+
+class _AllPairsPyramidFn(torch.autograd.Function):
+    """All-pairs correlation + pyramid with a HIP backward (pool backward + two f32-MFMA GEMMs)."""
+
+    @staticmethod
+    def forward(ctx, fmap1, fmap2, num_levels):
+        levels = _pyramid_forward(fmap1, fmap2, num_levels)
+        ctx.save_for_backward(fmap1, fmap2)
+        ctx.num_levels = num_levels
+        return tuple(levels)
+
+    @staticmethod
+    def backward(ctx, *glevels):
+        f1, f2 = ctx.saved_tensors
+        B, C, H, W1 = f1.shape
+        W2 = f2.shape[3]
+        rows = B * H * W1
+        # the kernel folds the coarse cotangents into level 0 in place: work on private copies
+        top = max([i for i, g in enumerate(glevels) if g is not None], default=-1)
+        if top < 0:
+            return None, None, None
+        bufs = []
+        for i in range(top + 1):
+            g = glevels[i]
+            bufs.append(N.dev_f32(g, "all-pairs backward: grad").clone() if g is not None else
+                        torch.zeros((rows, 1, 1, W2 >> i), device=f1.device, dtype=torch.float32))
+        arr = (ctypes.c_void_p * (ctx.num_levels + 1))(*([b.data_ptr() for b in bufs] + [0] * (ctx.num_levels - top)))
+        g1 = torch.empty_like(f1) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(f2) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(f1.device):
+            N.call("stereo_allpairs_pyramid_bwd_f32", N.ptr(f1), N.ptr(f2), arr, N.ptr(g1), N.ptr(g2), B, C, H, W1, W2,
+                   ctx.num_levels, N.stream_ptr(f1.device))
+        return g1, g2, None
+
+
+class _CorrLookupFn(torch.autograd.Function):
+    """Pyramid lookup with a HIP backward onto the pyramid levels (no gradient w.r.t. coords: the reference
+    detaches them every iteration, raft_stereo.py:171)."""
+
+    @staticmethod
+    def forward(ctx, coords, shape, radius, num_levels, *levels):
+        B, H, W1, W2 = shape
+        T = 2 * radius + 1
+        out = torch.empty((B, num_levels * T, H, W1), device=coords.device, dtype=torch.float32)
+        with torch.cuda.device(coords.device):
+            N.call("stereo_corr_lookup_f32", _level_array(list(levels)), N.ptr(coords), N.ptr(out), B, H, W1, W2,
+                   num_levels, radius, N.stream_ptr(coords.device))
+        ctx.save_for_backward(coords)
+        ctx.cfg = (shape, radius, num_levels, [tuple(l.shape) for l in levels])
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (coords,) = ctx.saved_tensors
+        (B, H, W1, W2), radius, num_levels, shapes = ctx.cfg
+        go = N.dev_f32(grad_out, "corr lookup backward: grad")
+        gl = [torch.zeros(sh, device=coords.device, dtype=torch.float32) for sh in shapes]
+        with torch.cuda.device(coords.device):
+            N.call("stereo_corr_lookup_bwd_f32", _level_array(gl), N.ptr(coords), N.ptr(go), B, H, W1, W2, num_levels,
+                   radius, N.stream_ptr(coords.device))
+        return (None, None, None, None, *gl)
+
+
 class CorrBlock1D:
     """``CorrBlock1D(fmap1, fmap2, num_levels=4, radius=4)`` (corr.py:54-111).
 
@@ -25,28 +98,28 @@ class CorrBlock1D:
     def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
         self.num_levels = num_levels
         self.radius = radius
-        fmap1 = N.dev_f32(fmap1, "CorrBlock1D: fmap1")
-        fmap2 = N.dev_f32(fmap2, "CorrBlock1D: fmap2")
-        B, C, H, W1 = fmap1.shape
-        W2 = fmap2.shape[3]
         if fmap2.shape[:3] != fmap1.shape[:3]:
             raise ValueError("CorrBlock1D: fmap1/fmap2 must share B, C, H")
+        B, C, H, W1 = fmap1.shape
+        self._shape = (B, H, W1, fmap2.shape[3])
+        if torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad):
+            self.corr_pyramid = list(_AllPairsPyramidFn.apply(fmap1.contiguous(), fmap2.contiguous(), num_levels))
+            return
+        fmap1 = N.dev_f32(fmap1, "CorrBlock1D: fmap1")
+        fmap2 = N.dev_f32(fmap2, "CorrBlock1D: fmap2")
         N.same_device(fmap1, fmap2)
-        self._shape = (B, H, W1, W2)
-        rows = B * H * W1
-        widths = [W2 >> i for i in range(num_levels + 1)]
-        self.corr_pyramid = [torch.empty((rows, 1, 1, w), device=fmap1.device, dtype=torch.float32) for w in widths]
-        with torch.cuda.device(fmap1.device):
-            N.call("stereo_allpairs_pyramid_f32", N.ptr(fmap1), N.ptr(fmap2), _level_array(self.corr_pyramid),
-                   B, C, H, W1, W2, num_levels, N.stream_ptr(fmap1.device))
+        self.corr_pyramid = _pyramid_forward(fmap1, fmap2, num_levels)
 
     def __call__(self, coords):
-        coords = N.dev_f32(coords, "CorrBlock1D: coords")
         B, H, W1, W2 = self._shape
+        coords = N.dev_f32(coords.detach(), "CorrBlock1D: coords")  # no gradient flows to coords (raft_stereo.py:171)
         if coords.dim() != 4 or coords.shape[0] != B or coords.shape[1] < 1 or tuple(coords.shape[2:]) != (H, W1):
             raise ValueError(f"CorrBlock1D: coords must be [B,2,H,W1] = [{B},2,{H},{W1}]")
         if coords.shape[1] != 2:  # the reference only reads channel 0 (corr.py:80)
             coords = torch.cat([coords[:, :1], torch.zeros_like(coords[:, :1])], 1).contiguous()
+        if torch.is_grad_enabled() and any(l.requires_grad for l in self.corr_pyramid[:self.num_levels]):
+            return _CorrLookupFn.apply(coords, self._shape, self.radius, self.num_levels,
+                                       *self.corr_pyramid[:self.num_levels])
         T = 2 * self.radius + 1
         out = torch.empty((B, self.num_levels * T, H, W1), device=coords.device, dtype=torch.float32)
         with torch.cuda.device(coords.device):

@@ -67,7 +67,8 @@ class RAFTStereoLoop(nn.Module):
         self._graphs = _GraphCache()
 
     def _iteration(self, corr_fn, coords0, coords1, net_list, inp_list):
-        corr = corr_fn(coords1)                                     # raft_stereo.py:173
+        coords1 = coords1.detach()                                  # raft_stereo.py:171
+        corr = corr_fn(coords1)                                     # :173
         flow = coords1 - coords0
         net_list, up_mask, delta_flow = self.update_block(net_list, inp_list, corr, flow,
                                                           iter32=self.n_gru_layers == 3,
@@ -75,7 +76,6 @@ class RAFTStereoLoop(nn.Module):
         delta_flow[:, 1] = 0.0                                      # :180
         return net_list, up_mask, coords1 + delta_flow
 
-    @torch.no_grad()
     def forward(self, fmap1, fmap2, net_list, inp_list, iters=12, flow_init=None, test_mode=False, use_graph=False):
         """fmap1/fmap2 [B,256,H/4,W/4] (fnet outputs), net_list: tanh'ed hidden states per scale,
         inp_list: per scale the (cz, cr, cq) context tensors (``raft_stereo.py:143-148``).
@@ -83,6 +83,8 @@ class RAFTStereoLoop(nn.Module):
         host launch cost)."""
         if not use_graph:
             return self._forward_eager(fmap1, fmap2, net_list, inp_list, iters, flow_init, test_mode)
+        if torch.is_grad_enabled():
+            raise RuntimeError("RAFTStereoLoop: use_graph=True is an inference path; call it under torch.no_grad()")
         nl, ni = len(net_list), [len(x) for x in inp_list]
         flat = [fmap1, fmap2, *net_list, *[t for lvl in inp_list for t in lvl]]
         if flow_init is not None:
@@ -109,7 +111,7 @@ class RAFTStereoLoop(nn.Module):
         coords1 = coords0.clone()
         if flow_init is not None:
             coords1 = coords1 + flow_init
-        net_list = [n.contiguous() for n in net_list]
+        net_list = [n.contiguous() for n in net_list]   # a private list: the update block writes into it
         preds = []
         up_mask = None
         for itr in range(iters):

@@ -3,8 +3,8 @@
 Host-side mirror of ``models/IterativeLocalCostVolume/update/update.py`` (module and parameter names
 are kept so the reference's ``state_dict``s load unchanged).  Convolutions and pooling are left to
 the host framework (MIOpen); what this package owns on the path is the gate math -- ``sigmoid(conv +
-c) * h`` and ``(1 - z) * h + z * tanh(conv + c)`` as single HIP kernels -- and the bilinear ``interp``.
-The block is an inference path: ``forward`` runs under ``torch.no_grad()``.
+c) * h`` and ``(1 - z) * h + z * tanh(conv + c)`` as single HIP kernels -- and the bilinear ``interp``; all three
+have HIP backward kernels, so the block trains (call under ``torch.no_grad()`` for inference).
 """
 from __future__ import annotations
 
@@ -115,7 +115,6 @@ class BasicMultiUpdateBlock_LZH(nn.Module):
         self.mask = nn.Sequential(_conv(h08, 256, 3), nn.ReLU(inplace=True),
                                   _conv(256, 9 * (2 ** n_downsample) ** 2, 1))
 
-    @torch.no_grad()
     def forward(self, net, inp, corr=None, flow=None, iter08=True, iter16=True, iter32=True, update=True):
         if iter32:
             net[2] = self.gru32(net[2], *inp[2], pool2x(net[1]))

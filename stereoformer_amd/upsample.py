@@ -77,8 +77,27 @@ def upsample_flow(flow, mask, downsample=2):
     return upsample_convex(flow, mask, 2 ** downsample)
 
 
+class _ResizeBilinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size, align_corners, scale):
+        ctx.cfg = (tuple(x.shape), (int(size[0]), int(size[1])), bool(align_corners), float(scale))
+        return resize_bilinear(x, size, align_corners, scale)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (n, c, hi, wi), (ho, wo), ac, scale = ctx.cfg
+        go = N.dev_f32(grad_out, "resize_bilinear backward: grad")
+        gin = torch.zeros((n, c, hi, wi), device=go.device, dtype=torch.float32)
+        with torch.cuda.device(go.device):
+            N.call("stereo_resize_bilinear_bwd_f32", N.ptr(go), N.ptr(gin), n * c, hi, wi, ho, wo, 1 if ac else 0, scale,
+                   N.stream_ptr(go.device))
+        return gin, None, None, None
+
+
 def resize_bilinear(x, size, align_corners, scale=1.0):
-    """``scale * F.interpolate(x, size, mode='bilinear', align_corners=...)`` in one kernel."""
+    """``scale * F.interpolate(x, size, mode='bilinear', align_corners=...)`` in one kernel (HIP backward)."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _ResizeBilinearFn.apply(x.contiguous(), (int(size[0]), int(size[1])), bool(align_corners), float(scale))
     x = N.dev_f32(x, "resize_bilinear: x")
     n, c, hi, wi = x.shape
     ho, wo = int(size[0]), int(size[1])

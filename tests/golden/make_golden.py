@@ -446,6 +446,66 @@ def g11_backward():
     save("g11_backward", **out)
 
 
+# ------------------------------------------------------------------ G12
+def g12_raft_backward():
+    """Gradients of the RAFT_Stereo hot loop from the reference's autograd: 3 iterations, loss over all
+    predictions; cotangents w.r.t. the tensors the extractors hand over and the update block's parameters."""
+    import types
+    t = types.ModuleType("turtle"); t.left = t.right = None; sys.modules["turtle"] = t
+    sys.argv = ["x"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        from models.IterativeLocalCostVolume import raft_stereo as RS
+    torch.manual_seed(1201)
+    with torch.enable_grad():
+        model = RS.RAFT_Stereo(hidden_dim=[32, 32, 32]).eval()
+        fill_state_dict_(model, seed=0.125)
+        cap = {}
+        orig_init = RS.CorrBlock1D.__init__
+
+        def rec_init(self, fmap1, fmap2, num_levels=4, radius=4):
+            fmap1.retain_grad(); fmap2.retain_grad()
+            cap["fmap1"], cap["fmap2"] = fmap1, fmap2
+            orig_init(self, fmap1, fmap2, num_levels=num_levels, radius=radius)
+
+        RS.CorrBlock1D.__init__ = rec_init
+
+        def pre_hook(mod, args, kwargs):
+            if "net" not in cap:
+                for x in args[0]:
+                    x.retain_grad()
+                for lvl in args[1]:
+                    for c in lvl:
+                        c.retain_grad()
+                cap["net"] = list(args[0])
+                cap["inp"] = [list(lvl) for lvl in args[1]]
+
+        hk = model.update_block.register_forward_pre_hook(pre_hook, with_kwargs=True)
+        left = torch.rand(1, 3, 64, 96) * 255
+        right = torch.rand(1, 3, 64, 96) * 255
+        with contextlib.redirect_stdout(io.StringIO()):
+            preds = model(left, right, iters=3, test_mode=False)
+        hk.remove()
+        RS.CorrBlock1D.__init__ = orig_init
+        cots = [torch.randn_like(p) for p in preds]
+        loss = sum((p * c).sum() for p, c in zip(preds, cots))
+        loss.backward()
+    out = {"fmap1": npy(cap["fmap1"]), "fmap2": npy(cap["fmap2"]),
+           "g_fmap1": npy(cap["fmap1"].grad), "g_fmap2": npy(cap["fmap2"].grad)}
+    out["keys"] = np.array(sorted(model.state_dict().keys()))
+    for i in range(3):
+        out[f"net{i}"], out[f"g_net{i}"] = npy(cap["net"][i]), npy(cap["net"][i].grad)
+        for j in range(3):
+            out[f"inp{i}{j}"], out[f"g_inp{i}{j}"] = npy(cap["inp"][i][j]), npy(cap["inp"][i][j].grad)
+    for k, c in enumerate(cots):
+        out[f"cot{k}"] = npy(c)
+    names = [n for n, _ in model.update_block.named_parameters()]
+    out["param_names"] = np.array(names)
+    for n_, p_ in model.update_block.named_parameters():
+        g_ = p_.grad
+        out["gp_" + n_] = npy(g_) if g_.numel() < 20000 else npy(g_.flatten()[::37])
+    save("g12_raft_backward", **out)
+
+
 # ------------------------------------------------------------------ cfg-1 check
 def check_oracle_cfg1():
     """Not a fixture: proves the C oracle == the reference at BASELINE
@@ -482,5 +542,6 @@ if __name__ == "__main__":
     g9_raft_loop()
     g10_metrics_io()
     g11_backward()
+    g12_raft_backward()
     if CHECK:
         check_oracle_cfg1()

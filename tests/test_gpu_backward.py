@@ -176,3 +176,92 @@ def test_dlc_updater_module_gradients_g11(S, golden):
         ref = g["dlc_gp_" + n_]
         got = g_ if g_.numel() < 20000 else g_.flatten()[::17]
         assert rel(got, ref) < 2e-3, (n_, rel(got, ref))
+
+
+def test_allpairs_pyramid_and_lookup_backward_vs_torch(S):
+    """A8 + A9 backward (pool backward, two f32-MFMA GEMMs, lookup scatter) against torch autograd of the same
+    math written with einsum / avg_pool / gather-style sampling on the GPU."""
+    import torch.nn.functional as F
+    torch.manual_seed(5)
+    B, C, H, W1, W2, L, r = 2, 40, 5, 70, 72, 3, 3
+    f1 = torch.randn(B, C, H, W1, device="cuda").requires_grad_(True)
+    f2 = torch.randn(B, C, H, W2, device="cuda").requires_grad_(True)
+    coords = torch.rand(B, 1, H, W1, device="cuda") * (W2 + 8) - 4
+    blk = S.CorrBlock1D(f1, f2, num_levels=L, radius=r)
+    out = blk(coords)
+    cot = torch.randn_like(out)
+    g1, g2 = torch.autograd.grad((out * cot).sum(), [f1, f2])
+
+    f1r, f2r = f1.detach().clone().requires_grad_(True), f2.detach().clone().requires_grad_(True)
+    corr = torch.einsum("bchi,bchj->bhij", f1r, f2r).reshape(B * H * W1, 1, 1, W2) / C ** 0.5
+    pyr = [corr]
+    for _ in range(L):
+        pyr.append(F.avg_pool2d(pyr[-1], [1, 2], stride=[1, 2]))
+    outs = []
+    x0 = coords.permute(0, 2, 3, 1).reshape(B * H * W1, 1, 1, 1)
+    dx = torch.linspace(-r, r, 2 * r + 1, device="cuda").view(1, 1, 2 * r + 1, 1)
+    for i in range(L):
+        lvl = pyr[i]
+        w = lvl.shape[-1]
+        x = (dx + x0 / 2 ** i)[..., 0]                       # [N,1,T]
+        xf = torch.floor(x)
+        a = x - xf
+        v = 0
+        for xi, wt in ((xf, 1 - a), (xf + 1, a)):
+            ok = ((xi >= 0) & (xi <= w - 1)).float()
+            idx = xi.clamp(0, w - 1).long()
+            v = v + torch.gather(lvl[:, 0], 2, idx) * wt * ok
+        outs.append(v.view(B, H, W1, -1))
+    ref = torch.cat(outs, -1).permute(0, 3, 1, 2).contiguous()
+    close(out, ref.detach().cpu().numpy(), rtol=1e-4, atol=2e-4)
+    r1, r2 = torch.autograd.grad((ref * cot).sum(), [f1r, f2r])
+    close(g1, r1.cpu().numpy(), rtol=1e-4, atol=2e-4)
+    close(g2, r2.cpu().numpy(), rtol=1e-4, atol=2e-4)
+
+
+def test_resize_bilinear_backward_vs_torch(S):
+    import torch.nn.functional as F
+    torch.manual_seed(6)
+    for (hi, wi, ho, wo, ac) in ((9, 13, 18, 26, True), (9, 13, 17, 31, False), (16, 20, 8, 10, True), (5, 7, 5, 7, False)):
+        x = torch.randn(2, 3, hi, wi, device="cuda").requires_grad_(True)
+        y = S.resize_bilinear(x, (ho, wo), ac, scale=2.0)
+        cot = torch.randn_like(y)
+        (g,) = torch.autograd.grad((y * cot).sum(), x)
+        xr = x.detach().clone().requires_grad_(True)
+        yr = 2.0 * F.interpolate(xr, (ho, wo), mode="bilinear", align_corners=ac)
+        (gr,) = torch.autograd.grad((yr * cot).sum(), xr)
+        close(y, yr.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+        close(g, gr.cpu().numpy(), rtol=1e-5, atol=2e-5)
+
+
+def test_raft_stereo_loop_gradients_g12(S, golden):
+    """RAFT_Stereo hot loop, 3 iterations in training mode: gradients w.r.t. fmap1/fmap2, the hidden states, the
+    context tensors and EVERY update-block parameter against the reference model's own autograd (golden G12)."""
+    from _weights import fill_state_dict_
+    g = golden("g12_raft_backward")
+    torch.backends.cudnn.allow_tf32 = False
+    loop = S.RAFTStereoLoop(hidden_dims=[32, 32, 32]).eval()
+    fill_state_dict_(loop.update_block, seed=0.125, keys=list(g["keys"]), prefix="update_block.")
+    loop = loop.cuda()
+    f1, f2 = dev(g["fmap1"], True), dev(g["fmap2"], True)
+    net = [dev(g[f"net{i}"], True) for i in range(3)]
+    inp = [[dev(g[f"inp{i}{j}"], True) for j in range(3)] for i in range(3)]
+    preds = loop(f1, f2, net, inp, iters=3, test_mode=False)
+    loss = sum((p * dev(g[f"cot{k}"])).sum() for k, p in enumerate(preds))
+    names = [n for n, _ in loop.update_block.named_parameters()]
+    assert names == list(g["param_names"])
+    leaves = [f1, f2] + net + [t for lvl in inp for t in lvl]
+    grads = torch.autograd.grad(loss, leaves + [p for _, p in loop.update_block.named_parameters()])
+
+    def rel(a, b):
+        a = a.detach().cpu().numpy()
+        return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+    refs = [g["g_fmap1"], g["g_fmap2"]] + [g[f"g_net{i}"] for i in range(3)] + \
+           [g[f"g_inp{i}{j}"] for i in range(3) for j in range(3)]
+    for k, (got, ref) in enumerate(zip(grads, refs)):
+        assert rel(got, ref) < 2e-3, (k, rel(got, ref))
+    for n_, g_ in zip(names, grads[len(leaves):]):
+        ref = g["gp_" + n_]
+        got = g_ if g_.numel() < 20000 else g_.flatten()[::37]
+        assert rel(got, ref) < 2e-3, (n_, rel(got, ref))

@@ -128,6 +128,8 @@ def test_raft_stereo_loop_end_to_end_g9(S, golden):
     # the fixture carries that model's sorted key list so the update block gets identical values
     fill_state_dict_(loop.update_block, seed=0.125, keys=list(g["keys"]), prefix="update_block.")
     loop = loop.cuda()
+    for p_ in loop.parameters():
+        p_.requires_grad_(False)
     f1, f2, net, inp = _raft_inputs(g)
     flow_lo, flow_up = loop(f1, f2, net, inp, iters=4, test_mode=True)
     close(flow_lo, g["flow_lo"], rtol=1e-4, atol=1e-3)
@@ -140,8 +142,10 @@ def test_raft_stereo_loop_end_to_end_g9(S, golden):
         close(p, g[f"pred{k}"], rtol=1e-4, atol=2e-3)
     # HIP-graph replay of the iteration == eager
     f1, f2, net, inp = _raft_inputs(g)
-    lo_g, up_g = loop(f1, f2, net, inp, iters=4, test_mode=True, use_graph=True)
-    assert (lo_g - flow_lo).abs().max().item() < 1e-5 and (up_g - flow_up).abs().max().item() < 1e-5
+    with torch.no_grad():
+        lo_g, up_g = loop(f1, f2, net, inp, iters=4, test_mode=True, use_graph=True)
+    # flows are O(10): a few ulp (MIOpen may pick another conv algorithm in the warm-up before capture)
+    assert (lo_g - flow_lo).abs().max().item() < 5e-5 and (up_g - flow_up).abs().max().item() < 1e-4
 
 
 def test_lowcnn_gru_loop_graph_matches_eager(S):
