@@ -74,6 +74,21 @@ int stereo_corr_soft_argmin_f32(const float *left, const float *right, float *di
                                 int B, int C, int H, int W, int D, int match_similarity,
                                 void *stream);
 
+/* A1 + A4 in one pass: vol [B,D,H,W] = correlation volume, disp [B,H,W] = its soft-argmin
+ *     (build_cost_volume.py:18-52 + estimation.py:14-34); the volume is not read back. */
+int stereo_corr_volume_soft_argmin_f32(const float *left, const float *right, float *vol,
+                                       float *disp, int B, int C, int H, int W, int D,
+                                       int match_similarity, void *stream);
+
+/* A3 + group mean + A4 in one call: vol [B,G,D,H,W] = build_gwc_volume (GWC_Cost_Volume.py:14-24),
+ *     mean [B,D,H,W] = vol.mean(1) (may be NULL), disp [B,H,W] = soft-argmin over D of mean
+ *     (estimation.py:14-34).  With equal group sizes vol.mean(1) equals the all-channel correlation
+ *     volume, so mean/disp come from the feature tiles and the 4*B*G*D*H*W-byte volume is written
+ *     once and never read back. */
+int stereo_gwc_volume_soft_argmin_f32(const float *left, const float *right, float *vol,
+                                      float *mean, float *disp, int B, int C, int H, int W, int D,
+                                      int G, int match_similarity, void *stream);
+
 /* A5  build_cost_volume_from_volume  .../Attempts/fixed_local_cost_volume.py:61-80
  *     vol [B,D,H,W], cand [B,K,H,W] -> out [B,K,H,W] */
 int stereo_sample_volume_f32(const float *vol, const float *cand, float *out,

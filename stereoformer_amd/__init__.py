@@ -8,6 +8,7 @@ the C ABI in ``include/stereo_hip.h`` (``libstereo_hip.so``).  No CPU fallback.
 """
 from . import _native
 from .cost_volume import (CostVolume, CostVolumePyramid, build_concat_volume, build_gwc_volume,
+                          build_gwc_volume_with_disparity, corr_volume_with_disparity,
                           groupwise_correlation)
 from .estimation import (DisparityEstimation, DisparityEstimationWithProb, corr_soft_argmin,
                          disparity_regression, group_mean_soft_argmin)
@@ -36,7 +37,7 @@ __all__ = [
     "AlternateCorrBlock", "CorrBlock1D", "InputPadder", "PytorchAlternateCorrBlock1D", "bilinear_sampler",
     "coords_grid", "CrossAttentionCostVolume", "disp_warp", "ConvAffinityUpsample", "interp", "resize_bilinear",
     "upflow8", "upsample_convex", "upsample_convex8", "upsample_flow", "upsample_simple8",
-    "CostVolume", "CostVolumePyramid", "build_concat_volume", "build_gwc_volume", "groupwise_correlation",
+    "CostVolume", "CostVolumePyramid", "build_concat_volume", "build_gwc_volume", "build_gwc_volume_with_disparity", "corr_volume_with_disparity", "groupwise_correlation",
     "DisparityEstimation", "DisparityEstimationWithProb", "corr_soft_argmin", "disparity_regression",
     "group_mean_soft_argmin", "LocalCostVolume", "Variance_Based_Local_Cost_Volume", "bounds_lookup",
     "build_cost_volume_from_volume", "uncertainty_volume",

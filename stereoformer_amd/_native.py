@@ -32,6 +32,8 @@ SIGNATURES = {
     "stereo_disparity_regression_f32": [_vp, _vp, _i, _i, _i, _i, _vp],
     "stereo_group_mean_soft_argmin_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_corr_soft_argmin_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_corr_volume_soft_argmin_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_gwc_volume_soft_argmin_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_sample_volume_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_local_lookup_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
     "stereo_variance_lookup_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],

@@ -28,7 +28,7 @@ constexpr int CCMAX = 8;  // channels staged per LDS round
 // online softmax-expectation instead (A1+A4 fused; `vol` is then disp [B,H,W]
 // and G must be 1): each wave keeps (max, sum, d-weighted sum) for its own
 // disparity chunks, the 8 partial states meet in LDS at the end.
-enum { EPI_STORE = 0, EPI_ARGMIN = 1 };
+enum { EPI_STORE = 0, EPI_ARGMIN = 1, EPI_BOTH = 2 };  // BOTH (pipelined kernel only): volume -> vol, disparity -> aux
 
 template <int DC, bool VEC, int EPI>
 __global__ __launch_bounds__(NT) void gwc_volume_kernel(const float *__restrict__ L, const float *__restrict__ R,
@@ -206,10 +206,13 @@ __global__ __launch_bounds__(NT) void gwc_volume_kernel(const float *__restrict_
 template <int DC, int NWV, int EPI>
 __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *__restrict__ L,
                                                                    const float *__restrict__ R,
-                                                                   float *__restrict__ vol, int C, int H, int W, int D,
-                                                                   int G, int CPG, int Dpad, int CC, float inv_cpg,
-                                                                   int exact_div, float sgn, int nparts, int RB, int nt)
+                                                                   float *__restrict__ vol, float *__restrict__ aux,
+                                                                   int C, int H, int W, int D, int G, int CPG, int Dpad,
+                                                                   int CC, float inv_cpg, int exact_div, float sgn,
+                                                                   int nparts, int RB, int nt)
 {
+    constexpr bool DO_STORE = EPI == EPI_STORE || EPI == EPI_BOTH;
+    constexpr bool DO_ARGMIN = EPI == EPI_ARGMIN || EPI == EPI_BOTH;
     extern __shared__ f32x4 smem4[];
     float *Rs = reinterpret_cast<float *>(smem4);  // [CC][RS]
     const int RS = TW + Dpad;
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
         if (it + 2 < nitems) item_loads(it + 2);
         if (ck == nchunk - 1 && active) {  // group finished: epilogue
             const int w = w0 + wl;
-            if (EPI == EPI_STORE) {
+            if (DO_STORE) {
                 float *vbase = vol + (((size_t)b * G + g) * D) * HW + (size_t)h * W;
                 const bool interior = (w0 >= d0 + DC - 1) && (w0 + TW <= W) && (d0 + DC <= D);  // wave-uniform
                 if (interior) {  // no w<d zeros, no ragged edge: straight scaled stores
@@ -382,7 +385,8 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
                         }
                     }
                 }
-            } else {
+            }
+            if (DO_ARGMIN) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float x[DC];
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
                 }
             }
         }
-        if (EPI == EPI_ARGMIN && ir == per_row - 1) {  // row finished: combine the waves' softmax states
+        if (DO_ARGMIN && ir == per_row - 1) {  // row finished: combine the waves' softmax states
             // (single disparity part: the launcher guarantees nparts == 1).  Uses its own LDS region.
             float *stt = reinterpret_cast<float *>(smem4) + 2 * BUF;  // [3][NWV][TW]
 #pragma unroll
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
                     S = fmaf(stt[(1 * NWV + k) * TW + tid], sc, S);
                     E = fmaf(stt[(2 * NWV + k) * TW + tid], sc, E);
                 }
-                vol[((size_t)b * H + h) * W + w0 + tid] = E / S;
+                (EPI == EPI_BOTH ? aux : vol)[((size_t)b * H + h) * W + w0 + tid] = E / S;
             }
         }
         __syncthreads();  // all waves: done reading buffer it&1, buffer (it+1)&1 fully written
@@ -685,19 +689,19 @@ int launch_pk(const float *L, const float *R, float *vol, int B, int C, int H, i
 
 template <int DC, int NWV, int EPI>
 int launch_pipe(const float *L, const float *R, float *vol, int B, int C, int H, int W, int D, int G, float sgn,
-                hipStream_t st)
+                hipStream_t st, float *aux = nullptr)
 {
     const int CPG = C / G;
     const int Dpad = ((D + DC - 1) / DC) * DC;
     const int CC = CPG < CCMAX ? CPG : CCMAX;
     size_t lds = (size_t)2 * CC * (size_t)(TW + Dpad + TW) * sizeof(float);  // two staging buffers
-    if (EPI == EPI_ARGMIN) lds += (size_t)3 * NWV * TW * sizeof(float);          // + softmax-state exchange
+    if (EPI != EPI_STORE) lds += (size_t)3 * NWV * TW * sizeof(float);           // + softmax-state exchange
     int RB = 4;                                                                  // rows per workgroup
     if (const char *e = getenv("STEREO_VOL_ROWS")) RB = atoi(e) > 0 ? atoi(e) : RB;
     while (RB > 1 && (long long)((H + RB - 1) / RB) * ((W + TW - 1) / TW) * B * ((D + NWV * DC - 1) / (NWV * DC)) < 2048)
         RB >>= 1;                                                                // keep >= 8 workgroups per CU
     const int nparts = (D + NWV * DC - 1) / (NWV * DC);
-    if (Dpad > 256 || lds > 160 * 1024 || !fits_grid_yz((long long)B * nparts) || (EPI == EPI_ARGMIN && nparts != 1))
+    if (Dpad > 256 || lds > 160 * 1024 || !fits_grid_yz((long long)B * nparts) || (EPI != EPI_STORE && nparts != 1))
         return STEREO_ERR_UNSUPPORTED;
     if ((long long)CCMAX * H * W + W >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;  // 32-bit per-slot offsets
     if (lds > 64 * 1024 &&
@@ -708,8 +712,8 @@ int launch_pipe(const float *L, const float *R, float *vol, int B, int C, int H,
     int nt = 0;
     if (const char *e = getenv("STEREO_VOL_NT")) nt = atoi(e);
     dim3 pgrid((W + TW - 1) / TW, (H + RB - 1) / RB, (unsigned)(B * nparts));
-    hipLaunchKernelGGL((gwc_volume_pipe_kernel<DC, NWV, EPI>), pgrid, dim3(NWV * 64), lds, st, L, R, vol, C, H, W, D, G,
-                       CPG, Dpad, CC, 1.0f / (float)CPG, pow2 ? 0 : 1, sgn, nparts, RB, nt);
+    hipLaunchKernelGGL((gwc_volume_pipe_kernel<DC, NWV, EPI>), pgrid, dim3(NWV * 64), lds, st, L, R, vol, aux, C, H, W, D,
+                       G, CPG, Dpad, CC, 1.0f / (float)CPG, pow2 ? 0 : 1, sgn, nparts, RB, nt);
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }
@@ -883,6 +887,49 @@ extern "C" int stereo_concat_volume_f32(const float *left, const float *right, f
                                         int D, void *stream)
 {
     return shift_dispatch<true>(left, right, vol, B, C, H, W, D, stream);
+}
+
+// A1 + A4 in one pass: the correlation volume is stored AND folded into the soft-argmin while it is produced.
+extern "C" int stereo_corr_volume_soft_argmin_f32(const float *left, const float *right, float *vol, float *disp,
+                                                  int B, int C, int H, int W, int D, int match_similarity,
+                                                  void *stream)
+{
+    if (D == 0 && B > 0 && H > 0 && W > 0) return STEREO_ERR_BAD_SHAPE;  // softmax over an empty axis
+    if (B < 0 || C < 0 || H < 0 || W < 0 || D < 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0) return STEREO_OK;
+    if (C == 0) return STEREO_ERR_BAD_SHAPE;
+    STEREO_REQUIRE_PTR(left);
+    STEREO_REQUIRE_PTR(right);
+    STEREO_REQUIRE_PTR(vol);
+    STEREO_REQUIRE_PTR(disp);
+    const float sgn = match_similarity ? 1.0f : -1.0f;
+    hipStream_t st = as_stream(stream);
+    if ((W % 4 == 0) && aligned16(left) && aligned16(right) && aligned16(vol) && fits_grid_yz(H)) {
+        int rc = STEREO_ERR_UNSUPPORTED;
+        if (D <= 64) rc = launch_pipe<8, 8, EPI_BOTH>(left, right, vol, B, C, H, W, D, 1, sgn, st, disp);
+        else if (D <= 192) rc = launch_pipe<16, 12, EPI_BOTH>(left, right, vol, B, C, H, W, D, 1, sgn, st, disp);
+        if (rc != STEREO_ERR_UNSUPPORTED) return rc;
+    }
+    const int rc = gwc_dispatch<EPI_STORE>(left, right, vol, B, C, H, W, D, 1, 1.0f, stream);
+    if (rc != STEREO_OK) return rc;
+    return gwc_dispatch<EPI_ARGMIN>(left, right, disp, B, C, H, W, D, 1, sgn, stream);
+}
+
+// A3 + group-mean + A4 in one call.  The mean over groups of the group-wise volume IS the correlation volume of
+// all C channels (equal group sizes; SURVEY 8(c) identity I1), so the disparity and the mean volume are produced from
+// the LDS-staged feature tiles (1 GB of input) instead of re-reading the 25.5 GB group-wise volume.
+extern "C" int stereo_gwc_volume_soft_argmin_f32(const float *left, const float *right, float *vol, float *mean,
+                                                 float *disp, int B, int C, int H, int W, int D, int G,
+                                                 int match_similarity, void *stream)
+{
+    if (D == 0 && B > 0 && H > 0 && W > 0) return STEREO_ERR_BAD_SHAPE;
+    const int rc = gwc_dispatch<EPI_STORE>(left, right, vol, B, C, H, W, D, G, 1.0f, stream);
+    if (rc != STEREO_OK) return rc;
+    if (B == 0 || C == 0 || H == 0 || W == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(disp);
+    if (mean == nullptr)
+        return gwc_dispatch<EPI_ARGMIN>(left, right, disp, B, C, H, W, D, 1, match_similarity ? 1.0f : -1.0f, stream);
+    return stereo_corr_volume_soft_argmin_f32(left, right, mean, disp, B, C, H, W, D, match_similarity, stream);
 }
 
 extern "C" int stereo_corr_soft_argmin_f32(const float *left, const float *right, float *disp, int B, int C, int H,

@@ -152,6 +152,32 @@ def test_group_mean_soft_argmin(S, oracle, shape):
     close(S.group_mean_soft_argmin(dev(vg), match_similarity=False), oracle.soft_argmin(mean, False), **DISP_TOL)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 5, 300, 64, 8), (1, 32, 3, 960, 192, 8), (1, 6, 3, 37, 9, 3), (1, 8, 2, 40, 200, 2),
+                                   (2, 24, 4, 516, 100, 4)])
+def test_gwc_volume_with_disparity(S, oracle, shape):
+    """A3 + group mean + A4 in one call (volume written once, never read back) == the separate ops == oracle,
+    on the pipelined fast path (W % 4 == 0, D <= 192) and on the generic fallbacks."""
+    B, C, H, W, D, G = shape
+    rng = np.random.default_rng(29)
+    L = rng.standard_normal((B, C, H, W), dtype=np.float32) * 2
+    R = rng.standard_normal((B, C, H, W), dtype=np.float32) * 2
+    ovol = oracle.gwc_volume(L, R, D, G)
+    omean = oracle.group_mean(ovol)
+    for sim in (True, False):
+        vol, disp, mean = S.build_gwc_volume_with_disparity(dev(L), dev(R), D, G, return_mean=True, match_similarity=sim)
+        close(vol, ovol, **VOL_TOL)
+        close(mean, omean, **VOL_TOL)
+        close(disp, oracle.soft_argmin(omean, sim), **DISP_TOL)
+        d2 = S.group_mean_soft_argmin(S.build_gwc_volume(dev(L), dev(R), D, G), match_similarity=sim)
+        close(disp, host(d2), **DISP_TOL)
+    vol, disp = S.build_gwc_volume_with_disparity(dev(L), dev(R), D, G)
+    close(vol, ovol, **VOL_TOL)
+    close(disp, oracle.soft_argmin(omean), **DISP_TOL)
+    cv, cd = S.corr_volume_with_disparity(dev(L), dev(R), D)
+    close(cv, oracle.corr_volume(L, R, D), **VOL_TOL)
+    close(cd, oracle.soft_argmin(oracle.corr_volume(L, R, D)), **DISP_TOL)
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 5, 300, 64), (1, 32, 2, 960, 192), (1, 6, 3, 37, 9), (1, 8, 2, 40, 200)])
 def test_fused_corr_soft_argmin(S, oracle, shape):
     B, C, H, W, D = shape
@@ -365,6 +391,10 @@ def test_cfg2_full_size_identities(S, oracle):
     assert corr[:, 100, :, :100].abs().max().item() == 0.0
     disp = S.DisparityEstimation(D)(corr)
     assert (disp - disp_g).abs().max().item() < 1e-3
+    volf, dispf, meanf = S.build_gwc_volume_with_disparity(L, R, D, G, return_mean=True)
+    assert (meanf - corr).abs().max().item() < 2e-5 and (dispf - disp_g).abs().max().item() < 1e-3
+    assert torch.equal(volf[3, :, 150:160], S.build_gwc_volume(L[3:4], R[3:4], D, G)[0, :, 150:160])
+    del volf, meanf
     fused = S.corr_soft_argmin(L, R, D)
     assert (fused - disp).abs().max().item() < 1e-3
     assert (fused - disp).abs().mean().item() < 1e-4
@@ -388,6 +418,8 @@ def test_empty_and_degenerate_inputs(S):
     o, dd = S.CrossAttentionCostVolume(4)(z(0, 8, 3, 8), z(0, 8, 3, 8))
     assert o.shape == (0, 8, 3, 8) and dd.shape == (0, 3, 8)
     assert S.group_mean_soft_argmin(z(0, 2, 4, 3, 8)).shape == (0, 3, 8)
+    v0, d0 = S.build_gwc_volume_with_disparity(z(0, 8, 3, 8), z(0, 8, 3, 8), 4, 2)
+    assert v0.shape == (0, 2, 4, 3, 8) and d0.shape == (0, 3, 8)
     assert S.gru_blend(z(0, 4, 2, 2), z(0, 4, 2, 2), z(0, 4, 2, 2)).shape == (0, 4, 2, 2)
     # a single disparity plane: softmax over one element -> disparity 0 everywhere
     v1 = torch.randn(2, 1, 3, 8, device="cuda")
@@ -432,6 +464,10 @@ def test_cfg3_full_size_identity(S, oracle):
     L = torch.randn(B, C, H, W, device="cuda", generator=g)
     R = torch.randn(B, C, H, W, device="cuda", generator=g)
     out, disp = S.CrossAttentionCostVolume(D, "zero", "mean")(L, R)
+    volf, dispf, meanf = S.build_gwc_volume_with_disparity(L, R, D, G, return_mean=True)
+    assert (meanf - corr).abs().max().item() < 2e-5 and (dispf - disp_g).abs().max().item() < 1e-3
+    assert torch.equal(volf[3, :, 150:160], S.build_gwc_volume(L[3:4], R[3:4], D, G)[0, :, 150:160])
+    del volf, meanf
     fused = S.corr_soft_argmin(L, R, D)
     assert (disp - fused).abs().max().item() < 1e-3 and (disp - fused).abs().mean().item() < 1e-4
     rows = [0, 377]
