@@ -226,22 +226,48 @@ __device__ __forceinline__ float lerp_zero_pad_ac(const float *__restrict__ row,
     return acc;
 }
 
-// A9: CorrBlock1D.__call__ (corr.py:78-101)
+// A9: CorrBlock1D.__call__ (corr.py:78-101).  One thread per (pixel, level) -- blockIdx.y is the level -- so that a
+// pixel's 2r+1 taps (which fall into one or two cache lines of its correlation row) are fetched by one lane with all
+// loads issued before the first use (clamped index + masked weight instead of a branch per tap), and consecutive
+// lanes write consecutive pixels of each output plane.  R > 0: compile-time radius (taps unrolled).
+template <int R>
 __global__ __launch_bounds__(256) void corr_lookup_kernel(LevelPtrs lv, const float *__restrict__ coords,
-                                                          float *__restrict__ out, int L, int r, long long HW,
+                                                          float *__restrict__ out, int L, int r_rt, long long HW,
                                                           long long npix)
 {
+    const int r = R > 0 ? R : r_rt;
     const int T = 2 * r + 1;
+    const int i = blockIdx.y;
+    const float *__restrict__ base = lv.p[i];
+    const int Wl = lv.w[i];
+    const float wmax = (float)(Wl - 1);
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npix;
          t += (long long)gridDim.x * blockDim.x) {
         const long long b = t / HW, p = t - b * HW;
-        const float x = coords[(size_t)b * 2 * HW + p];
-        float *o = out + (size_t)b * (size_t)(L * T) * HW + p;
-        for (int i = 0; i < L; ++i) {
-            const float *row = lv.p[i] + (size_t)t * lv.w[i];
-            const float xl = x / (float)(1 << i);
-            for (int k = 0; k < T; ++k)
-                o[(size_t)(i * T + k) * HW] = lerp_zero_pad_ac(row, lv.w[i], __fadd_rn((float)(k - r), xl));
+        const float xl = coords[(size_t)b * 2 * HW + p] / (float)(1 << i);
+        const float *row = base + (size_t)t * Wl;
+        float *o = out + ((size_t)b * (size_t)(L * T) + (size_t)i * T) * HW + p;
+        if (R > 0) {
+            float v0[2 * R + 1], v1[2 * R + 1], w0[2 * R + 1], w1[2 * R + 1];
+#pragma unroll
+            for (int k = 0; k < 2 * R + 1; ++k) {
+                // bilinear_sampler's normalise (utils/utils.py:64-66) + grid_sample's align_corners=True un-normalise
+                const float x = __fadd_rn((float)(k - R), xl);
+                const float xg = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, x), wmax), 1.0f);
+                const float ix = __fmul_rn(__fdiv_rn(__fadd_rn(xg, 1.0f), 2.0f), wmax);
+                const float fx = floorf(ix);
+                const float a = ix - fx;
+                const bool ok0 = fx >= 0.0f && fx <= wmax, ok1 = fx + 1.0f >= 0.0f && fx + 1.0f <= wmax;
+                const int i0 = (int)fminf(fmaxf(fx, 0.0f), wmax), i1 = (int)fminf(fmaxf(fx + 1.0f, 0.0f), wmax);
+                v0[k] = row[i0];
+                v1[k] = row[i1];
+                w0[k] = ok0 ? 1.0f - a : 0.0f;
+                w1[k] = ok1 ? a : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < 2 * R + 1; ++k) o[(size_t)k * HW] = v0[k] * w0[k] + v1[k] * w1[k];
+        } else {
+            for (int k = 0; k < T; ++k) o[(size_t)k * HW] = lerp_zero_pad_ac(row, Wl, __fadd_rn((float)(k - r), xl));
         }
     }
 }
@@ -356,8 +382,13 @@ extern "C" int stereo_corr_lookup_f32(const float *const *levels, const float *c
         lv.w[i] = w;
     }
     const long long HW = (long long)H * W1, n = (long long)B * HW;
-    hipLaunchKernelGGL(corr_lookup_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), lv, coords, out,
-                       num_levels, radius, HW, n);
+    const dim3 grid(grid_for(n), (unsigned)num_levels);
+    if (radius == 4)
+        hipLaunchKernelGGL(corr_lookup_kernel<4>, grid, dim3(256), 0, as_stream(stream), lv, coords, out, num_levels,
+                           radius, HW, n);
+    else
+        hipLaunchKernelGGL(corr_lookup_kernel<0>, grid, dim3(256), 0, as_stream(stream), lv, coords, out, num_levels,
+                           radius, HW, n);
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }

@@ -112,6 +112,94 @@ __global__ __launch_bounds__(256) void soft_argmin_kernel(const float *__restric
     }
 }
 
+// A4 with probabilities, single pass: the whole softmax column lives in registers.  A workgroup of NWV waves owns
+// 64/SPLIT pixel quads (16 B each); the D planes are dealt round-robin to NWV*SPLIT "phases" -- phase = wave * SPLIT +
+// lane / (64/SPLIT) -- and every lane keeps its J planes of one quad (D <= NWV*SPLIT*J).  A wave load / store covers
+// SPLIT segments of 1024/SPLIT contiguous bytes.  All J loads are issued before the first use, the running max / sums
+// are combined across the phases through LDS (two barriers), and the normalised probabilities are written straight
+// from the registers: the volume is read once and the probabilities written once.  Small workgroups (4 waves) so
+// that several are resident per CU and one's load phase overlaps another's store phase.
+template <int J, int NWV, int SPLIT>
+__global__ __launch_bounds__(NWV * 64) void soft_argmin_prob_regs_kernel(const float *__restrict__ vol,
+                                                                         float *__restrict__ disp,
+                                                                         float *__restrict__ prob, int D, long long HW,
+                                                                         float sgn)
+{
+    constexpr int QPW = 64 / SPLIT, NPH = NWV * SPLIT;
+    __shared__ float red[3][NPH][QPW * 4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ph = wave * SPLIT + lane / QPW, ql = lane % QPW;
+    const long long p = ((long long)blockIdx.x * QPW + ql) * 4;
+    const bool okp = p < HW;  // HW % 4 == 0: a quad is entirely in or out
+    const size_t boff = (size_t)blockIdx.y * D * HW + (okp ? p : 0);
+    const float *v = vol + boff;
+    f32x4 x[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int d = ph + NPH * j;
+        if (okp && d < D) {
+            const f32x4 r = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(v + (size_t)d * HW));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[j][i] = sgn * r[i];
+        } else {
+            x[j] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+    }
+    float m[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float mm = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < J; ++j) mm = fmaxf(mm, x[j][i]);
+        red[0][ph][ql * 4 + i] = mm;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float mm = red[0][0][ql * 4 + i];
+#pragma unroll
+        for (int k = 1; k < NPH; ++k) mm = fmaxf(mm, red[0][k][ql * 4 + i]);
+        m[i] = (mm == -INFINITY) ? 0.0f : mm;  // out-of-range quad: keep the arithmetic finite
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float ss = 0.0f, ee = 0.0f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const float e = fast_exp(x[j][i] - m[i]);  // -inf -> 0
+            x[j][i] = e;
+            ss += e;
+            ee = fmaf(e, (float)(ph + NPH * j), ee);
+        }
+        red[1][ph][ql * 4 + i] = ss;
+        red[2][ph][ql * 4 + i] = ee;
+    }
+    __syncthreads();
+    float inv[4];
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float S = 0.0f, E = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NPH; ++k) S += red[1][k][ql * 4 + i], E += red[2][k][ql * 4 + i];
+        inv[i] = 1.0f / S;
+        o[i] = E / S;
+    }
+    if (!okp) return;
+    if (ph == 0) st4(disp + (size_t)blockIdx.y * HW + p, o);
+    float *pr = prob + boff;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int d = ph + NPH * j;
+        if (d < D) {
+            f32x4 q;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = x[j][i] * inv[i];
+            st4(pr + (size_t)d * HW, q);
+        }
+    }
+}
+
 // volg [B, G, D, HW] -> mean over G -> (vol_mean [B, D, HW]) -> disp [B, HW]
 template <int V, int U, bool WRITE_MEAN, bool NT>
 __global__ __launch_bounds__(256) void group_mean_soft_argmin_kernel(const float *__restrict__ volg,
@@ -224,7 +312,19 @@ extern "C" int stereo_soft_argmin_f32(const float *vol, float *disp, float *prob
     const bool vec = (HW % 4 == 0) && aligned16(vol) && aligned16(disp) && (prob == nullptr || aligned16(prob));
     if (vec) {
         const long long n = (long long)B * (HW / 4);
-        if (prob)
+        if (prob && D <= 192 && fits_grid_yz(B) && !getenv("STEREO_PROB_TWOPASS")) {
+            int cfg = 0;  // dev knob: 1 forces the 8-wave / 1 KiB-segment shape for D > 96
+            if (const char *e = getenv("STEREO_PROB_CFG")) cfg = atoi(e);
+#define PROB_LAUNCH(JV, NWVV, SPL)                                                                                   \
+    hipLaunchKernelGGL((soft_argmin_prob_regs_kernel<JV, NWVV, SPL>),                                                \
+                       dim3((unsigned)((HW / 4 + 64 / SPL - 1) / (64 / SPL)), (unsigned)B), dim3(NWVV * 64), 0, st, \
+                       vol, disp, prob, D, HW, sgn)
+            if (D <= 48) PROB_LAUNCH(12, 4, 1);
+            else if (D <= 96) PROB_LAUNCH(24, 4, 1);
+            else if (cfg == 1) PROB_LAUNCH(24, 8, 1);
+            else PROB_LAUNCH(24, 4, 2);
+#undef PROB_LAUNCH
+        } else if (prob)
             hipLaunchKernelGGL((soft_argmin_kernel<4, 8, true>), dim3(grid_for(n)), dim3(256), 0, st, vol, disp, prob, D,
                                HW, n, sgn);
         else

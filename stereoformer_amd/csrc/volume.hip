@@ -846,6 +846,52 @@ __global__ __launch_bounds__(256) void shift_volume_kernel(const float *__restri
     }
 }
 
+// Fast path (W % 4 == 0, 16-B aligned): a workgroup writes whole rows of DS consecutive disparity planes of one
+// (b, c, h).  Each lane keeps its left quad and a (DS+4)-float right window in registers (five aligned 16-B loads,
+// L2 hits: the features are ~1000x smaller than the volume), so the kernel is a pure row-contiguous store stream.
+template <bool CONCAT, int DS>
+__global__ __launch_bounds__(256) void shift_volume_rows_kernel(const float *__restrict__ L,
+                                                                const float *__restrict__ R, float *__restrict__ vol,
+                                                                int C, int H, int W, int D)
+{
+    const int Cout = CONCAT ? 2 * C : C;
+    const int h = blockIdx.y, bc = blockIdx.z;
+    const int b = bc / Cout, c = bc - b * Cout;
+    const int cs = (CONCAT && c >= C) ? c - C : c;
+    const bool left_copy = CONCAT && c < C;  // workgroup-uniform
+    const size_t HW = (size_t)H * W;
+    const float *lrow = L + (((size_t)b * C + cs) * H + h) * (size_t)W;
+    const float *rrow = R + (((size_t)b * C + cs) * H + h) * (size_t)W;
+    const int d0 = blockIdx.x * DS;
+    float *dst0 = vol + ((size_t)bc * D + d0) * HW + (size_t)h * W;
+    for (int w = threadIdx.x * 4; w < W; w += 1024) {
+        f32x4 lv = {0.f, 0.f, 0.f, 0.f};
+        if (!CONCAT || left_copy) lv = ld4(lrow + w);
+        float win[DS + 4];  // win[k] = R[w - d0 - DS + k]; the quad of plane d0+dd is win[DS-dd .. DS-dd+3]
+        if (!left_copy) {
+            const int base = w - d0 - DS;  // multiple of 4: every quad is entirely in or out of the row
+#pragma unroll
+            for (int q = 0; q < DS / 4 + 1; ++q) {
+                const f32x4 t = (base + 4 * q >= 0) ? ld4(rrow + base + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                win[4 * q + 0] = t[0], win[4 * q + 1] = t[1], win[4 * q + 2] = t[2], win[4 * q + 3] = t[3];
+            }
+        }
+#pragma unroll
+        for (int dd = 0; dd < DS; ++dd) {
+            const int d = d0 + dd;
+            if (d < D) {
+                f32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = left_copy ? lv[i] : (CONCAT ? win[DS - dd + i] : lv[i] - win[DS - dd + i]);
+                    o[i] = (w + i >= d) ? v : 0.0f;
+                }
+                st4(dst0 + (size_t)dd * HW + w, o);
+            }
+        }
+    }
+}
+
 template <bool CONCAT>
 int shift_dispatch(const float *L, const float *R, float *vol, int B, int C, int H, int W, int D, void *stream)
 {
@@ -854,6 +900,14 @@ int shift_dispatch(const float *L, const float *R, float *vol, int B, int C, int
     STEREO_REQUIRE_PTR(L);
     STEREO_REQUIRE_PTR(R);
     STEREO_REQUIRE_PTR(vol);
+    const long long BC = (long long)B * (CONCAT ? 2 * C : C);
+    if (W % 4 == 0 && aligned16(L) && aligned16(R) && aligned16(vol) && fits_grid_yz(H) && fits_grid_yz(BC)) {
+        constexpr int DS = 16;
+        hipLaunchKernelGGL((shift_volume_rows_kernel<CONCAT, DS>), dim3((unsigned)((D + DS - 1) / DS), H, (unsigned)BC),
+                           dim3(256), 0, as_stream(stream), L, R, vol, C, H, W, D);
+        STEREO_LAUNCH_CHECK();
+        return STEREO_OK;
+    }
     const long long nquads = (long long)B * (CONCAT ? 2 * C : C) * D * H * ((W + 3) / 4);
     long long blocks = (nquads + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;

@@ -72,7 +72,7 @@ def main():
         if want("A4_soft_argmin"):
             add("A4_soft_argmin cfg-2", timeit(lambda: S.DisparityEstimation(D)(vol), args.reps), (N * D * 4 + N * 4) / 1e9)
             add("A4_soft_argmin_with_prob cfg-2", timeit(lambda: S.DisparityEstimationWithProb(D)(vol), args.reps),
-                (2 * N * D * 4 + N * 4) / 1e9, note="1 read + 1 write algorithmic; the re-read is cache traffic")
+                (2 * N * D * 4 + N * 4) / 1e9, note="single pass: softmax column held in registers (1 read + 1 write)")
         disp = S.DisparityEstimation(D)(vol).unsqueeze(1)
         if want("A5_local_lookup"):
             add("A5_local_lookup r=2 S=20 cfg-2", timeit(lambda: S.LocalCostVolume(2, 20)(vol, disp, True), args.reps),
