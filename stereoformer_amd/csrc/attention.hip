@@ -594,6 +594,170 @@ __global__ __launch_bounds__(A2_NT) void cross_attention_pipe_kernel(const float
     }
 }
 
+// ---------------------------------------------------------------------------
+// v4: scores never leave the registers.  One wave owns 32 queries of a row; a workgroup is A4_NW such waves over
+// consecutive queries sharing ONE LDS tile of keys (32 channels x (32*A4_NW + Dk) keys, odd row stride).
+//   phase 1  S^T tile t (32 keys x 32 queries) = K_t Q^T on v_mfma_f32_32x32x2_f32: A = K from LDS (lanes = keys),
+//            B = Q straight from global (lanes = queries, 128-B coalesced per channel row); NT = Dk/32 + 1 key tiles
+//            cover the band of a 32-query tile, all NT accumulators (16 VGPRs each) stay live.
+//   phase 2  exact two-pass softmax over the lane's 16*NT scores of its query (column j = lane & 31); the two lane
+//            halves hold the two halves of every key tile, so one xor-32 exchange per reduction.
+//   phase 3  O^T (32 channels x 32 queries) = V^T P: the MFMA contracts over two keys per step and the order of the
+//            contraction is free, so step s takes key (s&3)+8(s>>2) from lane half 0 and that key + 4 from half 1 --
+//            which is exactly how the accumulator layout holds them.  The probabilities therefore feed the B
+//            operand directly from the phase-1 accumulators: no LDS score sheet, no skew transform, no barriers.
+// With V == K (value = right features, C <= 32) the workgroup stages one tile and runs barrier-free after it; LDS is
+// ~41 KB (Dk = 192), so several workgroups share a CU and one's staging / softmax overlaps another's MFMA phases.
+constexpr int A4_NW = 4;
+constexpr int A4_TQ = 32 * A4_NW;
+
+template <int NT, int MINW>
+__global__ __launch_bounds__(A4_NW * 64, MINW) void cross_attention_reg_kernel(const float *__restrict__ L,
+                                                                         const float *__restrict__ R,
+                                                                         const float *__restrict__ V,
+                                                                         float *__restrict__ out,
+                                                                         float *__restrict__ disp, int C, int Cv, int H,
+                                                                         int W, int D, int mask_mode, float scale,
+                                                                         int same_kv)
+{
+    constexpr int Dk = 32 * (NT - 1);
+    constexpr int NK = A4_TQ + Dk;               // keys in the tile
+    constexpr int KS = NK + 1;                   // odd row stride: conflict-free for lanes = keys AND lanes = channels
+    constexpr int NQD = 32 * (NK / 4);           // 16-B quads per staged 32-channel chunk
+    constexpr int NTH = A4_NW * 64;
+    constexpr int NSL = (NQD + NTH - 1) / NTH;
+    __shared__ float Ks[32 * KS];
+
+    const int w0 = blockIdx.x * A4_TQ, h = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const size_t HW = (size_t)H * W;
+    const int kbase = w0 - Dk;                   // image column of LDS column 0 (multiple of 4)
+    const int q = w0 + 32 * wave + l31;          // this lane's query
+    const bool wave_active = w0 + 32 * wave < W; // wave-uniform
+
+    auto stage = [&](const float *__restrict__ src, int nch, int c0) {  // channels c0..c0+31 of row h -> Ks
+        const float *base = src + ((size_t)b * nch + c0) * HW + (size_t)h * W;
+        f32x4 rk[NSL];
+        unsigned okm = 0;
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) {
+            const int qi = tid + k * NTH;
+            const int row = qi / (NK / 4), xq = qi - row * (NK / 4);
+            const int w = kbase + 4 * xq;
+            const bool ok = qi < NQD && c0 + row < nch && w >= 0 && w + 3 < W;
+            rk[k] = ld4(base + (ok ? (size_t)row * HW + w : 0));
+            okm |= ok ? (1u << k) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) {
+            const int qi = tid + k * NTH;
+            if (qi < NQD) {
+                const int row = qi / (NK / 4), xq = qi - row * (NK / 4);
+                const bool ok = (okm >> k) & 1u;
+                float *d = Ks + row * KS + 4 * xq;
+                d[0] = ok ? rk[k][0] : 0.0f;
+                d[1] = ok ? rk[k][1] : 0.0f;
+                d[2] = ok ? rk[k][2] : 0.0f;
+                d[3] = ok ? rk[k][3] : 0.0f;
+            }
+        }
+    };
+
+    // ---------------- phase 1: S^T = K Q^T, accumulated over 32-channel chunks
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    for (int c0 = 0; c0 < C; c0 += 32) {
+        if (c0 > 0) __syncthreads();             // the previous chunk's readers are done
+        stage(R, C, c0);
+        float qv[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int c = c0 + 2 * s + half;
+            qv[s] = (c < C && q < W) ? L[((size_t)b * C + c) * HW + (size_t)h * W + q] : 0.0f;
+        }
+        __syncthreads();
+        if (wave_active) {
+            const float *kp = Ks + half * KS + 32 * wave + l31;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s * KS + 32 * t], qv[s], acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---------------- phase 2: masked softmax over the band, in registers
+    // accumulator element r of tile t: key row i = (r&3) + 8*(r>>2) + 4*half, disparity d = Dk - 32 t + l31 - i
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = Dk - 32 * t + l31 - ((r & 3) + 8 * (r >> 2) + 4 * half);
+            float v = acc[t][r] * scale;
+            if (d < 0 || d >= D) v = -INFINITY;
+            else if (q - d < 0) v = mask_mode == STEREO_MASK_ZERO ? 0.0f : -INFINITY;
+            acc[t][r] = v;
+            m = fmaxf(m, v);
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));             // d = 0 is always in the band: m is finite
+    float ssum = 0.0f, esum = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = Dk - 32 * t + l31 - ((r & 3) + 8 * (r >> 2) + 4 * half);
+            const float pexp = fast_exp(acc[t][r] - m);
+            acc[t][r] = pexp;
+            ssum += pexp;
+            esum = fmaf(pexp, (float)d, esum);
+        }
+    }
+    ssum += __shfl_xor(ssum, 32);
+    esum += __shfl_xor(esum, 32);
+    const float inv = 1.0f / ssum;
+    if (disp && half == 0 && q < W) disp[((size_t)b * H + h) * W + q] = esum * inv;
+    if (out == nullptr) return;                  // workgroup-uniform
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] *= inv;
+
+    // ---------------- phase 3: O^T = V^T P, 32 value channels per round
+    for (int c0 = 0; c0 < Cv; c0 += 32) {
+        if (!(same_kv && c0 == 0 && C <= 32)) {  // otherwise the K tile in LDS already is the value tile
+            __syncthreads();
+            stage(V, Cv, c0);
+            __syncthreads();
+        }
+        if (wave_active) {
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+            const float *vp = Ks + l31 * KS + 32 * wave + 4 * half;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    o = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * t + (s & 3) + 8 * (s >> 2)], acc[t][s], o, 0, 0, 0);
+            }
+            if (q < W) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = c0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (c < Cv) out[((size_t)b * Cv + c) * HW + (size_t)h * W + q] = o[r];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int stereo_cross_attention_f32(const float *left, const float *right, const float *value, float *out,
@@ -609,6 +773,27 @@ extern "C" int stereo_cross_attention_f32(const float *left, const float *right,
     if (out) STEREO_REQUIRE_PTR(value);
     if (D == 0 || C == 0) return STEREO_ERR_BAD_SHAPE;
     if (!fits_grid_yz(H) || !fits_grid_yz(B)) return STEREO_ERR_UNSUPPORTED;
+    {   // v4: register-resident scores (aligned, W % 4 == 0, band <= 256 after rounding up to a multiple of 32)
+        const bool vec = (W % 4 == 0) && aligned16(left) && aligned16(right) && (out == nullptr || aligned16(value));
+        const char *v4off = getenv("STEREO_ATT_V3");
+        const char *v2on = getenv("STEREO_ATT_V2");
+        if (vec && D <= 256 && !(v4off && v4off[0] == '1') && !(v2on && v2on[0] == '1')) {
+            const int nt = (D + 31) / 32 + 1;
+            const float sc = scale_mode == STEREO_SCALE_MEAN ? 1.0f / (float)C : 1.0f / sqrtf((float)C);
+            const int same_kv = (out != nullptr && value == right && Cv == C) ? 1 : 0;
+            dim3 grid4((W + A4_TQ - 1) / A4_TQ, H, B);
+#define ATT4(NTV)                                                                                                      \
+    hipLaunchKernelGGL((cross_attention_reg_kernel<NTV, (NTV <= 7 ? 2 : 1)>), grid4, dim3(A4_NW * 64), 0, as_stream(stream), left, right, value, \
+                       out, disp, C, Cv, H, W, D, mask_mode, sc, same_kv)
+            if (nt <= 3) ATT4(3);
+            else if (nt <= 5) ATT4(5);
+            else if (nt <= 7) ATT4(7);
+            else ATT4(9);
+#undef ATT4
+            STEREO_LAUNCH_CHECK();
+            return STEREO_OK;
+        }
+    }
     {   // v3: row-pipelined MFMA path (aligned, W % 4 == 0, one 32-channel chunk each side)
         const int Dk = (D + 31) / 32 * 32;
         const bool vec = (W % 4 == 0) && aligned16(left) && aligned16(right) && (out == nullptr || aligned16(value));

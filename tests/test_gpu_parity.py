@@ -328,9 +328,11 @@ def test_resize_vs_oracle(S, oracle, golden):
 @pytest.mark.parametrize("cfg", [(2, 16, 5, 40, 12), (1, 32, 3, 200, 192), (1, 48, 2, 70, 33), (1, 40, 2, 300, 230),
                                  (1, 256, 2, 312, 64), (1, 8, 1, 64, 1), (1, 32, 1, 130, 352), (1, 20, 1, 96, 32),
                                  (2, 32, 3, 960, 192), (1, 24, 2, 516, 250)])
-@pytest.mark.parametrize("force_v2", ["0", "1"])
-def test_cross_attention(S, oracle, cfg, force_v2, monkeypatch):
-    monkeypatch.setenv("STEREO_ATT_V2", force_v2)   # "1": per-tile MFMA kernel; "0": row-pipelined MFMA kernel when eligible
+@pytest.mark.parametrize("variant", ["v4", "v3", "v2"])
+def test_cross_attention(S, oracle, cfg, variant, monkeypatch):
+    # v4 (default): scores stay in registers; v3: row-pipelined LDS score sheet; v2: per-tile MFMA kernel
+    monkeypatch.setenv("STEREO_ATT_V3", "1" if variant == "v3" else "0")
+    monkeypatch.setenv("STEREO_ATT_V2", "1" if variant == "v2" else "0")
     B, C, H, W, D = cfg
     rng = np.random.default_rng(29)
     L = rng.standard_normal((B, C, H, W), dtype=np.float32)
@@ -344,6 +346,11 @@ def test_cross_attention(S, oracle, cfg, force_v2, monkeypatch):
             # fp32 logit-accumulation noise is amplified by the spread of d: the mean-error budget grows
             # with D (tools/accuracy_probe.py: the oracle itself sits 5e-5 from fp64 truth at D=352)
             close(d, od, rtol=0, atol=1e-3, mean_atol=2.5e-4 * max(1.0, D / 192.0))
+    # value defaults to the right features (one staged tile serves as K and V when C <= 32)
+    o, d = S.CrossAttentionCostVolume(D, "neginf", "sqrt_c")(dev(L), dev(R))
+    oo, od = oracle.cross_attention(L, R, None, D, "neginf", "sqrt_c")
+    close(o, oo, rtol=1e-4, atol=5e-5)
+    close(d, od, rtol=0, atol=1e-3, mean_atol=2.5e-4 * max(1.0, D / 192.0))
     # I3: mask='zero', scale='mean' reproduces CostVolume + DisparityEstimation of the HIP path itself
     _, d = S.CrossAttentionCostVolume(D, "zero", "mean")(dev(L), dev(R), need_out=False)
     close(d, host(S.DisparityEstimation(D)(S.CostVolume(D)(dev(L), dev(R)))), **DISP_TOL)
