@@ -758,6 +758,212 @@ __global__ __launch_bounds__(A4_NW * 64, MINW) void cross_attention_reg_kernel(c
     }
 }
 
+// ---------------------------------------------------------------------------
+// v5: v4 with an ONLINE softmax and a persistent, prefetching workgroup, for C <= 32 and value == right features (one
+// LDS tile is K and V).  The key tiles of a wave's band are visited one at a time, nearest first: 16 MFMAs give the
+// 32x32 score tile, the running maximum is updated (one xor-32 exchange), the output accumulator and the running sums
+// are rescaled, and the tile's probabilities go straight back into 16 MFMAs of P V.  Only one score tile is live
+// (~110 VGPRs instead of 256).  Exponentials in base 2 with log2(e) and the logit scale folded into Q; the disparity
+// expectation uses sum p*d = cb * sum p - sum p * i_r (i_r a per-register constant).
+//
+// Measured on MI355X (tools/mfma_coexec.hip, and by switching the phases of this kernel off one at a time): f32 MFMA
+// and VALU work do NOT overlap on a SIMD, not even across waves, and the kernel's time is the plain sum of its phases
+// -- operand fetch (K tile + Q, ~1.5 GB at HBM/L2 speed), QK MFMAs, softmax VALU, PV MFMAs.  So (1) every VALU
+// instruction is paid in MFMA time: packed f32 math, no index divisions, one compare + select per masked score;
+// (2) the fetch phase has to be hidden explicitly: a workgroup walks `tiles_per_wg` consecutive query tiles of the
+// image (row-major, so the 192-key halo it re-reads was fetched by itself a moment ago and sits in L2) and the K
+// quads and Q values of the NEXT tile are loaded into registers before the current tile's MFMAs start; they are
+// committed to LDS between two barriers once every wave is done with the current tile.
+template <int NT, int NWV>
+__global__ __launch_bounds__(NWV * 64) void cross_attention_online_kernel(const float *__restrict__ L,
+                                                                          const float *__restrict__ R,
+                                                                          float *__restrict__ out,
+                                                                          float *__restrict__ disp, int C, int H, int W,
+                                                                          int D, int mask_mode, float scale,
+                                                                          int tiles_per_wg, int ntiles)
+{
+    constexpr int Dk = 32 * (NT - 1);
+    constexpr int TQW = 32 * NWV;                // queries per workgroup tile
+    constexpr int NK = TQW + Dk;                 // keys in the tile (multiple of 32)
+    constexpr int KS = NK + 4;                   // row stride: 16-B aligned rows, KS/4 odd (K reads conflict-free,
+                                                 // V reads 2-way at worst -- 4 LDS cycles under a 64-cycle MFMA)
+    constexpr int RMAX = (32 + NWV - 1) / NWV;   // staged rows per wave (row = wave, wave + NWV, ...)
+    constexpr int NPASS = (NK / 4 + 63) / 64;    // 16-B quads per lane and row
+    __shared__ f32x4 Ks4[32 * KS / 4];
+    float *Ks = reinterpret_cast<float *>(Ks4);
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const unsigned HWu = (unsigned)H * (unsigned)W;  // launcher: 32 * H * W < 2^31, the lane offsets below fit 32 bits
+    const int nx = (W + TQW - 1) / TQW;
+    const float sc2 = scale * 1.44269504088896340736f;  // logits in units of log2, folded into Q
+    const int dl = l31 - 4 * half;                      // d = (Dk - 32 t + dl) - i_r
+    const float *kp = Ks + half * KS + 32 * wave + l31;
+    const float *vp = Ks + l31 * KS + 32 * wave + 4 * half;
+
+    int tile = blockIdx.x * tiles_per_wg;
+    const int tile_end = (tile + tiles_per_wg < ntiles) ? tile + tiles_per_wg : ntiles;
+    if (tile >= tile_end) return;
+
+    f32x4 rk[RMAX][NPASS];
+    float qn[16];
+    unsigned okbits = 0;  // validity of the prefetched quads, applied at commit time (keeps the loads in flight)
+    auto issue = [&](int tl) {  // K quads and Q values of tile tl -> registers
+        const int x = tl % nx, bh = tl / nx;  // bh = b * H + h
+        const int hh = bh % H, bb = bh / H;
+        const int w0 = x * TQW, kbase = w0 - Dk;
+        const float *Rb = R + ((size_t)bb * C * HWu + (size_t)hh * W);  // workgroup-uniform bases
+        const float *Lb = L + ((size_t)bb * C * HWu + (size_t)hh * W);
+        okbits = 0;
+#pragma unroll
+        for (int pp = 0; pp < NPASS; ++pp) {
+            const int w = kbase + 4 * (lane + 64 * pp);
+            if (lane + 64 * pp < NK / 4 && w >= 0 && w + 3 < W) okbits |= 1u << pp;
+        }
+#pragma unroll
+        for (int rr = 0; rr < RMAX; ++rr) {
+            const int row = wave + rr * NWV;  // wave-uniform
+#pragma unroll
+            for (int pp = 0; pp < NPASS; ++pp) {
+                const bool ok = ((okbits >> pp) & 1u) && row < C && row < 32;
+                rk[rr][pp] = ld4(Rb + (ok ? (unsigned)row * HWu + (unsigned)(kbase + 4 * (lane + 64 * pp)) : 0u));
+            }
+        }
+        const int q = w0 + 32 * wave + l31;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int c = 2 * s + half;
+            qn[s] = Lb[(c < C && q < W) ? (unsigned)c * HWu + (unsigned)q : 0u];
+        }
+    };
+    auto commit = [&]() {  // registers -> the LDS tile; one ds_write_b128 per quad
+#pragma unroll
+        for (int rr = 0; rr < RMAX; ++rr) {
+            const int row = wave + rr * NWV;
+            if (row < 32) {
+#pragma unroll
+                for (int pp = 0; pp < NPASS; ++pp) {
+                    if (lane + 64 * pp < NK / 4)
+                        Ks4[(row * KS) / 4 + lane + 64 * pp] =
+                            (((okbits >> pp) & 1u) && row < C) ? rk[rr][pp] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    };
+
+    issue(tile);
+    commit();
+    float qv[16];
+    for (;;) {
+        const int x = tile % nx, bh = tile / nx;
+        const int w0 = x * TQW, kbase = w0 - Dk;
+        const int q = w0 + 32 * wave + l31;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int c = 2 * s + half;
+            qv[s] = (c < C && q < W) ? qn[s] * sc2 : 0.0f;
+        }
+        __syncthreads();  // the tile is visible
+        const bool more = tile + 1 < tile_end;
+        if (more) issue(tile + 1);  // lands under this tile's MFMAs
+
+        if (w0 + 32 * wave < W) {  // wave-uniform
+            const bool neg_left = mask_mode == STEREO_MASK_NEGINF && kbase < 0;  // workgroup-uniform
+            float m = -INFINITY, ssum = 0.0f, esc = 0.0f;
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+#pragma unroll 1
+            for (int t = NT - 1; t >= 0; --t) {  // nearest keys first: the d = 0 key makes the maximum finite at once
+                // (a real loop: unrolled, the compiler hoists every tile's LDS operands and the occupancy is gone)
+                f32x16 a;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+                const float *kpt = kp + 32 * t;
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    a = __builtin_amdgcn_mfma_f32_32x32x2f32(kpt[2 * s * KS], qv[s], a, 0, 0, 0);
+                const int cb = Dk - 32 * t + dl;  // d of register r = cb - i_r,  i_r = (r&3) + 8*(r>>2)
+                // tile t holds d in [Dk - 32 t - 31, Dk - 32 t + 31]: only the band's end tiles can leave [0, D)
+                // (wave-uniform tests); i_r is a compile-time constant, so a check is one compare + one select.
+                // Out-of-image keys need nothing in 'zero' mode: the tile is zero-padded, their logit is 0.
+                if (t == NT - 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (cb < (r & 3) + 8 * (r >> 2)) a[r] = -INFINITY;  // d < 0
+                }
+                if (Dk - 32 * t + 31 >= D) {
+                    const int lim = cb - D;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (lim >= (r & 3) + 8 * (r >> 2)) a[r] = -INFINITY;  // d >= D
+                }
+                if (neg_left) {
+                    const int lim = cb - q;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (lim > (r & 3) + 8 * (r >> 2)) a[r] = -INFINITY;  // key = q - d < 0
+                }
+                float mt = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) mt = fmaxf(mt, fmaxf(a[r], a[r + 1]));  // v_max3_f32
+                mt = fmaxf(mt, __shfl_xor(mt, 32));
+                const float mn = fmaxf(m, mt);
+                const float alpha = __builtin_amdgcn_exp2f(m - mn);  // first tile: exp2(-inf) = 0 on zeros
+                m = mn;
+                const f32x2 nm = {-mn, -mn};
+                f32x2 T2 = {0.0f, 0.0f}, U2 = {0.0f, 0.0f};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {  // register pairs: v_pk_add / v_pk_fma, two scores per issue
+                    const f32x2 sh = (f32x2){a[2 * k], a[2 * k + 1]} + nm;
+                    const f32x2 pe = {__builtin_amdgcn_exp2f(sh[0]), __builtin_amdgcn_exp2f(sh[1])};
+                    a[2 * k] = pe[0];
+                    a[2 * k + 1] = pe[1];
+                    T2 += pe;
+                    const float base = (float)(2 * (k & 1) + 8 * (k >> 1));  // i_r of the pair = base, base + 1
+                    U2 = __builtin_elementwise_fma(pe, (f32x2){base, base}, U2);
+                }
+                const float ts = T2[0] + T2[1], ti = U2[0] + U2[1] + T2[1];
+                ssum = fmaf(ssum, alpha, ts);
+                esc = fmaf(esc, alpha, fmaf((float)cb, ts, -ti));  // sum p*d = cb * sum p - sum p*i_r
+                if (out) {
+                    const f32x2 al2 = {alpha, alpha};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const f32x2 ov = (f32x2){o[2 * k], o[2 * k + 1]} * al2;
+                        o[2 * k] = ov[0];
+                        o[2 * k + 1] = ov[1];
+                    }
+                    const float *vpt = vp + 32 * t;
+#pragma unroll
+                    for (int s = 0; s < 16; ++s)
+                        o = __builtin_amdgcn_mfma_f32_32x32x2f32(vpt[(s & 3) + 8 * (s >> 2)], a[s], o, 0, 0, 0);
+                }
+            }
+            float e = esc;  // dl is already folded into cb
+            ssum += __shfl_xor(ssum, 32);
+            e += __shfl_xor(e, 32);
+            const float inv = 1.0f / ssum;
+            if (q < W) {
+                if (disp && half == 0) disp[(size_t)bh * W + q] = e * inv;
+                if (out) {
+                    const int hh = bh % H, bb = bh / H;
+                    float *ob = out + ((size_t)bb * C * HWu + (size_t)hh * W);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (c < C) ob[(unsigned)c * HWu + (unsigned)q] = o[r] * inv;
+                    }
+                }
+            }
+        }
+        if (!more) break;
+        __syncthreads();  // every wave is done reading the tile
+        commit();
+        ++tile;
+    }
+}
+
 }  // namespace
 
 extern "C" int stereo_cross_attention_f32(const float *left, const float *right, const float *value, float *out,
@@ -782,6 +988,36 @@ extern "C" int stereo_cross_attention_f32(const float *left, const float *right,
             const float sc = scale_mode == STEREO_SCALE_MEAN ? 1.0f / (float)C : 1.0f / sqrtf((float)C);
             const int same_kv = (out != nullptr && value == right && Cv == C) ? 1 : 0;
             dim3 grid4((W + A4_TQ - 1) / A4_TQ, H, B);
+            const char *v5off = getenv("STEREO_ATT_V4");
+            if (C <= 32 && (out == nullptr || same_kv) && (long long)32 * H * W < (1LL << 31) &&
+                !(v5off && v5off[0] == '1')) {  // v5: online softmax
+                // waves (32 queries each) per workgroup: 8 (256 queries, the halo is re-fetched 1.75x) unless the row
+                // is so short that half of them would idle.  (6 waves = 192 queries divides W = 960 exactly but
+                // measured slower: its register budget admits a single 6-wave workgroup per CU.)
+                int nwv = W > 128 ? 8 : 4;
+                if (const char *e = getenv("STEREO_ATT_NW")) nwv = atoi(e) == 8 ? 8 : 4;
+                // persistent workgroups: two resident per CU walk contiguous runs of tiles (row-major)
+                const int ntl = ((W + 32 * nwv - 1) / (32 * nwv)) * H * B;
+                int tpw = (ntl + 511) / 512;
+                if (const char *e = getenv("STEREO_ATT_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;
+                const int nwg = (ntl + tpw - 1) / tpw;
+#define ATT5N(NTV, NWVV)                                                                                               \
+    hipLaunchKernelGGL((cross_attention_online_kernel<NTV, NWVV>), dim3(nwg), dim3(NWVV * 64), 0, as_stream(stream), left, \
+                       right, out, disp, C, H, W, D, mask_mode, sc, tpw, ntl)
+#define ATT5(NTV)                    \
+    do {                             \
+        if (nwv == 8) ATT5N(NTV, 8); \
+        else ATT5N(NTV, 4);          \
+    } while (0)
+                if (nt <= 3) ATT5(3);
+                else if (nt <= 5) ATT5(5);
+                else if (nt <= 7) ATT5(7);
+                else ATT5(9);
+#undef ATT5N
+#undef ATT5
+                STEREO_LAUNCH_CHECK();
+                return STEREO_OK;
+            }
 #define ATT4(NTV)                                                                                                      \
     hipLaunchKernelGGL((cross_attention_reg_kernel<NTV, (NTV <= 7 ? 2 : 1)>), grid4, dim3(A4_NW * 64), 0, as_stream(stream), left, right, value, \
                        out, disp, C, Cv, H, W, D, mask_mode, sc, same_kv)

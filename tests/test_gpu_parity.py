@@ -328,9 +328,11 @@ def test_resize_vs_oracle(S, oracle, golden):
 @pytest.mark.parametrize("cfg", [(2, 16, 5, 40, 12), (1, 32, 3, 200, 192), (1, 48, 2, 70, 33), (1, 40, 2, 300, 230),
                                  (1, 256, 2, 312, 64), (1, 8, 1, 64, 1), (1, 32, 1, 130, 352), (1, 20, 1, 96, 32),
                                  (2, 32, 3, 960, 192), (1, 24, 2, 516, 250)])
-@pytest.mark.parametrize("variant", ["v4", "v3", "v2"])
+@pytest.mark.parametrize("variant", ["auto", "v4", "v3", "v2"])
 def test_cross_attention(S, oracle, cfg, variant, monkeypatch):
-    # v4 (default): scores stay in registers; v3: row-pipelined LDS score sheet; v2: per-tile MFMA kernel
+    # auto: v5 (online softmax, scores in registers; C <= 32 and value = right features) else v4 (two-pass, scores in
+    # registers); v3: row-pipelined LDS score sheet; v2: per-tile MFMA kernel
+    monkeypatch.setenv("STEREO_ATT_V4", "1" if variant == "v4" else "0")
     monkeypatch.setenv("STEREO_ATT_V3", "1" if variant == "v3" else "0")
     monkeypatch.setenv("STEREO_ATT_V2", "1" if variant == "v2" else "0")
     B, C, H, W, D = cfg
@@ -354,6 +356,25 @@ def test_cross_attention(S, oracle, cfg, variant, monkeypatch):
     # I3: mask='zero', scale='mean' reproduces CostVolume + DisparityEstimation of the HIP path itself
     _, d = S.CrossAttentionCostVolume(D, "zero", "mean")(dev(L), dev(R), need_out=False)
     close(d, host(S.DisparityEstimation(D)(S.CostVolume(D)(dev(L), dev(R)))), **DISP_TOL)
+
+
+@pytest.mark.parametrize("nw,tpw", [("4", "0"), ("8", "0"), ("8", "1"), ("4", "3")])
+def test_cross_attention_online_workgroup_shapes(S, oracle, nw, tpw, monkeypatch):
+    """v5 with 4 / 8 waves (128 / 256 queries) per workgroup tile and 1 / 3 / auto tiles per persistent workgroup, incl.
+    partial last tiles, every band size class (NT = 3, 5, 7, 9), both masks, disparity-only mode."""
+    monkeypatch.setenv("STEREO_ATT_NW", nw)
+    monkeypatch.setenv("STEREO_ATT_TPW", tpw)
+    rng = np.random.default_rng(31)
+    for (B, C, H, W, D) in ((1, 32, 2, 960, 192), (2, 16, 3, 200, 40), (1, 8, 2, 516, 100), (1, 32, 1, 300, 256), (1, 5, 2, 36, 7)):
+        L = rng.standard_normal((B, C, H, W), dtype=np.float32)
+        R = rng.standard_normal((B, C, H, W), dtype=np.float32)
+        for mask in ("zero", "neginf"):
+            o, d = S.CrossAttentionCostVolume(D, mask, "sqrt_c")(dev(L), dev(R))
+            oo, od = oracle.cross_attention(L, R, None, D, mask, "sqrt_c")
+            close(o, oo, rtol=1e-4, atol=5e-5)
+            close(d, od, rtol=0, atol=1e-3, mean_atol=2.5e-4 * max(1.0, D / 192.0))
+            _, d2 = S.CrossAttentionCostVolume(D, mask, "sqrt_c")(dev(L), dev(R), need_out=False)
+            close(d2, od, rtol=0, atol=1e-3, mean_atol=2.5e-4 * max(1.0, D / 192.0))
 
 
 # ------------------------------------------------------------------ GRU gate math
