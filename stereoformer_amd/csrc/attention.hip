@@ -367,234 +367,6 @@ __global__ __launch_bounds__(A2_NT) void cross_attention_mfma_kernel(const float
 
 
 // ---------------------------------------------------------------------------
-// v3: the v2 kernel turned into a software pipeline along the image row (fast path: 16-B aligned,
-// W % 4 == 0, C <= 32, Cv <= 32).  One workgroup walks `tiles_per_wg` consecutive 64-query tiles; the
-// global loads of the NEXT operand tile are always in flight in registers while the matrix cores or
-// the softmax work on the current one:
-//     phase 1 (QK^T on MFMA)       || value tile V_t loading
-//     phase 2 (softmax in regs)    || K_{t+1}, Q_{t+1} loading        (V_t committed to LDS first)
-//     phase 3 (P V on MFMA)        || K_{t+1}, Q_{t+1} still landing
-// so the ~2 x 2.5 us of exposed HBM/L2 latency per tile of the v2 kernel (one workgroup per CU, every
-// phase behind a barrier) disappears.  LDS: score sheet + one operand tile + Q tile + reduction scratch.
-template <int DKMAX>
-__global__ __launch_bounds__(A2_NT) void cross_attention_pipe_kernel(const float *__restrict__ L,
-                                                                   const float *__restrict__ R,
-                                                                   const float *__restrict__ V,
-                                                                   float *__restrict__ out, float *__restrict__ disp,
-                                                                   int C, int Cv, int H, int W, int D, int Dk,
-                                                                   int mask_mode, float scale, int tiles_per_wg)
-{
-    constexpr int NPT = DKMAX / A2_NW;               // scores per lane in the softmax phase
-    constexpr int NSK = (A2_TQ + DKMAX) / 64;        // operand-tile quads per lane: 32 rows x (64+Dk)/4 / 512
-    extern __shared__ f32x4 smem4[];
-    const int KS = A2_TQ + Dk + 1;
-    const int NKT = (A2_TQ + Dk) / 32;
-    const int PROWS = Dk + 2 * A2_PAD;
-    float *P = reinterpret_cast<float *>(smem4);     // [PROWS][64], row = 32 + d
-    float *Ks = P + (size_t)PROWS * A2_TQ;           // [32][KS]  K tile, then V tile
-    float *Qs = Ks + A2_CK * KS;                     // [32][64]  Q tile; softmax reduction scratch
-    float *Rd = Qs + A2_CK * A2_TQ;                  // [(NKG-1)*2*16][64] phase-3 partial tiles
-    float *red = Qs;
-
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int l31 = lane & 31, half = lane >> 5;
-    const size_t HW = (size_t)H * W;
-    const int qt = wave & 1, qq = qt * 32 + l31;
-    const int NKH = (NKT + A2_NKG - 1) / A2_NKG;
-    const int kg = wave >> 1;
-    const int kt_end = ((kg + 1) * NKH < NKT) ? (kg + 1) * NKH : NKT;
-    auto in_band = [&](int kt) { const int dq = Dk + (qt - kt) * 32; return dq >= 0 && dq <= Dk; };
-
-    const int ntiles = (W + A2_TQ - 1) / A2_TQ;
-    const int t_begin = blockIdx.x * tiles_per_wg;
-    const int t_end = (t_begin + tiles_per_wg < ntiles) ? t_begin + tiles_per_wg : ntiles;
-
-    // staging slots (identical for every tile): operand tile quad k -> (row, column quad); Q tile quad
-    const int nq = (A2_TQ + Dk) >> 2;
-    int srow[NSK], sxq[NSK];
-#pragma unroll
-    for (int k = 0; k < NSK; ++k) {
-        const int qi = tid + k * A2_NT;
-        srow[k] = qi / nq;
-        sxq[k] = qi - srow[k] * nq;
-    }
-    const int qrow = tid >> 4, qxq = tid & 15;       // Q tile: 32 rows x 16 quads = 512 slots
-    f32x4 rk[NSK], rq;
-    unsigned kmask = 0, qmask = 0;  // validity, applied at COMMIT time: a select on the loaded value at issue time
-                                    // would make the compiler wait for the load right there
-    auto issue_tile = [&](const float *__restrict__ src, int nch, int w0) {  // -> rk (rows = channels)
-        const float *base = src + (size_t)b * nch * HW + (size_t)h * W;
-        kmask = 0;
-#pragma unroll
-        for (int k = 0; k < NSK; ++k) {
-            const int w = w0 - Dk + 4 * sxq[k];
-            const bool ok = srow[k] < nch && srow[k] < A2_CK && w >= 0 && w + 3 < W;
-            rk[k] = ld4(base + (ok ? (size_t)srow[k] * HW + w : 0));
-            kmask |= ok ? (1u << k) : 0u;
-        }
-    };
-    auto commit_tile = [&]() {
-#pragma unroll
-        for (int k = 0; k < NSK; ++k) {
-            if (srow[k] < A2_CK) {
-                const bool ok = (kmask >> k) & 1u;
-                float *d = Ks + srow[k] * KS + 4 * sxq[k];
-                d[0] = ok ? rk[k][0] : 0.0f;
-                d[1] = ok ? rk[k][1] : 0.0f;
-                d[2] = ok ? rk[k][2] : 0.0f;
-                d[3] = ok ? rk[k][3] : 0.0f;
-            }
-        }
-    };
-    auto issue_q = [&](int w0) {
-        const int w = w0 + 4 * qxq;
-        const bool ok = qrow < C && w + 3 < W;
-        rq = ld4(L + (size_t)b * C * HW + (size_t)h * W + (ok ? (size_t)qrow * HW + w : 0));
-        qmask = ok ? 1u : 0u;
-    };
-    auto commit_q = [&]() {
-        *reinterpret_cast<f32x4 *>(Qs + qrow * A2_TQ + 4 * qxq) = qmask ? rq : (f32x4){0.f, 0.f, 0.f, 0.f};
-    };
-
-    if (t_begin >= t_end) return;
-    issue_tile(R, C, t_begin * A2_TQ);
-    issue_q(t_begin * A2_TQ);
-    commit_tile();
-    commit_q();
-    __syncthreads();
-
-    for (int t = t_begin; t < t_end; ++t) {
-        const int w0 = t * A2_TQ;
-        // ---------------- phase 1: band logits (K_t, Q_t are in LDS); V_t starts loading
-        if (out) issue_tile(V, Cv, w0);
-        {
-            f32x16 acc[A2_TPW];
-            const int npass = (NKH + A2_TPW - 1) / A2_TPW;
-            for (int pass = 0; pass < npass; ++pass) {
-                const int kt0 = kg * NKH + pass * A2_TPW;
-#pragma unroll
-                for (int tt = 0; tt < A2_TPW; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[tt][r] = 0.0f;
-                const float *qp = Qs + half * A2_TQ + qq;
-                const float *kp = Ks + half * KS + kt0 * 32 + l31;
-#pragma unroll 4
-                for (int s = 0; s < A2_CK / 2; ++s) {
-                    const float qv = qp[2 * s * A2_TQ];
-#pragma unroll
-                    for (int tt = 0; tt < A2_TPW; ++tt) {
-                        if (kt0 + tt < kt_end && in_band(kt0 + tt)) {
-                            const float kv = kp[2 * s * KS + tt * 32];
-                            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, qv, acc[tt], 0, 0, 0);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int tt = 0; tt < A2_TPW; ++tt) {
-                    const int kt = kt0 + tt;
-                    if (kt < kt_end && in_band(kt)) {
-                        float *pp = P + (A2_PAD + Dk + qq - kt * 32 - 4 * half) * A2_TQ + qq;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) pp[-((r & 3) + 8 * (r >> 2)) * A2_TQ] = acc[tt][r];
-                    }
-                }
-            }
-        }
-        __syncthreads();  // #1: P complete; nobody reads Ks / Qs any more
-        if (out) commit_tile();  // V_t -> Ks
-        if (t + 1 < t_end) {     // next tile's K and Q start loading now, land during phases 2-3
-            issue_tile(R, C, w0 + A2_TQ);
-            issue_q(w0 + A2_TQ);
-        }
-        // ---------------- phase 2: zero the pad rows; masked softmax over d, scores in registers
-        {
-            for (int idx = tid; idx < A2_PAD * A2_TQ; idx += A2_NT) P[idx] = 0.0f;
-            for (int idx = (A2_PAD + D) * A2_TQ + tid; idx < PROWS * A2_TQ; idx += A2_NT) P[idx] = 0.0f;
-            const int q = tid & 63, part = tid >> 6;
-            const int w = w0 + q;
-            float *pc = P + (A2_PAD + part) * A2_TQ + q;
-            float x[NPT];
-            float m = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < NPT; ++i) {
-                const int d = part + A2_NW * i;
-                float v = -INFINITY;
-                if (d < D) {
-                    v = pc[A2_NW * i * A2_TQ] * scale;
-                    if (w - d < 0) v = mask_mode == STEREO_MASK_ZERO ? 0.0f : -INFINITY;
-                }
-                x[i] = v;
-                m = fmaxf(m, v);
-            }
-            red[part * 64 + q] = m;
-            __syncthreads();  // #2
-            m = red[q];
-#pragma unroll
-            for (int k = 1; k < A2_NW; ++k) m = fmaxf(m, red[k * 64 + q]);
-            float s = 0.0f, e = 0.0f;
-#pragma unroll
-            for (int i = 0; i < NPT; ++i) {
-                const float p = fast_exp(x[i] - m);
-                x[i] = p;
-                s += p;
-                e = fmaf(p, (float)(part + A2_NW * i), e);
-            }
-            red[(A2_NW + part) * 64 + q] = s;
-            red[(2 * A2_NW + part) * 64 + q] = e;
-            __syncthreads();  // #3
-            s = 0.0f, e = 0.0f;
-#pragma unroll
-            for (int k = 0; k < A2_NW; ++k) {
-                s += red[(A2_NW + k) * 64 + q];
-                e += red[(2 * A2_NW + k) * 64 + q];
-            }
-            const float inv = 1.0f / s;
-#pragma unroll
-            for (int i = 0; i < NPT; ++i)
-                if (part + A2_NW * i < D) pc[A2_NW * i * A2_TQ] = x[i] * inv;
-            if (part == 0 && disp && w < W) disp[((size_t)b * H + h) * W + w] = e * inv;
-        }
-        __syncthreads();  // #4: P normalised, V_t visible, red (= Qs) free
-        // ---------------- phase 3: O^T = V^T P
-        f32x16 o;
-        if (out) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = 0.0f;
-            for (int kt = kg * NKH; kt < kt_end; ++kt) {
-                if (!in_band(kt)) continue;
-                const float *ap = Ks + l31 * KS + kt * 32 + half;
-                const float *bp = P + (A2_PAD + Dk + qq - kt * 32 - half) * A2_TQ + qq;
-#pragma unroll
-                for (int s = 0; s < 16; ++s)
-                    o = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[-2 * s * A2_TQ], o, 0, 0, 0);
-            }
-            if (kg > 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Rd[(((kg - 1) * 2 + qt) * 16 + r) * 64 + lane] = o[r];
-            }
-        }
-        __syncthreads();  // #5: Ks (V_t) and P no longer read; partial tiles visible
-        if (t + 1 < t_end) {  // next tile's operands -> LDS (their loads had phases 2-3 to land)
-            commit_tile();
-            commit_q();
-        }
-        if (out && kg == 0) {
-            const int w = w0 + qq;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v = o[r];
-#pragma unroll
-                for (int k = 1; k < A2_NKG; ++k) v += Rd[(((k - 1) * 2 + qt) * 16 + r) * 64 + lane];
-                if (c < Cv && w < W) out[((size_t)b * Cv + c) * HW + (size_t)h * W + w] = v;
-            }
-        }
-        __syncthreads();  // #6: K_{t+1}, Q_{t+1} visible; Rd free for the next tile
-    }
-}
-
-// ---------------------------------------------------------------------------
 // v4: scores never leave the registers.  One wave owns 32 queries of a row; a workgroup is A4_NW such waves over
 // consecutive queries sharing ONE LDS tile of keys (32 channels x (32*A4_NW + Dk) keys, odd row stride).
 //   phase 1  S^T tile t (32 keys x 32 queries) = K_t Q^T on v_mfma_f32_32x32x2_f32: A = K from LDS (lanes = keys),
@@ -981,9 +753,8 @@ extern "C" int stereo_cross_attention_f32(const float *left, const float *right,
     if (!fits_grid_yz(H) || !fits_grid_yz(B)) return STEREO_ERR_UNSUPPORTED;
     {   // v4: register-resident scores (aligned, W % 4 == 0, band <= 256 after rounding up to a multiple of 32)
         const bool vec = (W % 4 == 0) && aligned16(left) && aligned16(right) && (out == nullptr || aligned16(value));
-        const char *v4off = getenv("STEREO_ATT_V3");
-        const char *v2on = getenv("STEREO_ATT_V2");
-        if (vec && D <= 256 && !(v4off && v4off[0] == '1') && !(v2on && v2on[0] == '1')) {
+        const char *v2on = getenv("STEREO_ATT_V2");  // dev/test knob: force the LDS-score-sheet kernel below
+        if (vec && D <= 256 && !(v2on && v2on[0] == '1')) {
             const int nt = (D + 31) / 32 + 1;
             const float sc = scale_mode == STEREO_SCALE_MEAN ? 1.0f / (float)C : 1.0f / sqrtf((float)C);
             const int same_kv = (out != nullptr && value == right && Cv == C) ? 1 : 0;
@@ -1026,34 +797,6 @@ extern "C" int stereo_cross_attention_f32(const float *left, const float *right,
             else if (nt <= 7) ATT4(7);
             else ATT4(9);
 #undef ATT4
-            STEREO_LAUNCH_CHECK();
-            return STEREO_OK;
-        }
-    }
-    {   // v3: row-pipelined MFMA path (aligned, W % 4 == 0, one 32-channel chunk each side)
-        const int Dk = (D + 31) / 32 * 32;
-        const bool vec = (W % 4 == 0) && aligned16(left) && aligned16(right) && (out == nullptr || aligned16(value));
-        const size_t lds3 = ((size_t)(Dk + 2 * A2_PAD) * A2_TQ + (size_t)A2_CK * (A2_TQ + Dk + 1) + (size_t)A2_CK * A2_TQ +
-                             (size_t)(A2_NKG - 1) * 2 * 16 * 64) * sizeof(float);
-        const char *v3off = getenv("STEREO_ATT_V2");
-        if (vec && C <= A2_CK && (out == nullptr || Cv <= 32) && Dk <= 320 && lds3 <= 160 * 1024 &&
-            !(v3off && v3off[0] == '1')) {
-            auto kern = Dk <= 64 ? cross_attention_pipe_kernel<64>
-                        : Dk <= 128 ? cross_attention_pipe_kernel<128>
-                        : Dk <= 192 ? cross_attention_pipe_kernel<192>
-                        : Dk <= 256 ? cross_attention_pipe_kernel<256>
-                                    : cross_attention_pipe_kernel<320>;
-            if (lds3 > 64 * 1024 &&
-                hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds3) != hipSuccess)
-                return STEREO_ERR_UNSUPPORTED;
-            const int ntiles = (W + A2_TQ - 1) / A2_TQ;
-            int tpw = ntiles;  // tiles per workgroup: whole rows unless that leaves the chip under-filled
-            while (tpw > 1 && (long long)((ntiles + tpw - 1) / tpw) * H * B < 2048) tpw = (tpw + 1) / 2;
-            const float scale3 = scale_mode == STEREO_SCALE_MEAN ? 1.0f / (float)C : 1.0f / sqrtf((float)C);
-            dim3 grid3((ntiles + tpw - 1) / tpw, H, B);
-            hipLaunchKernelGGL(kern, grid3, dim3(A2_NT), lds3, as_stream(stream), left, right, value, out, disp, C, Cv, H,
-                               W, D, Dk, mask_mode, scale3, tpw);
             STEREO_LAUNCH_CHECK();
             return STEREO_OK;
         }

@@ -287,10 +287,6 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
         }
     };
 
-    float sm_m[4], sm_s[4], sm_e[4];  // EPI_ARGMIN state
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sm_m[i] = -INFINITY, sm_s[i] = 0.0f, sm_e[i] = 0.0f;
-
     const int nchunk = (CPG + CC - 1) / CC;
     const int per_row = G * nchunk;
     const int nitems = nrows * per_row;  // the pipeline runs across groups, chunks AND rows: the stores of one
@@ -387,38 +383,45 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
                 }
             }
             if (DO_ARGMIN) {
+                // G == 1 here (launcher), so the end of the group is the end of the row: this wave's softmax state over
+                // its DC planes goes straight to the LDS exchange (no state carried across items -- with the store
+                // epilogue in the same kernel those registers, and a DC-float logit array, spilled to scratch).  The
+                // logit of (dd, i) is recomputed from the accumulator in both passes.
+                float *stt = reinterpret_cast<float *>(smem4) + 2 * BUF;  // [3][NWV][TW], its own LDS region
+                auto logit = [&](int dd, int i) {
+                    const float m = exact_div ? acc[dd][i] / (float)CPG : acc[dd][i] * inv_cpg;
+                    return (w + i >= d0 + dd) ? sgn * m : sgn * 0.0f;
+                };
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float x[DC];
-                    float cm = sm_m[i];
+                    float cm = -INFINITY;
 #pragma unroll
-                    for (int dd = 0; dd < DC; ++dd) {
-                        const float m = exact_div ? acc[dd][i] / (float)CPG : acc[dd][i] * inv_cpg;
-                        x[dd] = (w + i >= d0 + dd) ? sgn * m : sgn * 0.0f;
-                        if (d0 + dd < D) cm = fmaxf(cm, x[dd]);
-                    }
-                    const float sc = (sm_m[i] == cm) ? 1.0f : fast_exp(sm_m[i] - cm);
-                    float ss = sm_s[i] * sc, ee = sm_e[i] * sc;
+                    for (int dd = 0; dd < DC; ++dd)
+                        if (d0 + dd < D) cm = fmaxf(cm, logit(dd, i));
+                    float ss = 0.0f, ee = 0.0f;
 #pragma unroll
                     for (int dd = 0; dd < DC; ++dd)
                         if (d0 + dd < D) {
-                            const float p = fast_exp(x[dd] - cm);
+                            const float p = fast_exp(logit(dd, i) - cm);
                             ss += p;
                             ee = fmaf(p, (float)(d0 + dd), ee);
                         }
-                    sm_m[i] = cm, sm_s[i] = ss, sm_e[i] = ee;
+                    stt[(0 * NWV + wave) * TW + wl + i] = cm;
+                    stt[(1 * NWV + wave) * TW + wl + i] = ss;
+                    stt[(2 * NWV + wave) * TW + wl + i] = ee;
                 }
             }
         }
         if (DO_ARGMIN && ir == per_row - 1) {  // row finished: combine the waves' softmax states
             // (single disparity part: the launcher guarantees nparts == 1).  Uses its own LDS region.
             float *stt = reinterpret_cast<float *>(smem4) + 2 * BUF;  // [3][NWV][TW]
+            if (!active) {  // a wave past the last disparity contributes the neutral state
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                stt[(0 * NWV + wave) * TW + wl + i] = sm_m[i];
-                stt[(1 * NWV + wave) * TW + wl + i] = sm_s[i];
-                stt[(2 * NWV + wave) * TW + wl + i] = sm_e[i];
-                sm_m[i] = -INFINITY, sm_s[i] = 0.0f, sm_e[i] = 0.0f;
+                for (int i = 0; i < 4; ++i) {
+                    stt[(0 * NWV + wave) * TW + wl + i] = -INFINITY;
+                    stt[(1 * NWV + wave) * TW + wl + i] = 0.0f;
+                    stt[(2 * NWV + wave) * TW + wl + i] = 0.0f;
+                }
             }
             __syncthreads();
             if (tid < TW && w0 + tid < W) {
