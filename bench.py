@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="run the N-rank code path with every rank on cuda:0 over gloo (1-GPU boxes; timings are "
+                         "NOT a valid measurement -- the ranks share one GPU)")
     ap.add_argument("--reread", action="store_true",
                     help="group-mean + soft-argmin by re-reading the 25.5 GB volume (the pre-fusion chain)")
     args = ap.parse_args()
@@ -121,9 +124,14 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with nproc-per-node {args.gpus} "
                          f"(WORLD_SIZE={world})")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 and args.rehearse_on_one_gpu:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    elif world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
@@ -230,7 +238,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not args.rehearse_on_one_gpu else "synthetic (REHEARSAL: all ranks share cuda:0 over gloo; not a measurement)",
             "config": {"workload": "cfg-2: SceneFlow 960x540 D=192 group-wise (G=8,C=32) LocalCostVolume + soft-argmin, "
                                    "batch=8 per GPU, all reference-API intermediates materialised"
                                    + (" (group mean by re-reading the volume)" if args.reread else

@@ -34,20 +34,23 @@ def gather_pairs(local: torch.Tensor, total_pairs: int, group=None) -> torch.Ten
     if local.shape[0] != sizes[dist.get_rank(group)]:
         raise ValueError(f"rank {dist.get_rank(group)} holds {local.shape[0]} pairs, expected {sizes[dist.get_rank(group)]}")
     mx = max(sizes)
+    dev = local.device
+    if local.is_cuda and dist.get_backend(group) == "gloo":  # gloo has no device all_gather: stage through the host
+        local = local.cpu()
     padded = local
     if local.shape[0] < mx:
         pad = torch.zeros((mx - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         padded = torch.cat([local, pad], 0)
     bufs = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(bufs, padded.contiguous(), group=group)
-    return torch.cat([b[:n] for b, n in zip(bufs, sizes)], 0)
+    return torch.cat([b[:n] for b, n in zip(bufs, sizes)], 0).to(dev)
 
 
 def max_over_ranks(value: float, device=None, group=None) -> float:
     """Whole-job time = the slowest rank's time."""
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=None if dist.get_backend(group) == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
 
@@ -55,6 +58,6 @@ def max_over_ranks(value: float, device=None, group=None) -> float:
 def sum_over_ranks(value: float, device=None, group=None) -> float:
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=None if dist.get_backend(group) == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return float(t.item())

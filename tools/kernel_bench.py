@@ -110,6 +110,17 @@ def main():
         Br, Cr, Hr, Wr = 8, 256, 136, 240
         f1 = torch.randn(Br, Cr, Hr, Wr, device=dev)
         f2 = torch.randn(Br, Cr, Hr, Wr, device=dev)
+        if want("A7_cross_attention"):
+            # cfg-3 secondary shape (RAFT-fnet-like features, quarter resolution) and cfg-5 (KITTI 384x1248 / 4, D/4 = 64)
+            for (nm, bb, cc, hh, ww, dd) in (("cfg-3b [8,256,136,240] D=48", 8, 256, 136, 240, 48),
+                                             ("cfg-5 [4,256,96,312] D=64", 4, 256, 96, 312, 64)):
+                q1 = torch.randn(bb, cc, hh, ww, device=dev)
+                q2 = torch.randn(bb, cc, hh, ww, device=dev)
+                a2 = S.CrossAttentionCostVolume(dd, "neginf", "sqrt_c")
+                bnd = dd * ww - dd * (dd - 1) / 2
+                add(f"A7_cross_attention {nm}", timeit(lambda: a2(q1, q2), 3, 1),
+                    (4 * bb * cc * hh * ww * 4 + bb * hh * ww * 4) / 1e9, 2 * 2 * bb * hh * cc * bnd / 1e9, bound="mfma")
+                del q1, q2
         if want("A8_allpairs"):
             pyr_bytes = Br * Hr * Wr * (Wr + Wr // 2 + Wr // 4 + Wr // 8 + Wr // 16) * 4
             add("A8_allpairs+pyramid cfg-4 [8,256,136,240]", timeit(lambda: S.CorrBlock1D(f1, f2, 4, 4), args.reps),
