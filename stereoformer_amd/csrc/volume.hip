@@ -203,7 +203,7 @@ __global__ __launch_bounds__(NT) void gwc_volume_kernel(const float *__restrict_
 // group overlaps the next group's loads the same way.  NWV waves per workgroup, each owning DC
 // disparities; the store variant may split the disparity range over several small workgroups so
 // that more independent workgroups share a CU (barriers and phases of different workgroups overlap).
-template <int DC, int NWV, int EPI>
+template <int DC, int NWV, int EPI, int WX = 1, int CCM = CCMAX>
 __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *__restrict__ L,
                                                                    const float *__restrict__ R,
                                                                    float *__restrict__ vol, float *__restrict__ aux,
@@ -211,29 +211,38 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
                                                                    int CC, float inv_cpg, int exact_div, float sgn,
                                                                    int nparts, int RB, int nt)
 {
+    // WX waves side by side along W (WX * 256 pixels per workgroup), NWV / WX disparity strips.  WX = 4 makes a
+    // workgroup's stores whole 3840-B image rows per plane instead of 1-KiB pieces (6.1 vs 5.6 TB/s as a pure store
+    // stream, tools/hbm_ceiling.hip); it is the store-only shape (the soft-argmin epilogues need all of D in one
+    // workgroup).  CCM = channels per staged chunk (bounds the prefetch registers: 4 for the wide shape).
+    static_assert(WX == 1 || EPI == EPI_STORE, "the wide workgroup shape is store-only");
+    static_assert(NWV % WX == 0, "waves = WX x disparity strips");
     constexpr bool DO_STORE = EPI == EPI_STORE || EPI == EPI_BOTH;
     constexpr bool DO_ARGMIN = EPI == EPI_ARGMIN || EPI == EPI_BOTH;
+    constexpr int TWG = TW * WX;  // pixels per workgroup
     extern __shared__ f32x4 smem4[];
     float *Rs = reinterpret_cast<float *>(smem4);  // [CC][RS]
-    const int RS = TW + Dpad;
-    float *Ls = Rs + CC * RS;  // [CC][TW]
+    const int RS = TWG + Dpad;
+    float *Ls = Rs + CC * RS;  // [CC][TWG]
 
     constexpr int NTV = NWV * 64;
-    constexpr int NSR = (CCMAX * 512 / 4 + NTV - 1) / NTV;  // staging slots per lane: right tile (Dpad <= 256)
-    constexpr int NSL = (CCMAX * TW / 4 + NTV - 1) / NTV;   //                         left tile
-    const int w0 = blockIdx.x * TW, h0 = blockIdx.y * RB;  // RB consecutive rows per workgroup
+    constexpr int NSR = (CCM * (TWG + 256) / 4 + NTV - 1) / NTV;  // staging slots per lane: right tile (Dpad <= 256)
+    constexpr int NSL = (CCM * TWG / 4 + NTV - 1) / NTV;          //                         left tile
+    static_assert(NSR <= 8 && NSL <= 8, "okmask holds 8 + 8 slot bits");
+    const int w0 = blockIdx.x * TWG, h0 = blockIdx.y * RB;  // RB consecutive rows per workgroup
     const int nrows = (H - h0) < RB ? (H - h0) : RB;
     const int b = blockIdx.z / nparts, dpart = blockIdx.z - b * nparts;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wl = lane * 4;
+    const int wx = wave % WX, wd = wave / WX;  // tile column / disparity strip of this wave
+    const int wl = (wx * 64 + lane) * 4;
     const size_t HW = (size_t)H * W;
     const float *Lb = L + (size_t)b * C * HW;
     const float *Rb = R + (size_t)b * C * HW;
 
-    const int d0 = (dpart * NWV + wave) * DC;
+    const int d0 = (dpart * (NWV / WX) + wd) * DC;
     const bool active = d0 < D;  // wave-uniform
 
-    const int rq = RS / 4, lq = TW / 4;
+    const int rq = RS / 4, lq = TWG / 4;
     int rc[NSR], rx[NSR], lc[NSL], lx[NSL];
 #pragma unroll
     for (int k = 0; k < NSR; ++k) {
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
     const int per_row = G * nchunk;
     const int nitems = nrows * per_row;  // the pipeline runs across groups, chunks AND rows: the stores of one
                                          // row drain while the next row is being computed
-    const int BUF = CC * (RS + TW);  // floats per LDS buffer; two buffers, ONE barrier per item
+    const int BUF = CC * (RS + TWG);  // floats per LDS buffer; two buffers, ONE barrier per item
     auto item_loads = [&](int item) {
         const int r2 = item / per_row, i2 = item - r2 * per_row;
         const int g2 = i2 / nchunk, ck2 = i2 - g2 * nchunk;
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
 #pragma unroll
         for (int k = 0; k < NSL; ++k)
             if (lc[k] < CC)
-                *reinterpret_cast<f32x4 *>(ls + lc[k] * TW + lx[k]) = (okmask >> (8 + k)) & 1u ? pl[k] : zero;
+                *reinterpret_cast<f32x4 *>(ls + lc[k] * TWG + lx[k]) = (okmask >> (8 + k)) & 1u ? pl[k] : zero;
     };
     item_loads(0);
     commit(0);
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
         if (active) {
             const float *rwin = Rcur + (Dpad + wl - d0 - DC);
             for (int c = 0; c < ncc; ++c) {
-                const f32x4 lv = *reinterpret_cast<const f32x4 *>(Lcur + c * TW + wl);
+                const f32x4 lv = *reinterpret_cast<const f32x4 *>(Lcur + c * TWG + wl);
                 float win[DC + 4];
 #pragma unroll
                 for (int q = 0; q < DC / 4 + 1; ++q) {
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
             const int w = w0 + wl;
             if (DO_STORE) {
                 float *vbase = vol + (((size_t)b * G + g) * D) * HW + (size_t)h * W;
-                const bool interior = (w0 >= d0 + DC - 1) && (w0 + TW <= W) && (d0 + DC <= D);  // wave-uniform
+                const bool interior = (w0 + wx * TW >= d0 + DC - 1) && (w0 + (wx + 1) * TW <= W) && (d0 + DC <= D);  // wave-uniform
                 if (interior) {  // no w<d zeros, no ragged edge: straight scaled stores
 #pragma unroll
                     for (int dd = 0; dd < DC; ++dd) {
@@ -690,32 +699,33 @@ int launch_pk(const float *L, const float *R, float *vol, int B, int C, int H, i
     return STEREO_OK;
 }
 
-template <int DC, int NWV, int EPI>
+template <int DC, int NWV, int EPI, int WX = 1, int CCM = CCMAX>
 int launch_pipe(const float *L, const float *R, float *vol, int B, int C, int H, int W, int D, int G, float sgn,
                 hipStream_t st, float *aux = nullptr)
 {
     const int CPG = C / G;
     const int Dpad = ((D + DC - 1) / DC) * DC;
-    const int CC = CPG < CCMAX ? CPG : CCMAX;
-    size_t lds = (size_t)2 * CC * (size_t)(TW + Dpad + TW) * sizeof(float);  // two staging buffers
+    constexpr int TWG = TW * WX, NST = NWV / WX;  // pixels per workgroup, disparity strips per workgroup
+    const int CC = CPG < CCM ? CPG : CCM;
+    size_t lds = (size_t)2 * CC * (size_t)(TWG + Dpad + TWG) * sizeof(float);  // two staging buffers
     if (EPI != EPI_STORE) lds += (size_t)3 * NWV * TW * sizeof(float);           // + softmax-state exchange
     int RB = 4;                                                                  // rows per workgroup
     if (const char *e = getenv("STEREO_VOL_ROWS")) RB = atoi(e) > 0 ? atoi(e) : RB;
-    while (RB > 1 && (long long)((H + RB - 1) / RB) * ((W + TW - 1) / TW) * B * ((D + NWV * DC - 1) / (NWV * DC)) < 2048)
+    while (RB > 1 && (long long)((H + RB - 1) / RB) * ((W + TWG - 1) / TWG) * B * ((D + NST * DC - 1) / (NST * DC)) < 2048)
         RB >>= 1;                                                                // keep >= 8 workgroups per CU
-    const int nparts = (D + NWV * DC - 1) / (NWV * DC);
+    const int nparts = (D + NST * DC - 1) / (NST * DC);
     if (Dpad > 256 || lds > 160 * 1024 || !fits_grid_yz((long long)B * nparts) || (EPI != EPI_STORE && nparts != 1))
         return STEREO_ERR_UNSUPPORTED;
     if ((long long)CCMAX * H * W + W >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;  // 32-bit per-slot offsets
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(gwc_volume_pipe_kernel<DC, NWV, EPI>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(gwc_volume_pipe_kernel<DC, NWV, EPI, WX, CCM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return STEREO_ERR_UNSUPPORTED;
     const bool pow2 = (CPG & (CPG - 1)) == 0;
     int nt = 0;
     if (const char *e = getenv("STEREO_VOL_NT")) nt = atoi(e);
-    dim3 pgrid((W + TW - 1) / TW, (H + RB - 1) / RB, (unsigned)(B * nparts));
-    hipLaunchKernelGGL((gwc_volume_pipe_kernel<DC, NWV, EPI>), pgrid, dim3(NWV * 64), lds, st, L, R, vol, aux, C, H, W, D,
+    dim3 pgrid((W + TWG - 1) / TWG, (H + RB - 1) / RB, (unsigned)(B * nparts));
+    hipLaunchKernelGGL((gwc_volume_pipe_kernel<DC, NWV, EPI, WX, CCM>), pgrid, dim3(NWV * 64), lds, st, L, R, vol, aux, C, H, W, D,
                        G, CPG, Dpad, CC, 1.0f / (float)CPG, pow2 ? 0 : 1, sgn, nparts, RB, nt);
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
@@ -728,6 +738,17 @@ int pipe_dispatch(const float *L, const float *R, float *vol, int B, int C, int 
 {
     int dc = 0, nw = 0;
     if (const char *e = getenv("STEREO_VOL_CFG")) sscanf(e, "%d,%d", &dc, &nw);  // tuning knob (dev only)
+    if constexpr (EPI == EPI_STORE) {
+        // whole-row workgroups (4 waves side by side): opt-in.  As a pure store stream whole rows reach 6.1 TB/s
+        // against 5.6 for 1-KiB pieces, but the real kernel got SLOWER with it at cfg-2 (5.97 vs 5.42 ms in one
+        // A/B run): four disparity parts re-stage the features four times and the 48-plane workgroups overlap less.
+        int wide = 0;
+        if (const char *e = getenv("STEREO_VOL_WX")) wide = atoi(e) == 4;
+        if (wide) {
+            const int rc = launch_pipe<16, 12, EPI, 4, 4>(L, R, vol, B, C, H, W, D, G, sgn, st);
+            if (rc != STEREO_ERR_UNSUPPORTED) return rc;
+        }
+    }
     if (dc == 0) {  // measured on MI355X at cfg-2 (tools/vol_sweep.sh): (16,12) is the fastest for both epilogues
         if (D <= 64) dc = 8, nw = 8;
         else dc = 16, nw = 12;

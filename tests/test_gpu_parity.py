@@ -91,6 +91,19 @@ def test_shift_volumes_vs_oracle(S, oracle, shape):
     close(S.CostVolume(D, "concat")(dev(L), dev(R)), oracle.concat_volume(L, R, D), rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("wx", ["1", "4"])
+def test_volume_whole_row_workgroup_shape(S, oracle, wx, monkeypatch):
+    """Store-only group-wise build with 4 waves side by side along W (whole-row stores) vs the 256-pixel shape:
+    both against the oracle, incl. ragged last tile columns, W > 1024 (two workgroups per row), D not a multiple of
+    the 48 disparities a wide workgroup covers, channels/group in {1, 2, 4}."""
+    monkeypatch.setenv("STEREO_VOL_WX", wx)
+    rng = np.random.default_rng(17)
+    for (B, C, H, W, D, G) in ((1, 32, 5, 960, 192, 8), (2, 8, 6, 1300, 100, 4), (1, 6, 9, 520, 97, 6), (1, 8, 3, 260, 40, 2)):
+        L = rng.standard_normal((B, C, H, W), dtype=np.float32)
+        R = rng.standard_normal((B, C, H, W), dtype=np.float32)
+        close(S.build_gwc_volume(dev(L), dev(R), D, G), oracle.gwc_volume(L, R, D, G), **VOL_TOL)
+
+
 @pytest.mark.parametrize("cfg", ["24,8", "16,8", "12,8", "-8,12", "-12,8", "16,12"])
 def test_volume_kernel_variants(S, oracle, cfg, monkeypatch):
     """Every instantiated (disparities-per-wave, waves) variant of the pipelined volume kernel -- including the
