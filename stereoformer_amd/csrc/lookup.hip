@@ -115,18 +115,30 @@ __global__ __launch_bounds__(256) void variance_lookup_vec_kernel(const float *_
         float m[4], s[4], var[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) m[i] = -INFINITY, s[i] = 0.0f, var[i] = 0.0f;
-#pragma unroll 4
-        for (int d = 0; d < D; ++d) {
-            const f32x4 x = ld4(v + (size_t)d * HW);
+        constexpr int U = 8;  // planes in flight per lane; one running-max update (and one rescale exp) per batch
+        for (int d0 = 0; d0 < D; d0 += U) {
+            f32x4 x[U];
+            const int nv = (D - d0) < U ? (D - d0) : U;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (u < nv) x[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(v + (size_t)(d0 + u) * HW));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float cm = fmaxf(m[i], x[i]);
+                float cm = m[i];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (u < nv) cm = fmaxf(cm, x[u][i]);
                 const float sc = (m[i] == cm) ? 1.0f : fast_exp(m[i] - cm);
-                const float pe = fast_exp(x[i] - cm);
-                const float err = (float)d - cur[i];
-                s[i] = s[i] * sc + pe;
-                var[i] = var[i] * sc + pe * (err * err);
-                m[i] = cm;
+                float ss = s[i] * sc, vv = var[i] * sc;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (u < nv) {
+                        const float pe = fast_exp(x[u][i] - cm);
+                        const float err = (float)(d0 + u) - cur[i];
+                        ss += pe;
+                        vv = fmaf(pe, err * err, vv);
+                    }
+                m[i] = cm, s[i] = ss, var[i] = vv;
             }
         }
         f32x4 o;
