@@ -54,8 +54,13 @@ class _GraphCache:
 
 
 class RAFTStereoLoop(nn.Module):
-    def __init__(self, hidden_dims=(128, 128, 128), downsample=2, corr_levels=4, corr_radius=4, n_gru_layers=3):
+    def __init__(self, hidden_dims=(128, 128, 128), downsample=2, corr_levels=4, corr_radius=4, n_gru_layers=3,
+                 mixed_precision=False):
+        """``mixed_precision``: the reference's flag of the same name (``raft_stereo.py:176``): the update block's
+        convolutions run under fp16 ``autocast``; correlation, lookup, gate math, coordinates and the convex
+        upsampling stay fp32.  Off by default -- fp32 is the parity configuration."""
         super().__init__()
+        self.mixed_precision = bool(mixed_precision)
         self.hidden_dims = list(hidden_dims)
         self.downsample = downsample
         self.corr_levels = corr_levels
@@ -70,11 +75,13 @@ class RAFTStereoLoop(nn.Module):
         coords1 = coords1.detach()                                  # raft_stereo.py:171
         corr = corr_fn(coords1)                                     # :173
         flow = coords1 - coords0
-        net_list, up_mask, delta_flow = self.update_block(net_list, inp_list, corr, flow,
-                                                          iter32=self.n_gru_layers == 3,
-                                                          iter16=self.n_gru_layers >= 2)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision):    # :176
+            net_list, up_mask, delta_flow = self.update_block(net_list, inp_list, corr, flow,
+                                                              iter32=self.n_gru_layers == 3,
+                                                              iter16=self.n_gru_layers >= 2)
+        delta_flow = delta_flow.float()
         delta_flow[:, 1] = 0.0                                      # :180
-        return net_list, up_mask, coords1 + delta_flow
+        return net_list, up_mask.float(), coords1 + delta_flow
 
     def forward(self, fmap1, fmap2, net_list, inp_list, iters=12, flow_init=None, test_mode=False, use_graph=False):
         """fmap1/fmap2 [B,256,H/4,W/4] (fnet outputs), net_list: tanh'ed hidden states per scale,
@@ -100,7 +107,7 @@ class RAFTStereoLoop(nn.Module):
                                       test_mode)
             return list(out)
 
-        key = (tuple(tuple(t.shape) for t in flat), iters, bool(test_mode), flat[0].device.index)
+        key = (tuple(tuple(t.shape) for t in flat), iters, bool(test_mode), flat[0].device.index, self.mixed_precision)
         out = self._graphs.run(key, fn, flat)
         return tuple(out) if test_mode else out
 

@@ -32,12 +32,17 @@ def pool4x(x):
     return F.avg_pool2d(x, 5, stride=4, padding=1)
 
 
+def _f32(t):
+    """Gate math runs in fp32: under ``autocast`` (``mixed_precision``) the convolutions hand over fp16."""
+    return t if t is None or t.dtype == torch.float32 else t.float()
+
+
 def _gru_step(h, x, conv_z, conv_r, conv_q, cz=None, cr=None, cq=None):
     """One ConvGRU update with optional context biases; the two pointwise stages are HIP kernels."""
     hx = torch.cat((h, x), 1)
     z_pre = conv_z(hx)
-    gated = gru_reset(h, conv_r(hx), cr)
-    return gru_blend(h, z_pre, conv_q(torch.cat((gated, x), 1)), cz, cq)
+    gated = gru_reset(_f32(h), _f32(conv_r(hx)), _f32(cr))
+    return gru_blend(_f32(h), _f32(z_pre), _f32(conv_q(torch.cat((gated, x), 1))), _f32(cz), _f32(cq))
 
 
 class ConvGRU(nn.Module):
@@ -119,10 +124,10 @@ class BasicMultiUpdateBlock_LZH(nn.Module):
         if iter32:
             net[2] = self.gru32(net[2], *inp[2], pool2x(net[1]))
         if iter16:
-            extra = (interp(net[2], net[1]),) if self.n_gru_layers > 2 else ()
+            extra = (interp(_f32(net[2]), net[1]),) if self.n_gru_layers > 2 else ()
             net[1] = self.gru16(net[1], *inp[1], pool2x(net[0]), *extra)
         if iter08:
-            extra = (interp(net[1], net[0]),) if self.n_gru_layers > 1 else ()
+            extra = (interp(_f32(net[1]), net[0]),) if self.n_gru_layers > 1 else ()
             net[0] = self.gru08(net[0], *inp[0], self.encoder(flow, corr), *extra)
         if not update:
             return net

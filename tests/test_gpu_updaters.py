@@ -148,6 +148,27 @@ def test_raft_stereo_loop_end_to_end_g9(S, golden):
     assert (lo_g - flow_lo).abs().max().item() < 5e-5 and (up_g - flow_up).abs().max().item() < 1e-4
 
 
+def test_raft_loop_mixed_precision_option(S, golden):
+    """The reference's optional ``mixed_precision`` flag (update-block convolutions under fp16 autocast, everything
+    else fp32): not a parity configuration -- checked to stay close to the fp32 result of the same loop."""
+    g = golden("g9_raft_loop")
+    loop = S.RAFTStereoLoop(hidden_dims=[32, 32, 32]).eval()
+    fill_state_dict_(loop.update_block, seed=0.125, keys=list(g["keys"]), prefix="update_block.")
+    loop = loop.cuda()
+    with torch.no_grad():
+        f1, f2, net, inp = _raft_inputs(g)
+        lo32, up32 = loop(f1, f2, net, inp, iters=4, test_mode=True)
+        loop.mixed_precision = True
+        f1, f2, net, inp = _raft_inputs(g)
+        lo16, up16 = loop(f1, f2, net, inp, iters=4, test_mode=True)
+        f1, f2, net, inp = _raft_inputs(g)
+        lo16g, up16g = loop(f1, f2, net, inp, iters=4, test_mode=True, use_graph=True)
+    assert lo16.dtype == torch.float32 and up16.dtype == torch.float32
+    assert (up16 - up32).abs().mean().item() < 0.05 and (up16 - up32).abs().max().item() < 1.0
+    # fp16 convolutions: MIOpen may pick another algorithm for the captured replay -> fp16-level differences
+    assert (up16g - up16).abs().mean().item() < 0.02 and (up16g - up16).abs().max().item() < 0.5
+
+
 def test_lowcnn_gru_loop_graph_matches_eager(S):
     B, D, h, w = 2, 24, 36, 60
     torch.manual_seed(1)
