@@ -71,17 +71,17 @@ class RAFTStereoLoop(nn.Module):
                                                       hidden_dims=self.hidden_dims)
         self._graphs = _GraphCache()
 
-    def _iteration(self, corr_fn, coords0, coords1, net_list, inp_list):
+    def _iteration(self, corr_fn, coords0, coords1, net_list, inp_list, need_mask=True):
         coords1 = coords1.detach()                                  # raft_stereo.py:171
         corr = corr_fn(coords1)                                     # :173
         flow = coords1 - coords0
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision):    # :176
             net_list, up_mask, delta_flow = self.update_block(net_list, inp_list, corr, flow,
                                                               iter32=self.n_gru_layers == 3,
-                                                              iter16=self.n_gru_layers >= 2)
+                                                              iter16=self.n_gru_layers >= 2, need_mask=need_mask)
         delta_flow = delta_flow.float()
         delta_flow[:, 1] = 0.0                                      # :180
-        return net_list, up_mask.float(), coords1 + delta_flow
+        return net_list, None if up_mask is None else up_mask.float(), coords1 + delta_flow
 
     def forward(self, fmap1, fmap2, net_list, inp_list, iters=12, flow_init=None, test_mode=False, use_graph=False):
         """fmap1/fmap2 [B,256,H/4,W/4] (fnet outputs), net_list: tanh'ed hidden states per scale,
@@ -122,8 +122,10 @@ class RAFTStereoLoop(nn.Module):
         preds = []
         up_mask = None
         for itr in range(iters):
-            net_list, up_mask, coords1 = self._iteration(corr_fn, coords0, coords1, net_list, inp_list)
-            if test_mode and itr < iters - 1:
+            skip_up = test_mode and itr < iters - 1   # raft_stereo.py:184-185: only the last mask is read
+            net_list, up_mask, coords1 = self._iteration(corr_fn, coords0, coords1, net_list, inp_list,
+                                                         need_mask=not skip_up)
+            if skip_up:
                 continue
             if up_mask is None:
                 flow_up = upflow8(coords1 - coords0)
@@ -153,8 +155,8 @@ class LowCNNGRULoop(nn.Module):
 
             def fn(ts):
                 d, hid = ts[1], torch.zeros_like(hidden)
-                for _ in range(iters):
-                    d, hid, mask = self.update(ts[0], d, ts[2], ts[3], hid, True)
+                for it in range(iters):   # only the last iterate is upsampled: earlier mask heads are skipped
+                    d, hid, mask = self.update(ts[0], d, ts[2], ts[3], hid, True, need_mask=it == iters - 1)
                 return [upsample_convex8(d, mask)]
 
             key = (tuple(cost_volume.shape), tuple(left_image.shape), iters, cost_volume.device.index)

@@ -210,10 +210,13 @@ class DisparityUpdateDLCWithMask(nn.Module):
             nn.Conv2d(self.hidden_dim * 2, 256, 3, padding=1), nn.ReLU(inplace=True),
             nn.Conv2d(256, 64 * 9, 1, padding=0))
 
-    def forward(self, old_cost_volume, cur_disp, left_image, right_image, hidden_state=None, consider_valid=True):
+    def forward(self, old_cost_volume, cur_disp, left_image, right_image, hidden_state=None, consider_valid=True,
+                need_mask=True):
+        """``need_mask=False`` (not in the reference) skips the upsampling-mask head (returns ``None`` for it): an
+        inference loop that only upsamples its last iterate does not need the earlier masks."""
         offset_features = self.encoder(old_cost_volume, cur_disp, left_image, right_image)
         hidden_state = self.gru(offset_features, hidden_state)
-        mask = .25 * self.mask(hidden_state)
+        mask = .25 * self.mask(hidden_state) if need_mask else None
         bounds = self.offset(hidden_state)          # [B,2,h,w]: (lower offset, upper offset)
         disp = bounds_lookup(old_cost_volume, cur_disp, bounds, self.sample_points, consider_valid)
         return disp, hidden_state, mask

@@ -120,7 +120,11 @@ class BasicMultiUpdateBlock_LZH(nn.Module):
         self.mask = nn.Sequential(_conv(h08, 256, 3), nn.ReLU(inplace=True),
                                   _conv(256, 9 * (2 ** n_downsample) ** 2, 1))
 
-    def forward(self, net, inp, corr=None, flow=None, iter08=True, iter16=True, iter32=True, update=True):
+    def forward(self, net, inp, corr=None, flow=None, iter08=True, iter16=True, iter32=True, update=True,
+                need_mask=True):
+        """``need_mask=False`` (not in the reference) skips the upsampling-mask head and returns ``None`` for it: in
+        ``test_mode`` the reference computes the mask in every iteration but only reads the last one
+        (``raft_stereo.py:184-185``) -- 13 % of the block's FLOPs."""
         if iter32:
             net[2] = self.gru32(net[2], *inp[2], pool2x(net[1]))
         if iter16:
@@ -131,4 +135,5 @@ class BasicMultiUpdateBlock_LZH(nn.Module):
             net[0] = self.gru08(net[0], *inp[0], self.encoder(flow, corr), *extra)
         if not update:
             return net
-        return net, 0.25 * self.mask(net[0]), self.flow_head(net[0])  # mask scaled to balance gradients (:176)
+        mask = 0.25 * self.mask(net[0]) if need_mask else None  # scaled to balance gradients (:176)
+        return net, mask, self.flow_head(net[0])
