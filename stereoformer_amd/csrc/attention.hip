@@ -6,9 +6,12 @@
 //   take part, exactly like the zero-filled volume of A1 fed to A4; 'neginf':
 //   they are excluded);  disp[w] = sum_d P[d]*d;  out[:,w] = sum_d P[d]*V[:,w-d].
 //
-// v1 (this file): one workgroup per (row, 64 queries); the band logits live in
-// LDS ([D][64] floats), features are staged in 32-channel chunks, and the
-// softmax never leaves the CU (the [B,H,W,D] score tensor is not materialised).
+// Kernels in this file, newest last (the dispatcher at the bottom picks the newest that applies):
+//   v1  VALU/LDS: one workgroup per (row, 64 queries), band logits in LDS.  Last-resort fallback.
+//   v2  f32 MFMA for both contractions, probabilities through an LDS score sheet (ragged W, D > 256).
+//   v4  scores stay in the MFMA accumulators, two-pass softmax (any C / Cv / value tensor).
+//   v5  v4 + online softmax + persistent prefetching workgroups (C <= 32, value = right features).
+// The [B,H,W,D] score tensor is never materialised in HBM by any of them.
 #include <stdlib.h>
 
 #include "common.h"
@@ -101,16 +104,7 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(const float *__res
 
 
 // ---------------------------------------------------------------------------
-// v2: both contractions on the matrix cores (exact-f32 v_mfma_f32_32x32x2_f32).
-// WG = (row, 64 queries), 4 waves.
-//  phase 1  S^T[key][query] = K Q^T: A <- right-feature tile (rows = keys), B <- left tile
-//           (cols = queries), accumulated over 32-channel chunks staged in LDS; each wave owns
-//           one 32-query tile x four 32-key tiles (64 accumulator registers).  The band
-//           entries are scattered into the LDS score sheet P[d][query], d = query - key.
-//  phase 2  masked softmax over d per query on the score sheet (never leaves the CU) + disp.
-//  phase 3  O^T[c][query] = V^T P: A <- value tile (rows = channels), B <- P read back along
-//           the band (address 65*q - 64*key: conflict-free); waves split the key range and
-//           meet in LDS; stores are 128-B W-contiguous row segments.
+// staging helper of the LDS-score-sheet kernel (v2) below
 
 // Stage ROWS x ncols floats (ncols % 4 == 0): dst[r*dstride + x] = (r < nrows && 0 <= wstart+x < W) ?
 // src[r*cstride + wstart + x] : 0.  VEC: 16-byte global loads (W % 4 == 0, wstart % 4 == 0, aligned

@@ -1,14 +1,16 @@
 // Cost-volume builders (A1 correlation, A2 difference/concat, A3 group-wise).
 //
 // Correlation / group-wise volume:   vol[b,g,d,h,w] = mean_{c in g} L[b,c,h,w] * R[b,c,h,w-d]
-// (0.0 for w < d).  One workgroup = one image row segment of TW=256 pixels of
-// one (batch, group): the left tile [CC][TW] and the right tile with its
-// disparity halo [CC][TW+Dpad] are staged in LDS with coalesced 16-byte loads
-// along W; each of the 8 waves owns one chunk of DC disparities and keeps a
-// DC x 4 accumulator block in registers (lane = 4 consecutive pixels), reading
-// the right tile as a sliding window of ds_read_b128.  Every store is a full
-// 1-KiB W-contiguous wave store (16 B/lane); the w<d zeros are written by the
-// same kernel (the reference's new_zeros pass does not exist here).
+// (0.0 for w < d).  Common scheme of the three kernels below: a workgroup owns an image-row segment of TW=256 pixels;
+// the left tile [CC][TW] and the right tile with its disparity halo [CC][TW+Dpad] are staged in LDS with coalesced
+// 16-byte loads along W; each wave owns a strip of DC disparities and keeps a DC x 4 accumulator block in registers
+// (lane = 4 consecutive pixels), reading the right tile as a sliding window of ds_read_b128.  Every store is a full
+// 1-KiB W-contiguous wave store (16 B/lane); the w<d zeros are written by the same kernel (the reference's new_zeros
+// pass does not exist here).
+//   gwc_volume_kernel       generic (ragged W, D > 256): one (batch, group) per workgroup, a barrier per chunk
+//   gwc_volume_pipe_kernel  the fast path: software pipeline over rows x groups x chunks (default)
+//   gwc_volume_pk_kernel    channel-pair packed FMA experiment (opt-in, STEREO_VOL_CFG=-dc,nw)
+// Epilogues: store the volume, fold it into a soft-argmin (A1+A4, nothing stored), or both.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -20,9 +22,6 @@ constexpr int TW = 256;  // pixels per tile: 64 lanes x 4
 constexpr int NW = 8;    // waves per workgroup
 constexpr int NT = NW * 64;
 constexpr int CCMAX = 8;  // channels staged per LDS round
-#ifndef STEREO_PIPE_NW
-#define STEREO_PIPE_NW 4  // waves per workgroup of the pipelined store kernel
-#endif
 
 // EPI_STORE: write the volume.  EPI_ARGMIN: fold every disparity plane into an
 // online softmax-expectation instead (A1+A4 fused; `vol` is then disp [B,H,W]
@@ -361,8 +360,40 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
         // loads issued a whole item ago and the PREVIOUS group's stores, which had this item's math to drain
         // (vmcnt counts loads and stores in one in-order queue).
         if (it + 1 < nitems) commit((it + 1) & 1);
+        if (DO_ARGMIN && ck == nchunk - 1 && active) {
+            // soft-argmin epilogue, placed before the next loads are issued (the prefetch registers are dead here).  The
+            // store+argmin variant (EPI_BOTH) still spills 13 VGPRs at its 168-register budget; measured cost ~nil.
+            const int w = w0 + wl;
+            // G == 1 here (launcher), so the end of the group is the end of the row: this wave's softmax state over
+            // its DC planes goes straight to the LDS exchange (no state carried across items -- with the store
+            // epilogue in the same kernel those registers, and a DC-float logit array, spilled to scratch).  The
+            // logit of (dd, i) is recomputed from the accumulator in both passes.
+            float *stt = reinterpret_cast<float *>(smem4) + 2 * BUF;  // [3][NWV][TW], its own LDS region
+            auto logit = [&](int dd, int i) {
+                const float m = exact_div ? acc[dd][i] / (float)CPG : acc[dd][i] * inv_cpg;
+                return (w + i >= d0 + dd) ? sgn * m : sgn * 0.0f;
+            };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float cm = -INFINITY;
+#pragma unroll
+                for (int dd = 0; dd < DC; ++dd)
+                    if (d0 + dd < D) cm = fmaxf(cm, logit(dd, i));
+                float ss = 0.0f, ee = 0.0f;
+#pragma unroll
+                for (int dd = 0; dd < DC; ++dd)
+                    if (d0 + dd < D) {
+                        const float p = fast_exp(logit(dd, i) - cm);
+                        ss += p;
+                        ee = fmaf(p, (float)(d0 + dd), ee);
+                    }
+                stt[(0 * NWV + wave) * TW + wl + i] = cm;
+                stt[(1 * NWV + wave) * TW + wl + i] = ss;
+                stt[(2 * NWV + wave) * TW + wl + i] = ee;
+            }
+        }
         if (it + 2 < nitems) item_loads(it + 2);
-        if (ck == nchunk - 1 && active) {  // group finished: epilogue
+        if (DO_STORE && ck == nchunk - 1 && active) {  // group finished: store epilogue
             const int w = w0 + wl;
             if (DO_STORE) {
                 float *vbase = vol + (((size_t)b * G + g) * D) * HW + (size_t)h * W;
@@ -389,35 +420,6 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
                             if (w + 3 < W) st4(vbase + (size_t)d * HW + w, o);
                         }
                     }
-                }
-            }
-            if (DO_ARGMIN) {
-                // G == 1 here (launcher), so the end of the group is the end of the row: this wave's softmax state over
-                // its DC planes goes straight to the LDS exchange (no state carried across items -- with the store
-                // epilogue in the same kernel those registers, and a DC-float logit array, spilled to scratch).  The
-                // logit of (dd, i) is recomputed from the accumulator in both passes.
-                float *stt = reinterpret_cast<float *>(smem4) + 2 * BUF;  // [3][NWV][TW], its own LDS region
-                auto logit = [&](int dd, int i) {
-                    const float m = exact_div ? acc[dd][i] / (float)CPG : acc[dd][i] * inv_cpg;
-                    return (w + i >= d0 + dd) ? sgn * m : sgn * 0.0f;
-                };
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float cm = -INFINITY;
-#pragma unroll
-                    for (int dd = 0; dd < DC; ++dd)
-                        if (d0 + dd < D) cm = fmaxf(cm, logit(dd, i));
-                    float ss = 0.0f, ee = 0.0f;
-#pragma unroll
-                    for (int dd = 0; dd < DC; ++dd)
-                        if (d0 + dd < D) {
-                            const float p = fast_exp(logit(dd, i) - cm);
-                            ss += p;
-                            ee = fmaf(p, (float)(d0 + dd), ee);
-                        }
-                    stt[(0 * NWV + wave) * TW + wl + i] = cm;
-                    stt[(1 * NWV + wave) * TW + wl + i] = ss;
-                    stt[(2 * NWV + wave) * TW + wl + i] = ee;
                 }
             }
         }
