@@ -95,8 +95,14 @@ struct PyrOut {
     int nfused;  // levels 1..nfused are written by the all-pairs epilogue
 };
 
+// f32 MFMA and VALU instructions serialise on a gfx950 SIMD (tools/mfma_coexec.hip), so the epilogue's instruction
+// count is paid in MFMA time: FUSE = false (default) is the lean form -- one multiply (or, when sqrt(C) is not a power
+// of two, one true division) and one store per output, 32-bit offsets from a workgroup-uniform base, no bounds tests on
+// interior tiles.  FUSE = true additionally produces pooled levels with cross-lane adds (opt-in, slower).
+template <bool FUSE>
 __global__ __launch_bounds__(256) void allpairs_lds_kernel(const float *__restrict__ f1, const float *__restrict__ f2,
-                                                           PyrOut pyr, int C, int H, int W1, int W2, float sqrt_c)
+                                                           PyrOut pyr, int C, int H, int W1, int W2, float sqrt_c,
+                                                           float inv_sqrt_c, int mul_exact)
 {
     float *__restrict__ out = pyr.p[0];
     __shared__ float As[2][AP_KC][128];
@@ -165,11 +171,40 @@ __global__ __launch_bounds__(256) void allpairs_lds_kernel(const float *__restri
         }
         __syncthreads();
     }
-    // epilogue: level 0 plus the first pooled levels.  Level l+1 = mean of adjacent pairs of level l
+    const int jb0 = N0 + nw + l31, jb1 = jb0 + 32;
+    auto scaled = [&](float v) { return mul_exact ? v * inv_sqrt_c : v / sqrt_c; };  // corr.py:110 divides by sqrt(C)
+    if (!FUSE) {
+        // launcher: W1 * W2 < 2^31, so a row block's offsets fit 32 bits next to the uniform 64-bit base
+        float *ob = out + (size_t)bh * W1 * W2;
+        const unsigned off0 = (unsigned)(M0 + mw + 4 * half) * (unsigned)W2 + (unsigned)jb0;
+        const bool interior = M0 + 128 <= W1 && N0 + 128 <= W2;  // workgroup-uniform
+        if (interior) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned o = off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)W2;
+                ob[o] = scaled(acc00[r]);
+                ob[o + 32] = scaled(acc01[r]);
+                ob[o + 32u * (unsigned)W2] = scaled(acc10[r]);
+                ob[o + 32u * (unsigned)W2 + 32] = scaled(acc11[r]);
+            }
+        } else {
+            const bool okj0 = jb0 < W2, okj1 = jb1 < W2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int w1a = M0 + mw + 4 * half + (r & 3) + 8 * (r >> 2);
+                const unsigned o = off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)W2;
+                if (w1a < W1 && okj0) ob[o] = scaled(acc00[r]);
+                if (w1a < W1 && okj1) ob[o + 32] = scaled(acc01[r]);
+                if (w1a + 32 < W1 && okj0) ob[o + 32u * (unsigned)W2] = scaled(acc10[r]);
+                if (w1a + 32 < W1 && okj1) ob[o + 32u * (unsigned)W2 + 32] = scaled(acc11[r]);
+            }
+        }
+        return;
+    }
+    // fused epilogue: level 0 plus the first pooled levels.  Level l+1 = mean of adjacent pairs of level l
     // (corr.py:70-76): adjacent columns are adjacent lanes, so each level is one cross-lane add on the
     // already rounded level-l value -- bit-identical to pooling the stored level.
     const size_t rowbase = (size_t)bh * W1;
-    const int jb0 = N0 + nw + l31, jb1 = jb0 + 32;
     auto emit = [&](float v, int w1, int jb) {
         if (w1 < W1 && jb < W2) out[(rowbase + w1) * W2 + jb] = v;
         float cur = v;
@@ -187,10 +222,10 @@ __global__ __launch_bounds__(256) void allpairs_lds_kernel(const float *__restri
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
         const int w1a = M0 + mw + row, w1b = w1a + 32;
-        emit(acc00[r] / sqrt_c, w1a, jb0);
-        emit(acc01[r] / sqrt_c, w1a, jb1);
-        emit(acc10[r] / sqrt_c, w1b, jb0);
-        emit(acc11[r] / sqrt_c, w1b, jb1);
+        emit(scaled(acc00[r]), w1a, jb0);
+        emit(scaled(acc01[r]), w1a, jb1);
+        emit(scaled(acc10[r]), w1b, jb0);
+        emit(scaled(acc11[r]), w1b, jb1);
     }
 }
 
@@ -204,6 +239,43 @@ __global__ __launch_bounds__(256) void avgpool_w2_kernel(const float *__restrict
         const int x = (int)(t - r * Wout);
         const float *p = in + (size_t)r * Win + 2 * x;
         out[t] = (p[0] + p[1]) * 0.5f;
+    }
+}
+
+// Pyramid levels 1..NL from level 0 in ONE pass (W0 % 2^NL == 0, 16-B aligned): a lane owns 2^NL consecutive level-0
+// values (16-B loads), pools them NL times in registers -- each level from the already rounded previous one, exactly
+// like NL successive avg_pool calls -- and writes every level.  Level 0 is read once instead of every level twice.
+template <int NL>
+__global__ __launch_bounds__(256) void avgpool_pyramid_kernel(const float *__restrict__ l0, PyrOut pyr, int W0,
+                                                              long long ngroups)
+{
+    constexpr int G0 = 1 << NL;  // level-0 values per lane
+    const int gpr = W0 / G0;     // groups per row
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < ngroups;
+         t += (long long)gridDim.x * blockDim.x) {
+        const long long row = t / gpr;
+        const int gx = (int)(t - row * gpr);
+        float v[G0];
+        const float *src = l0 + (size_t)row * W0 + (size_t)gx * G0;
+#pragma unroll
+        for (int q = 0; q < G0 / 4; ++q) {
+            const f32x4 x = ld4(src + 4 * q);
+            v[4 * q + 0] = x[0], v[4 * q + 1] = x[1], v[4 * q + 2] = x[2], v[4 * q + 3] = x[3];
+        }
+#pragma unroll
+        for (int l = 1; l <= NL; ++l) {
+            const int n = G0 >> l;  // values of level l owned by this lane
+#pragma unroll
+            for (int k = 0; k < n; ++k) v[k] = (v[2 * k] + v[2 * k + 1]) * 0.5f;
+            float *dst = pyr.p[l] + (size_t)row * pyr.w[l] + (size_t)gx * n;
+            if (n >= 4) {
+#pragma unroll
+                for (int q = 0; q < n / 4; ++q) st4(dst + 4 * q, (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+            } else {
+#pragma unroll
+                for (int k = 0; k < n; ++k) dst[k] = v[k];
+            }
+        }
     }
 }
 
@@ -343,14 +415,41 @@ extern "C" int stereo_allpairs_pyramid_f32(const float *fmap1, const float *fmap
             if (AP_FUSE_PYRAMID && i >= 1 && i <= AP_MAX_FUSED && w > 0) pyr.nfused = i;
         }
         first_unpooled = pyr.nfused + 1;
-        hipLaunchKernelGGL(allpairs_lds_kernel, grid, dim3(256), 0, st, fmap1, fmap2, pyr, C, H, W1, W2,
-                           sqrtf((float)C));
+        const float sq = sqrtf((float)C);
+        int e2 = 0;
+        const int mul_exact = frexpf(sq, &e2) == 0.5f ? 1 : 0;  // sqrt(C) a power of two: x * (1/sqrt) == x / sqrt
+        if (pyr.nfused > 0 || (long long)W1 * W2 >= (1LL << 31))
+            hipLaunchKernelGGL(allpairs_lds_kernel<true>, grid, dim3(256), 0, st, fmap1, fmap2, pyr, C, H, W1, W2, sq,
+                               1.0f / sq, mul_exact);
+        else
+            hipLaunchKernelGGL(allpairs_lds_kernel<false>, grid, dim3(256), 0, st, fmap1, fmap2, pyr, C, H, W1, W2, sq,
+                               1.0f / sq, mul_exact);
     } else {
         hipLaunchKernelGGL(allpairs_kernel, grid, dim3(256), 0, st, fmap1, fmap2, levels[0], C, H, W1, W2,
                            sqrtf((float)C));
     }
     STEREO_LAUNCH_CHECK();
     const long long rows = (long long)B * H * W1;
+    if (first_unpooled == 1 && num_levels >= 2) {  // levels 1..NL in one pass over level 0
+        const int NL = num_levels >= 4 ? 4 : num_levels >= 3 ? 3 : 2;
+        bool ok = W2 % (1 << NL) == 0 && aligned16(levels[0]);
+        for (int i = 1; i <= NL; ++i) ok = ok && aligned16(levels[i]);
+        // 16-B stores of level l need (W2 >> l) * 4 B rows to keep 16-B alignment per lane group: W2 % 2^NL == 0 gives
+        // a lane (2^NL >> l) values at offset gx * (2^NL >> l); st4 is used only when that count is a multiple of 4
+        for (int i = 1; i <= NL; ++i)
+            if (((1 << NL) >> i) >= 4 && (W2 >> i) % 4 != 0) ok = false;
+        if (ok) {
+            PyrOut pyr;
+            pyr.nfused = 0;
+            for (int i = 0, w = W2; i <= NL; ++i, w /= 2) pyr.p[i] = levels[i], pyr.w[i] = w;
+            const long long ng = rows * (W2 >> NL);
+            if (NL == 4) hipLaunchKernelGGL(avgpool_pyramid_kernel<4>, dim3(grid_for(ng)), dim3(256), 0, st, levels[0], pyr, W2, ng);
+            else if (NL == 3) hipLaunchKernelGGL(avgpool_pyramid_kernel<3>, dim3(grid_for(ng)), dim3(256), 0, st, levels[0], pyr, W2, ng);
+            else hipLaunchKernelGGL(avgpool_pyramid_kernel<2>, dim3(grid_for(ng)), dim3(256), 0, st, levels[0], pyr, W2, ng);
+            STEREO_LAUNCH_CHECK();
+            first_unpooled = NL + 1;
+        }
+    }
     for (int i = 1, w = W2; i <= num_levels; ++i) {
         const int wo = w / 2;
         if (wo == 0) break;
