@@ -7,6 +7,7 @@ R=${1:-r01}
 O=gpurun_out/refresh_$R
 mkdir -p $O profiles
 timeout -k 10 600 python3 tools/kernel_bench.py > $O/kernel_bench.log 2>&1 && cp gpurun_out/kernel_bench.json profiles/${R}_kernel_bench.json
+timeout -k 10 600 python3 tools/bench_configs.py > $O/bench_configs.jsonl 2> $O/bench_configs.err && cp $O/bench_configs.jsonl profiles/${R}_bench_configs.jsonl
 timeout -k 10 300 python3 bench.py > $O/bench.json 2> $O/bench.err && cp $O/bench.json profiles/${R}_bench_line.json
 timeout -k 10 300 python3 bench.py --reread --no-cpu-baseline > $O/bench_reread.json 2>> $O/bench.err && cp $O/bench_reread.json profiles/${R}_bench_line_reread.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o run --output-format csv -- python3 bench.py --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
