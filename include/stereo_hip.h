@@ -171,6 +171,13 @@ int stereo_gru_reset_f32(const float *h, const float *rc, const float *cr, float
 int stereo_gru_blend_f32(const float *h, const float *zc, const float *qc, const float *cz,
                          const float *cq, float *out, long long n, int softsign, void *stream);
 
+/* The same two gates with fp16 tensors in and out (gate math in fp32 registers): the update block under the
+ * reference's optional mixed_precision flag (raft_stereo.py:176) hands over fp16 convolution outputs. */
+int stereo_gru_reset_f16(const void *h, const void *rc, const void *cr, void *out, long long n,
+                         void *stream);
+int stereo_gru_blend_f16(const void *h, const void *zc, const void *qc, const void *cz,
+                         const void *cq, void *out, long long n, int softsign, void *stream);
+
 /* ---- backward: the cfg-2 chain is differentiable -------------------------------- */
 
 /* backward of A4 (estimation.py:14-33,44-62): grad_disp [B,H,W], optional grad_prob [B,D,H,W] (the WithProb

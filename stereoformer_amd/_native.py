@@ -62,6 +62,8 @@ SIGNATURES = {
     "stereo_resize_bilinear_bwd_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "stereo_gru_reset_f32": [_vp, _vp, _vp, _vp, _ll, _vp],
     "stereo_gru_blend_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp],
+    "stereo_gru_reset_f16": [_vp, _vp, _vp, _vp, _ll, _vp],
+    "stereo_gru_blend_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp],
 }
 _RESTYPE = {"stereo_strerror": ctypes.c_char_p, "stereo_alt_corr_workspace_floats": _ll}
 
@@ -111,8 +113,9 @@ def ptr(t: torch.Tensor | None) -> ctypes.c_void_p:
     return _vp(0) if t is None else _vp(t.data_ptr())
 
 
-def dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
-    """Validate an op input: HIP device, fp32; returns it contiguous."""
+def dev_f32(t: torch.Tensor, name: str, dense_ok: bool = False) -> torch.Tensor:
+    """Validate an op input: HIP device, fp32; returns it contiguous (NCHW).  ``dense_ok``: a channels-last dense
+    tensor is returned as is -- for pointwise ops, which only need all operands in ONE dense layout."""
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
     if not t.is_cuda:
@@ -125,7 +128,18 @@ def dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
         raise RuntimeError(
             f"{name}: this op is forward-only (backward exists for CostVolume('correlation'), build_gwc_volume, "
             "DisparityEstimation(WithProb) and LocalCostVolume - SURVEY 8(f) N3); call under torch.no_grad()")
+    if dense_ok and t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return t
     return t.contiguous()
+
+
+def one_layout(*ts):
+    """Pointwise ops index the storage flat: every (non-None) operand must have the same strides.  Returns the
+    operands unchanged when they do, NCHW-contiguous copies otherwise."""
+    live = [t for t in ts if t is not None]
+    if all(t.stride() == live[0].stride() for t in live):
+        return ts
+    return tuple(None if t is None else t.contiguous() for t in ts)
 
 
 def same_device(*ts: torch.Tensor) -> torch.device:

@@ -58,6 +58,62 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict_
     }
 }
 
+// fp16 in / fp16 out variants for the update block under the reference's mixed_precision flag (fp16 convolutions):
+// the gate math itself stays fp32 in registers; 8 halves (16 B) per lane.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int V>
+__global__ __launch_bounds__(256) void gru_reset_f16_kernel(const _Float16 *__restrict__ h, const _Float16 *__restrict__ rc,
+                                                            const _Float16 *__restrict__ cr, _Float16 *__restrict__ out,
+                                                            long long nvec)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nvec;
+         t += (long long)gridDim.x * blockDim.x) {
+        if (V == 8) {
+            const f16x8 hv = *reinterpret_cast<const f16x8 *>(h + t * 8), rv = *reinterpret_cast<const f16x8 *>(rc + t * 8);
+            f16x8 bv = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (cr) bv = *reinterpret_cast<const f16x8 *>(cr + t * 8);
+            f16x8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (_Float16)(sigmoidf_((float)rv[i] + (float)bv[i]) * (float)hv[i]);
+            *reinterpret_cast<f16x8 *>(out + t * 8) = o;
+        } else {
+            out[t] = (_Float16)(sigmoidf_((float)rc[t] + (cr ? (float)cr[t] : 0.0f)) * (float)h[t]);
+        }
+    }
+}
+
+template <int V, bool SOFTSIGN>
+__global__ __launch_bounds__(256) void gru_blend_f16_kernel(const _Float16 *__restrict__ h, const _Float16 *__restrict__ zc,
+                                                            const _Float16 *__restrict__ qc, const _Float16 *__restrict__ cz,
+                                                            const _Float16 *__restrict__ cq, _Float16 *__restrict__ out,
+                                                            long long nvec)
+{
+    auto one = [](float hv, float zv, float qv) {
+        const float z = sigmoidf_(zv);
+        const float q = SOFTSIGN ? qv / (1.0f + fabsf(qv)) : tanhf(qv);
+        return (1.0f - z) * hv + z * q;
+    };
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nvec;
+         t += (long long)gridDim.x * blockDim.x) {
+        if (V == 8) {
+            const f16x8 hv = *reinterpret_cast<const f16x8 *>(h + t * 8), zv = *reinterpret_cast<const f16x8 *>(zc + t * 8),
+                        qv = *reinterpret_cast<const f16x8 *>(qc + t * 8);
+            f16x8 bz = {0, 0, 0, 0, 0, 0, 0, 0}, bq = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (cz) bz = *reinterpret_cast<const f16x8 *>(cz + t * 8);
+            if (cq) bq = *reinterpret_cast<const f16x8 *>(cq + t * 8);
+            f16x8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                o[i] = (_Float16)one((float)hv[i], (float)zv[i] + (float)bz[i], (float)qv[i] + (float)bq[i]);
+            *reinterpret_cast<f16x8 *>(out + t * 8) = o;
+        } else {
+            out[t] = (_Float16)one((float)h[t], (float)zc[t] + (cz ? (float)cz[t] : 0.0f),
+                                   (float)qc[t] + (cq ? (float)cq[t] : 0.0f));
+        }
+    }
+}
+
 inline unsigned grid_for(long long nthreads)
 {
     long long blocks = (nthreads + 255) / 256;
@@ -105,6 +161,53 @@ extern "C" int stereo_gru_blend_f32(const float *h, const float *zc, const float
     else if (softsign) BLEND(1, true);
     else BLEND(1, false);
 #undef BLEND
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+extern "C" int stereo_gru_reset_f16(const void *h, const void *rc, const void *cr, void *out, long long n, void *stream)
+{
+    if (n < 0) return STEREO_ERR_BAD_SHAPE;
+    if (n == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(h);
+    STEREO_REQUIRE_PTR(rc);
+    STEREO_REQUIRE_PTR(out);
+    const _Float16 *hh = static_cast<const _Float16 *>(h), *rr = static_cast<const _Float16 *>(rc),
+                   *cc = static_cast<const _Float16 *>(cr);
+    _Float16 *oo = static_cast<_Float16 *>(out);
+    if (n % 8 == 0 && aligned16(h) && aligned16(rc) && aligned16(out) && (cr == nullptr || aligned16(cr)))
+        hipLaunchKernelGGL(gru_reset_f16_kernel<8>, dim3(grid_for(n / 8)), dim3(256), 0, as_stream(stream), hh, rr, cc, oo,
+                           n / 8);
+    else
+        hipLaunchKernelGGL(gru_reset_f16_kernel<1>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), hh, rr, cc, oo, n);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+extern "C" int stereo_gru_blend_f16(const void *h, const void *zc, const void *qc, const void *cz, const void *cq, void *out,
+                                    long long n, int softsign, void *stream)
+{
+    if (n < 0) return STEREO_ERR_BAD_SHAPE;
+    if (n == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(h);
+    STEREO_REQUIRE_PTR(zc);
+    STEREO_REQUIRE_PTR(qc);
+    STEREO_REQUIRE_PTR(out);
+    hipStream_t st = as_stream(stream);
+    const bool v8 = n % 8 == 0 && aligned16(h) && aligned16(zc) && aligned16(qc) && aligned16(out) &&
+                    (cz == nullptr || aligned16(cz)) && (cq == nullptr || aligned16(cq));
+    const long long nv = v8 ? n / 8 : n;
+    const _Float16 *hh = static_cast<const _Float16 *>(h), *zz = static_cast<const _Float16 *>(zc),
+                   *qq = static_cast<const _Float16 *>(qc), *bz = static_cast<const _Float16 *>(cz),
+                   *bq = static_cast<const _Float16 *>(cq);
+    _Float16 *oo = static_cast<_Float16 *>(out);
+#define BLEND16(V, S) \
+    hipLaunchKernelGGL((gru_blend_f16_kernel<V, S>), dim3(grid_for(nv)), dim3(256), 0, st, hh, zz, qq, bz, bq, oo, nv)
+    if (v8 && softsign) BLEND16(8, true);
+    else if (v8) BLEND16(8, false);
+    else if (softsign) BLEND16(1, true);
+    else BLEND16(1, false);
+#undef BLEND16
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }

@@ -55,12 +55,16 @@ class _GraphCache:
 
 class RAFTStereoLoop(nn.Module):
     def __init__(self, hidden_dims=(128, 128, 128), downsample=2, corr_levels=4, corr_radius=4, n_gru_layers=3,
-                 mixed_precision=False):
-        """``mixed_precision``: the reference's flag of the same name (``raft_stereo.py:176``): the update block's
+                 mixed_precision=False, channels_last=False):
+        """``channels_last``: keep the update block's weights and activations in NHWC (MIOpen's convolutions are
+        17 % (fp32) to 2x (fp16) faster there and need no layout transposes); the pointwise HIP kernels take either
+        dense layout, lookups / upsampling convert their small inputs.  Same arithmetic, off by default.
+        ``mixed_precision``: the reference's flag of the same name (``raft_stereo.py:176``): the update block's
         convolutions run under fp16 ``autocast``; correlation, lookup, gate math, coordinates and the convex
         upsampling stay fp32.  Off by default -- fp32 is the parity configuration."""
         super().__init__()
         self.mixed_precision = bool(mixed_precision)
+        self.channels_last = bool(channels_last)
         self.hidden_dims = list(hidden_dims)
         self.downsample = downsample
         self.corr_levels = corr_levels
@@ -107,7 +111,7 @@ class RAFTStereoLoop(nn.Module):
                                       test_mode)
             return list(out)
 
-        key = (tuple(tuple(t.shape) for t in flat), iters, bool(test_mode), flat[0].device.index, self.mixed_precision)
+        key = (tuple(tuple(t.shape) for t in flat), iters, bool(test_mode), flat[0].device.index, self.mixed_precision, self.channels_last)
         out = self._graphs.run(key, fn, flat)
         return tuple(out) if test_mode else out
 
@@ -119,6 +123,13 @@ class RAFTStereoLoop(nn.Module):
         if flow_init is not None:
             coords1 = coords1 + flow_init
         net_list = [n.contiguous() for n in net_list]   # a private list: the update block writes into it
+        if self.mixed_precision and not torch.is_grad_enabled():
+            inp_list = [[t.half() for t in lvl] for lvl in inp_list]   # context biases: cast once, not per iteration
+        if self.channels_last:
+            cl = torch.channels_last
+            self.update_block.to(memory_format=cl)   # no-op once converted
+            net_list = [n.contiguous(memory_format=cl) for n in net_list]
+            inp_list = [[t.contiguous(memory_format=cl) for t in lvl] for lvl in inp_list]
         preds = []
         up_mask = None
         for itr in range(iters):

@@ -63,15 +63,37 @@ class _GruBlendFn(torch.autograd.Function):
         return gh, gz, gq, (gz if has_cz else None), (gq if has_cq else None), None
 
 
+def _all_f16(*ts):
+    live = [t for t in ts if t is not None]
+    return all(t.dtype == torch.float16 and t.is_cuda for t in live)
+
+
+def _dense16(t):
+    """fp16 operand of a pointwise op: NCHW- or channels-last-dense."""
+    if t is None or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)):
+        return t
+    return t.contiguous()
+
+
 def gru_reset(h, rc, cr=None):
-    """``sigmoid(rc + cr) * h`` in one kernel (differentiable: HIP backward)."""
+    """``sigmoid(rc + cr) * h`` in one kernel (differentiable: HIP backward).  fp32 tensors; all-fp16 operands (the
+    update block under ``mixed_precision``) run the fp16-in / fp16-out kernel (inference only)."""
+    if _all_f16(h, rc, cr) and not _wants_grad(h, rc, cr):
+        h, rc, cr = N.one_layout(_dense16(h), _dense16(rc), _dense16(cr))
+        if rc.shape != h.shape or (cr is not None and cr.shape != h.shape):
+            raise ValueError("gru_reset: shape mismatch")
+        out = torch.empty_like(h)
+        with torch.cuda.device(h.device):
+            N.call("stereo_gru_reset_f16", N.ptr(h), N.ptr(rc), N.ptr(cr), N.ptr(out), h.numel(), N.stream_ptr(h.device))
+        return out
     if _wants_grad(h, rc, cr):
         return _GruResetFn.apply(h.contiguous(), rc.contiguous(), None if cr is None else cr.contiguous())
-    h = N.dev_f32(h, "gru_reset: h")
-    rc = N.dev_f32(rc, "gru_reset: rc")
-    cr = None if cr is None else N.dev_f32(cr, "gru_reset: cr")
+    h = N.dev_f32(h, "gru_reset: h", dense_ok=True)
+    rc = N.dev_f32(rc, "gru_reset: rc", dense_ok=True)
+    cr = None if cr is None else N.dev_f32(cr, "gru_reset: cr", dense_ok=True)
     if rc.shape != h.shape or (cr is not None and cr.shape != h.shape):
         raise ValueError("gru_reset: shape mismatch")
+    h, rc, cr = N.one_layout(h, rc, cr)   # NCHW or channels-last, but one layout for all (flat indexing)
     out = torch.empty_like(h)
     with torch.cuda.device(h.device):
         N.call("stereo_gru_reset_f32", N.ptr(h), N.ptr(rc), N.ptr(cr), N.ptr(out), h.numel(), N.stream_ptr(h.device))
@@ -79,18 +101,30 @@ def gru_reset(h, rc, cr=None):
 
 
 def gru_blend(h, zc, qc, cz=None, cq=None, softsign=False):
-    """``(1-z)*h + z*act(qc+cq)`` with ``z = sigmoid(zc+cz)`` in one kernel (differentiable: HIP backward)."""
+    """``(1-z)*h + z*act(qc+cq)`` with ``z = sigmoid(zc+cz)`` in one kernel (differentiable: HIP backward).  fp32
+    tensors; all-fp16 operands run the fp16-in / fp16-out kernel (inference only)."""
+    if _all_f16(h, zc, qc, cz, cq) and not _wants_grad(h, zc, qc, cz, cq):
+        h, zc, qc, cz, cq = N.one_layout(_dense16(h), _dense16(zc), _dense16(qc), _dense16(cz), _dense16(cq))
+        for t in (zc, qc, cz, cq):
+            if t is not None and t.shape != h.shape:
+                raise ValueError("gru_blend: shape mismatch")
+        out = torch.empty_like(h)
+        with torch.cuda.device(h.device):
+            N.call("stereo_gru_blend_f16", N.ptr(h), N.ptr(zc), N.ptr(qc), N.ptr(cz), N.ptr(cq), N.ptr(out), h.numel(),
+                   1 if softsign else 0, N.stream_ptr(h.device))
+        return out
     if _wants_grad(h, zc, qc, cz, cq):
         c = lambda t: None if t is None else t.contiguous()
         return _GruBlendFn.apply(h.contiguous(), zc.contiguous(), qc.contiguous(), c(cz), c(cq), bool(softsign))
-    h = N.dev_f32(h, "gru_blend: h")
-    zc = N.dev_f32(zc, "gru_blend: zc")
-    qc = N.dev_f32(qc, "gru_blend: qc")
-    cz = None if cz is None else N.dev_f32(cz, "gru_blend: cz")
-    cq = None if cq is None else N.dev_f32(cq, "gru_blend: cq")
+    h = N.dev_f32(h, "gru_blend: h", dense_ok=True)
+    zc = N.dev_f32(zc, "gru_blend: zc", dense_ok=True)
+    qc = N.dev_f32(qc, "gru_blend: qc", dense_ok=True)
+    cz = None if cz is None else N.dev_f32(cz, "gru_blend: cz", dense_ok=True)
+    cq = None if cq is None else N.dev_f32(cq, "gru_blend: cq", dense_ok=True)
     for t in (zc, qc, cz, cq):
         if t is not None and t.shape != h.shape:
             raise ValueError("gru_blend: shape mismatch")
+    h, zc, qc, cz, cq = N.one_layout(h, zc, qc, cz, cq)
     out = torch.empty_like(h)
     with torch.cuda.device(h.device):
         N.call("stereo_gru_blend_f32", N.ptr(h), N.ptr(zc), N.ptr(qc), N.ptr(cz), N.ptr(cq), N.ptr(out), h.numel(),

@@ -37,8 +37,25 @@ def _f32(t):
     return t if t is None or t.dtype == torch.float32 else t.float()
 
 
+def _fp16_inference():
+    """fp16 autocast region without gradients: activations stay fp16 between the convolutions."""
+    return (torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16
+            and not torch.is_grad_enabled())
+
+
+def _to16(t):
+    return None if t is None else (t if t.dtype == torch.float16 else t.half())
+
+
 def _gru_step(h, x, conv_z, conv_r, conv_q, cz=None, cr=None, cq=None):
-    """One ConvGRU update with optional context biases; the two pointwise stages are HIP kernels."""
+    """One ConvGRU update with optional context biases; the two pointwise stages are HIP kernels.  Under fp16
+    ``autocast`` without gradients the hidden state and the gates stay fp16 end to end (as in the reference, where the
+    autocast region turns ``net`` into fp16 after the first iteration); otherwise the gate math takes fp32 tensors."""
+    if _fp16_inference():
+        h, x = _to16(h), _to16(x)
+        hx = torch.cat((h, x), 1)
+        gated = gru_reset(h, conv_r(hx), _to16(cr))
+        return gru_blend(h, conv_z(hx), conv_q(torch.cat((gated, x), 1)), _to16(cz), _to16(cq))
     hx = torch.cat((h, x), 1)
     z_pre = conv_z(hx)
     gated = gru_reset(_f32(h), _f32(conv_r(hx)), _f32(cr))
@@ -55,6 +72,8 @@ class ConvGRU(nn.Module):
             setattr(self, "conv" + gate, _conv(hidden_dim + input_dim, hidden_dim, kernel_size))
 
     def forward(self, h, cz, cr, cq, *x_list):
+        if _fp16_inference():
+            x_list = [_to16(t) for t in x_list]   # cast the small pieces, not their concatenation
         return _gru_step(h, torch.cat(x_list, 1), self.convz, self.convr, self.convq, cz, cr, cq)
 
 
@@ -120,6 +139,13 @@ class BasicMultiUpdateBlock_LZH(nn.Module):
         self.mask = nn.Sequential(_conv(h08, 256, 3), nn.ReLU(inplace=True),
                                   _conv(256, 9 * (2 ** n_downsample) ** 2, 1))
 
+    @staticmethod
+    def _like(t, ref):
+        """``t`` in the dense layout of ``ref`` (the channels-last loop keeps every concatenation in one layout)."""
+        if ref.dim() == 4 and not ref.is_contiguous() and ref.is_contiguous(memory_format=torch.channels_last):
+            return t.contiguous(memory_format=torch.channels_last)
+        return t
+
     def forward(self, net, inp, corr=None, flow=None, iter08=True, iter16=True, iter32=True, update=True,
                 need_mask=True):
         """``need_mask=False`` (not in the reference) skips the upsampling-mask head and returns ``None`` for it: in
@@ -128,11 +154,11 @@ class BasicMultiUpdateBlock_LZH(nn.Module):
         if iter32:
             net[2] = self.gru32(net[2], *inp[2], pool2x(net[1]))
         if iter16:
-            extra = (interp(_f32(net[2]), net[1]),) if self.n_gru_layers > 2 else ()
+            extra = (self._like(interp(_f32(net[2]), net[1]), net[1]),) if self.n_gru_layers > 2 else ()
             net[1] = self.gru16(net[1], *inp[1], pool2x(net[0]), *extra)
         if iter08:
-            extra = (interp(_f32(net[1]), net[0]),) if self.n_gru_layers > 1 else ()
-            net[0] = self.gru08(net[0], *inp[0], self.encoder(flow, corr), *extra)
+            extra = (self._like(interp(_f32(net[1]), net[0]), net[0]),) if self.n_gru_layers > 1 else ()
+            net[0] = self.gru08(net[0], *inp[0], self.encoder(self._like(flow, net[0]), self._like(corr, net[0])), *extra)
         if not update:
             return net
         mask = 0.25 * self.mask(net[0]) if need_mask else None  # scaled to balance gradients (:176)

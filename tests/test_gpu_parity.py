@@ -407,6 +407,30 @@ def test_gru_pointwise(S, oracle):
         close(out, oracle.gru_reset(a[0], a[1], a[3]), rtol=1e-5, atol=2e-6)
 
 
+def test_gru_pointwise_fp16(S):
+    """fp16-in / fp16-out gate kernels (update block under mixed_precision): against the fp32 formula on the same
+    (already fp16-rounded) inputs, to about one fp16 ulp; NCHW, channels-last and odd sizes (scalar path)."""
+    torch.manual_seed(3)
+    for shape, cl in (((2, 16, 9, 12), False), ((2, 16, 9, 12), True), ((1, 3, 5, 7), False)):
+        mk = lambda: (torch.randn(shape, device="cuda") * 2).half()
+        h, a, b, c1, c2 = mk(), mk(), mk(), mk(), mk()
+        if cl:
+            h, a, b, c1, c2 = [t.contiguous(memory_format=torch.channels_last) for t in (h, a, b, c1, c2)]
+        r = S.gru_reset(h, a, c1)
+        assert r.dtype == torch.float16 and r.stride() == h.stride()
+        ref = torch.sigmoid(a.float() + c1.float()) * h.float()
+        assert (r.float() - ref).abs().max().item() < 4e-3
+        for soft in (False, True):
+            o = S.gru_blend(h, a, b, c1, c2, softsign=soft)
+            z = torch.sigmoid(a.float() + c1.float())
+            qx = b.float() + c2.float()
+            q = qx / (1 + qx.abs()) if soft else torch.tanh(qx)
+            ref = (1 - z) * h.float() + z * q
+            assert o.dtype == torch.float16 and (o.float() - ref).abs().max().item() < 6e-3
+        z = torch.sigmoid(a.float())
+        assert (S.gru_blend(h, a, b).float() - ((1 - z) * h.float() + z * torch.tanh(b.float()))).abs().max().item() < 6e-3
+
+
 # ------------------------------------------------------------------ BASELINE configs
 def test_cfg1_chain_vs_oracle(S, oracle):
     """configs[0]: 1 pair 384x768 D=64: corr -> soft-argmin -> LocalCostVolume(r=2,S=20,consider_valid)."""

@@ -148,6 +148,24 @@ def test_raft_stereo_loop_end_to_end_g9(S, golden):
     assert (lo_g - flow_lo).abs().max().item() < 5e-5 and (up_g - flow_up).abs().max().item() < 1e-4
 
 
+def test_raft_loop_channels_last_matches_reference(S, golden):
+    """NHWC weights / activations through the update block: same arithmetic, so the golden outputs of the reference
+    RAFT_Stereo (G9) must still be reproduced at the fp32 parity tolerances."""
+    g = golden("g9_raft_loop")
+    loop = S.RAFTStereoLoop(hidden_dims=[32, 32, 32], channels_last=True).eval()
+    fill_state_dict_(loop.update_block, seed=0.125, keys=list(g["keys"]), prefix="update_block.")
+    loop = loop.cuda()
+    with torch.no_grad():
+        f1, f2, net, inp = _raft_inputs(g)
+        flow_lo, flow_up = loop(f1, f2, net, inp, iters=4, test_mode=True)
+        close(flow_lo, g["flow_lo"], rtol=1e-4, atol=1e-3)
+        close(flow_up, g["flow_up"], rtol=1e-4, atol=2e-3)
+        f1, f2, net, inp = _raft_inputs(g)
+        lo_g, up_g = loop(f1, f2, net, inp, iters=4, test_mode=True, use_graph=True)
+        assert (up_g - flow_up).abs().max().item() < 1e-4
+    assert flow_up.is_contiguous()
+
+
 def test_raft_loop_mixed_precision_option(S, golden):
     """The reference's optional ``mixed_precision`` flag (update-block convolutions under fp16 autocast, everything
     else fp32): not a parity configuration -- checked to stay close to the fp32 result of the same loop."""

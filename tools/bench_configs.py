@@ -106,11 +106,12 @@ def main():
         f1, f2, nets, inps = raft_inputs(B, Hq, Wq, dev)
         roof = allpairs_roofline(f1, f2)
         for mp in (False, True):
-            loop = S.RAFTStereoLoop([128, 128, 128], mixed_precision=mp).eval().cuda()
+            loop = S.RAFTStereoLoop([128, 128, 128], mixed_precision=mp, channels_last=True).eval().cuda()
             fn = lambda: loop(f1, f2, [n.clone() for n in nets], inps, iters=16, test_mode=True, use_graph=True)
             sec = timed(fn, args.steps)
             line("cfg-4: SceneFlow 960x540 (padded 544) IterativeLocalCostVolume loop (RAFT-style update operator at 1/4 "
-                 "resolution): all-pairs pyramid + 16 x (lookup + update block + coords) + convex upsampling, batch=8 per GPU"
+                 "resolution, NHWC through the update block): all-pairs pyramid + 16 x (lookup + update block + coords) + convex "
+                 "upsampling, batch=8 per GPU"
                  + (", update-block convolutions under fp16 autocast (the reference's mixed_precision flag; NOT the "
                     "parity configuration)" if mp else ", fp32"), B, sec, args.steps, roof,
                  {"bounded_by": "MIOpen convolutions of the update block (1.2 TFLOP per iteration for 8 pairs)",
@@ -134,7 +135,7 @@ def main():
         B, Hq, Wq, Dq = 4, 96, 312, 64  # 384x1248 / 4, D = 256 / 4
         f1, f2, nets, inps = raft_inputs(B, Hq, Wq, dev)
         att = S.CrossAttentionCostVolume(Dq, "neginf", "sqrt_c")
-        loop = S.RAFTStereoLoop([128, 128, 128]).eval().cuda()
+        loop = S.RAFTStereoLoop([128, 128, 128], channels_last=True).eval().cuda()
 
         def chain():
             _, d = att(f1, f2, need_out=False)

@@ -215,11 +215,15 @@ def main():
                                          use_graph=graph), 2, 1)
                 add(f"cfg-4 RAFT loop 16 iters B=8 {'graph' if graph else 'eager'}", ms, None, 8 * (15 * 146.3 + 168.0) + 32.09,
                     bound="miopen", note=f"{8 / ms * 1e3:.1f} pairs/s per GPU; conv FLOPs dominate (MIOpen fp32); mask head only in the last iteration")
+            loop.channels_last = True     # NHWC weights / activations through the update block (same arithmetic)
+            ms = timeit(lambda: loop(f1, f2, [n.clone() for n in nets], inps, iters=16, test_mode=True, use_graph=True), 2, 1)
+            add("cfg-4 RAFT loop 16 iters B=8 channels_last graph", ms, None, 8 * (15 * 146.3 + 168.0) + 32.09, bound="miopen",
+                note=f"{8 / ms * 1e3:.1f} pairs/s per GPU; fp32, NHWC through the update block")
             loop.mixed_precision = True   # the reference's optional flag: update-block convs under fp16 autocast
             for graph in (False, True):
                 ms = timeit(lambda: loop(f1, f2, [n.clone() for n in nets], inps, iters=16, test_mode=True,
                                          use_graph=graph), 2, 1)
-                add(f"cfg-4 RAFT loop 16 iters B=8 mixed_precision {'graph' if graph else 'eager'}", ms, None,
+                add(f"cfg-4 RAFT loop 16 iters B=8 mixed_precision channels_last {'graph' if graph else 'eager'}", ms, None,
                     8 * (15 * 146.3 + 168.0) + 32.09, bound="miopen",
                     note=f"{8 / ms * 1e3:.1f} pairs/s per GPU; update-block convs fp16 (reference option), rest fp32")
         if want("loop_lowcnn"):
