@@ -360,6 +360,15 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
         // loads issued a whole item ago and the PREVIOUS group's stores, which had this item's math to drain
         // (vmcnt counts loads and stores in one in-order queue).
         if (it + 1 < nitems) commit((it + 1) & 1);
+        // the group's sums become means: x 2^-k when C/G is a power of two (exact), else ONE uniform branch to a true
+        // division pass (bit-faithful to the reference's mean) -- not a branch per element in the epilogues below
+        if (ck == nchunk - 1 && active && exact_div) {
+#pragma unroll
+            for (int dd = 0; dd < DC; ++dd)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[dd][i] = acc[dd][i] / (float)CPG;
+        }
+        const float mscale = exact_div ? 1.0f : inv_cpg;
         if (DO_ARGMIN && ck == nchunk - 1 && active) {
             // soft-argmin epilogue, placed before the next loads are issued (the prefetch registers are dead here).  The
             // store+argmin variant (EPI_BOTH) still spills 13 VGPRs at its 168-register budget; measured cost ~nil.
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
             // logit of (dd, i) is recomputed from the accumulator in both passes.
             float *stt = reinterpret_cast<float *>(smem4) + 2 * BUF;  // [3][NWV][TW], its own LDS region
             auto logit = [&](int dd, int i) {
-                const float m = exact_div ? acc[dd][i] / (float)CPG : acc[dd][i] * inv_cpg;
+                const float m = acc[dd][i] * mscale;
                 return (w + i >= d0 + dd) ? sgn * m : sgn * 0.0f;
             };
 #pragma unroll
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
                     for (int dd = 0; dd < DC; ++dd) {
                         f32x4 o;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) o[i] = exact_div ? acc[dd][i] / (float)CPG : acc[dd][i] * inv_cpg;
+                        for (int i = 0; i < 4; ++i) o[i] = acc[dd][i] * mscale;
                         if (nt) st4_nt(vbase + (size_t)(d0 + dd) * HW + w, o); else st4(vbase + (size_t)(d0 + dd) * HW + w, o);
                     }
                 } else {
@@ -414,7 +423,7 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
                             f32x4 o;
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                const float m = exact_div ? acc[dd][i] / (float)CPG : acc[dd][i] * inv_cpg;
+                                const float m = acc[dd][i] * mscale;
                                 o[i] = (w + i >= d) ? m : 0.0f;
                             }
                             if (w + 3 < W) st4(vbase + (size_t)d * HW + w, o);
