@@ -753,10 +753,12 @@ int pipe_dispatch(const float *L, const float *R, float *vol, int B, int C, int 
         // whole-row workgroups (4 waves side by side): opt-in.  As a pure store stream whole rows reach 6.1 TB/s
         // against 5.6 for 1-KiB pieces, but the real kernel got SLOWER with it at cfg-2 (5.97 vs 5.42 ms in one
         // A/B run): four disparity parts re-stage the features four times and the 48-plane workgroups overlap less.
+        // Two waves side by side (2-KiB pieces, STEREO_VOL_WX=2) measured equal to the default.
         int wide = 0;
-        if (const char *e = getenv("STEREO_VOL_WX")) wide = atoi(e) == 4;
-        if (wide) {
-            const int rc = launch_pipe<16, 12, EPI, 4, 4>(L, R, vol, B, C, H, W, D, G, sgn, st);
+        if (const char *e = getenv("STEREO_VOL_WX")) wide = atoi(e);
+        if (wide == 4 || wide == 2) {
+            const int rc = wide == 4 ? launch_pipe<16, 12, EPI, 4, 4>(L, R, vol, B, C, H, W, D, G, sgn, st)
+                                     : launch_pipe<16, 12, EPI, 2, 4>(L, R, vol, B, C, H, W, D, G, sgn, st);
             if (rc != STEREO_ERR_UNSUPPORTED) return rc;
         }
     }

@@ -91,9 +91,9 @@ def test_shift_volumes_vs_oracle(S, oracle, shape):
     close(S.CostVolume(D, "concat")(dev(L), dev(R)), oracle.concat_volume(L, R, D), rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("wx", ["1", "4"])
+@pytest.mark.parametrize("wx", ["1", "2", "4"])
 def test_volume_whole_row_workgroup_shape(S, oracle, wx, monkeypatch):
-    """Store-only group-wise build with 4 waves side by side along W (whole-row stores) vs the 256-pixel shape:
+    """Store-only group-wise build with 2 / 4 waves side by side along W (4 = whole-row stores) vs the 256-pixel shape:
     both against the oracle, incl. ragged last tile columns, W > 1024 (two workgroups per row), D not a multiple of
     the 48 disparities a wide workgroup covers, channels/group in {1, 2, 4}."""
     monkeypatch.setenv("STEREO_VOL_WX", wx)
