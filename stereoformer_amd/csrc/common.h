@@ -51,3 +51,8 @@ __device__ __forceinline__ float sample_tap(const float *__restrict__ v, size_t 
     const float ceil_rate = 1.0f - floor_rate;
     return v[(size_t)ifl * stride] * floor_rate + v[(size_t)ic * stride] * ceil_rate;
 }
+
+// corr_mfma.hip: A1 (+ A4 when disp != nullptr) on the f32 matrix cores.  Library-internal (not part of the C ABI);
+// returns STEREO_ERR_UNSUPPORTED outside its envelope (C <= 32, D <= 192, W % 4 == 0, 16-B aligned).
+int stereo_corr_volume_mfma(const float *L, const float *R, float *vol, float *disp, int B, int C, int H, int W, int D,
+                            float sgn, hipStream_t st);

@@ -1,0 +1,264 @@
+// A1 (+ A4) on the f32 matrix cores: correlation volume vol[b,d,h,w] = mean_c L[b,c,h,w] * R[b,c,h,w-d] (0 for w < d),
+// optionally folded into the soft-argmin in the same pass (vol stored AND regressed, never read back).
+//
+// Why a second formulation next to volume.hip's VALU kernel: that kernel is FMA-issue bound (v_fma_f32 holds a SIMD
+// for 4 cycles) and its stores do not overlap its FMAs (one 12-wave workgroup per CU; vmcnt is one queue for loads and
+// stores, so a wave's next operand loads wait for its own stores): 1.42 ms = 37 % of the HBM roofline at cfg-2.
+// v_mfma_f32_32x32x2_f32 does the same exact-fp32 products at twice the rate, but an MFMA tile is (key x query) while
+// the volume is (disparity x query): d = query - key runs along the tile's diagonals.  The skew goes through LDS:
+//
+//   * a workgroup = 8 waves = 256 consecutive queries of one image row, one LDS tile of keys (32 channels x
+//     (256 + Dk) columns, zero-padded outside the image: the w < d zeros of the volume come for free);
+//   * step s = 0 .. NT-1 handles, per wave, the 32-key tile at distance 32 s: 16 MFMAs (A = K from LDS, lanes = keys;
+//     B = Q from registers with 1/C folded in) give S^T[key][query]; accumulator register r of lane (j, half) is the
+//     volume entry (d = 32 s + j - i_r - 4 half, query j): it is written to the LDS "sheet" row d mod 96, column =
+//     query -- one ds_write_b32 with an IMMEDIATE offset per register (the row of register r is a compile-time
+//     distance from the lane's base row; only every third step, where the 96-row ring wraps, needs a select);
+//   * after the barrier of step s the 32 sheet rows d = 32 (s-1) .. 32 s - 1 are complete (a row takes entries from two
+//     neighbouring key tiles) and leave as 32 x 1 KiB row-contiguous global stores while step s+1 runs: the ring has
+//     three 32-row blocks -- being read, complete, being written;
+//   * ARGMIN: the online softmax of attention.hip's v5 kernel runs on the same accumulators (packed-f32 VALU, one
+//     xor-32 exchange per tile) and the disparity leaves at the end of the tile.
+// Persistent workgroups walk runs of tiles; the next tile's K quads / Q values are prefetched into registers under the
+// current tile's MFMAs.  C <= 32 (one MFMA K-tile), D <= 192 (LDS: 58 KB keys + 100 KB sheet), W % 4 == 0.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int CM_NWV = 8;            // waves per workgroup
+constexpr int CM_TQW = 32 * CM_NWV;  // queries per workgroup tile
+constexpr int CM_RSTR = CM_TQW + 4;  // sheet row stride (floats): 16-B aligned rows, (RSTR + 1) odd -> conflict-free
+                                     // diagonal writes
+constexpr int CM_RING = 96;          // sheet rows: three 32-row blocks
+
+template <int NT, bool ARGMIN>
+__global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const float *__restrict__ L,
+                                                                       const float *__restrict__ R,
+                                                                       float *__restrict__ vol, float *__restrict__ disp,
+                                                                       int C, int H, int W, int D, float inv_c, float sgn,
+                                                                       int tiles_per_wg, int ntiles)
+{
+    constexpr int Dk = 32 * (NT - 1);
+    constexpr int NK = CM_TQW + Dk;
+    constexpr int KS = NK + 4;
+    constexpr int RMAX = 32 / CM_NWV;          // staged rows per wave
+    constexpr int NPASS = (NK / 4 + 63) / 64;  // 16-B quads per lane and row
+    extern __shared__ f32x4 smem4[];
+    f32x4 *Ks4 = smem4;
+    float *Ks = reinterpret_cast<float *>(smem4);
+    float *Sh = Ks + 32 * KS;  // [CM_RING][CM_RSTR]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const unsigned HWu = (unsigned)H * (unsigned)W;  // launcher: 32 * H * W < 2^31
+    const int nx = (W + CM_TQW - 1) / CM_TQW;
+    const int dl = l31 - 4 * half;                   // d of register r at step s = 32 s + dl - i_r
+    const float *kp = Ks + half * KS + 32 * wave + l31;
+    // sheet address of this lane's register r at step s: ((32 (s % 3) + dl - i_r) mod 96) * RSTR + 32 wave + l31
+    //   = lane_base + 32 (s % 3) * RSTR + (27 - i_r) * RSTR    with lane_base = (dl - 27) * RSTR + column  (may be < 0)
+    const int lane_base = (dl - 27) * CM_RSTR + 32 * wave + l31;
+
+    int tile = blockIdx.x * tiles_per_wg;
+    const int tile_end = (tile + tiles_per_wg < ntiles) ? tile + tiles_per_wg : ntiles;
+    if (tile >= tile_end) return;
+
+    f32x4 rk[RMAX][NPASS];
+    float qn[16];
+    unsigned okbits = 0;
+    auto issue = [&](int tl) {  // K quads and Q values of tile tl -> registers
+        const int x = tl % nx, bh = tl / nx;
+        const int hh = bh % H, bb = bh / H;
+        const int w0 = x * CM_TQW, kbase = w0 - Dk;
+        const float *Rb = R + ((size_t)bb * C * HWu + (size_t)hh * W);
+        const float *Lb = L + ((size_t)bb * C * HWu + (size_t)hh * W);
+        okbits = 0;
+#pragma unroll
+        for (int pp = 0; pp < NPASS; ++pp) {
+            const int w = kbase + 4 * (lane + 64 * pp);
+            if (lane + 64 * pp < NK / 4 && w >= 0 && w + 3 < W) okbits |= 1u << pp;
+        }
+#pragma unroll
+        for (int rr = 0; rr < RMAX; ++rr) {
+            const int row = wave + rr * CM_NWV;
+#pragma unroll
+            for (int pp = 0; pp < NPASS; ++pp) {
+                const bool ok = ((okbits >> pp) & 1u) && row < C;
+                rk[rr][pp] = ld4(Rb + (ok ? (unsigned)row * HWu + (unsigned)(kbase + 4 * (lane + 64 * pp)) : 0u));
+            }
+        }
+        const int q = w0 + 32 * wave + l31;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int c = 2 * s + half;
+            qn[s] = Lb[(c < C && q < W) ? (unsigned)c * HWu + (unsigned)q : 0u];
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int rr = 0; rr < RMAX; ++rr) {
+            const int row = wave + rr * CM_NWV;
+#pragma unroll
+            for (int pp = 0; pp < NPASS; ++pp) {
+                if (lane + 64 * pp < NK / 4)
+                    Ks4[(row * KS) / 4 + lane + 64 * pp] =
+                        (((okbits >> pp) & 1u) && row < C) ? rk[rr][pp] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    // 32 complete sheet rows (block blk, disparities dbase ..) -> global, 1 KiB per wave store
+    auto flush_block = [&](int blk, int dbase, size_t row_off, int w0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int qi = tid + k * (CM_NWV * 64);
+            const int row = qi >> 6, c4 = qi & 63;
+            const int d = dbase + row, w = w0 + 4 * c4;
+            if (d < D && w + 3 < W) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(Sh + (32 * blk + row) * CM_RSTR + 4 * c4);
+                st4(vol + row_off + (size_t)d * HWu + (unsigned)w, v);
+            }
+        }
+    };
+
+    issue(tile);
+    commit();
+    float qv[16];
+    const float l2 = sgn * 1.44269504088896340736f;  // mean -> logit in units of log2
+    for (;;) {
+        const int x = tile % nx, bh = tile / nx;
+        const int hh = bh % H, bb = bh / H;
+        const int w0 = x * CM_TQW;
+        const int q = w0 + 32 * wave + l31;
+        const size_t row_off = (size_t)bb * D * HWu + (size_t)hh * W;  // vol[bb, 0, hh, 0]
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int c = 2 * s + half;
+            qv[s] = (c < C && q < W) ? qn[s] * inv_c : 0.0f;
+        }
+        __syncthreads();  // the key tile is visible; the previous tile's last sheet reads are done
+        const bool more = tile + 1 < tile_end;
+        if (more) issue(tile + 1);
+
+        const bool wave_on = w0 + 32 * wave < W;  // wave-uniform
+        float m = -INFINITY, ssum = 0.0f, esc = 0.0f;
+#pragma unroll 1
+        for (int s = 0; s < NT; ++s) {
+            const int sb = s % 3;  // ring block of the rows 32 s .. 32 s + 31
+            if (wave_on) {
+                f32x16 a;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+                const float *kpt = kp + 32 * (NT - 1 - s);
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    a = __builtin_amdgcn_mfma_f32_32x32x2f32(kpt[2 * t * KS], qv[t], a, 0, 0, 0);
+                // ---- volume entries -> sheet (rows outside [0, D) land in ring slots nobody reads)
+                float *wp = Sh + lane_base + 32 * sb * CM_RSTR;
+                if (sb != 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) wp[(27 - ((r & 3) + 8 * (r >> 2))) * CM_RSTR] = a[r];
+                } else {  // the ring wraps: rows with dl < i_r are 96 rows up
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ir = (r & 3) + 8 * (r >> 2);
+                        float *p = wp + (27 - ir) * CM_RSTR;
+                        if (dl < ir) p += CM_RING * CM_RSTR;
+                        *p = a[r];
+                    }
+                }
+                if (ARGMIN) {
+                    const int cb = 32 * s + dl;  // d of register r = cb - i_r
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[r] *= l2;
+                    if (s == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (cb < (r & 3) + 8 * (r >> 2)) a[r] = -INFINITY;  // d < 0
+                    }
+                    if (32 * s + 31 >= D) {
+                        const int lim = cb - D;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (lim >= (r & 3) + 8 * (r >> 2)) a[r] = -INFINITY;  // d >= D
+                    }
+                    float mt = -INFINITY;
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) mt = fmaxf(mt, fmaxf(a[r], a[r + 1]));
+                    mt = fmaxf(mt, __shfl_xor(mt, 32));
+                    const float mn = fmaxf(m, mt);
+                    const float alpha = __builtin_amdgcn_exp2f(m - mn);
+                    m = mn;
+                    const f32x2 nm = {-mn, -mn};
+                    f32x2 T2 = {0.0f, 0.0f}, U2 = {0.0f, 0.0f};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const f32x2 sh = (f32x2){a[2 * k], a[2 * k + 1]} + nm;
+                        const f32x2 pe = {__builtin_amdgcn_exp2f(sh[0]), __builtin_amdgcn_exp2f(sh[1])};
+                        T2 += pe;
+                        const float base = (float)(2 * (k & 1) + 8 * (k >> 1));
+                        U2 = __builtin_elementwise_fma(pe, (f32x2){base, base}, U2);
+                    }
+                    const float ts = T2[0] + T2[1], ti = U2[0] + U2[1] + T2[1];
+                    ssum = fmaf(ssum, alpha, ts);
+                    esc = fmaf(esc, alpha, fmaf((float)cb, ts, -ti));
+                }
+            }
+            __syncthreads();  // step s is on the sheet: block (s-1) % 3 is complete
+            if (s >= 1) flush_block((s + 2) % 3, 32 * (s - 1), row_off, w0);
+        }
+        // the last complete block: rows 32 (NT-2) .. Dk - 1 needed no further step?  No: they take entries from tile
+        // NT-1 as well, which the loop has just written -> complete after its barrier.  (Rows >= Dk never exist.)
+        if (ARGMIN && wave_on) {
+            float e = esc;
+            ssum += __shfl_xor(ssum, 32);
+            e += __shfl_xor(e, 32);
+            if (half == 0 && q < W) disp[(size_t)bh * W + q] = e / ssum;
+        }
+        if (!more) break;
+        __syncthreads();  // every wave is done with the key tile
+        commit();
+        ++tile;
+    }
+}
+
+template <int NT, bool ARGMIN>
+int launch_cm(const float *L, const float *R, float *vol, float *disp, int B, int C, int H, int W, int D, float sgn,
+              hipStream_t st)
+{
+    constexpr int Dk = 32 * (NT - 1);
+    const size_t lds = ((size_t)32 * (CM_TQW + Dk + 4) + (size_t)CM_RING * CM_RSTR) * sizeof(float);
+    auto kern = corr_volume_mfma_kernel<NT, ARGMIN>;
+    if (lds > 160 * 1024) return STEREO_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return STEREO_ERR_UNSUPPORTED;
+    const long long ntl = (long long)((W + CM_TQW - 1) / CM_TQW) * H * B;
+    if (ntl >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
+    int tpw = (int)((ntl + 255) / 256);  // one resident workgroup per CU (LDS), each walking a run of tiles
+    if (const char *e = getenv("STEREO_CM_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;
+    const int nwg = (int)((ntl + tpw - 1) / tpw);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(CM_NWV * 64), lds, st, L, R, vol, disp, C, H, W, D, 1.0f / (float)C, sgn, tpw,
+                       (int)ntl);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+}  // namespace
+
+// Returns STEREO_ERR_UNSUPPORTED when the shape is outside the kernel's envelope (the caller then takes the VALU path).
+// disp == nullptr: store-only (A1).
+int stereo_corr_volume_mfma(const float *L, const float *R, float *vol, float *disp, int B, int C, int H, int W, int D,
+                            float sgn, hipStream_t st)
+{
+    if (C > 32 || D > 192 || D < 1 || W % 4 != 0 || !aligned16(L) || !aligned16(R) || !aligned16(vol)) return STEREO_ERR_UNSUPPORTED;
+    if ((long long)32 * H * W >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
+    const int nt = (D + 31) / 32 + 1;
+#define CM_CASE(NTV)                                                                                    \
+    return disp ? launch_cm<NTV, true>(L, R, vol, disp, B, C, H, W, D, sgn, st)                          \
+                : launch_cm<NTV, false>(L, R, vol, disp, B, C, H, W, D, sgn, st)
+    if (nt <= 3) { CM_CASE(3); }
+    if (nt <= 5) { CM_CASE(5); }
+    CM_CASE(7);
+#undef CM_CASE
+}

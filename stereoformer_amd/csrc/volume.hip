@@ -956,9 +956,19 @@ int shift_dispatch(const float *L, const float *R, float *vol, int B, int C, int
 
 }  // namespace
 
+static bool corr_mfma_enabled()
+{
+    const char *e = getenv("STEREO_CORR_MFMA");  // dev/test knob: "0" forces the VALU kernels
+    return !(e && e[0] == '0');
+}
+
 extern "C" int stereo_corr_volume_f32(const float *left, const float *right, float *vol, int B, int C, int H, int W,
                                       int D, void *stream)
 {
+    if (B > 0 && C > 0 && H > 0 && W > 0 && D > 0 && left && right && vol && corr_mfma_enabled()) {
+        const int rc = stereo_corr_volume_mfma(left, right, vol, nullptr, B, C, H, W, D, 1.0f, as_stream(stream));
+        if (rc != STEREO_ERR_UNSUPPORTED) return rc;
+    }
     return gwc_dispatch<EPI_STORE>(left, right, vol, B, C, H, W, D, 1, 1.0f, stream);
 }
 
@@ -995,6 +1005,10 @@ extern "C" int stereo_corr_volume_soft_argmin_f32(const float *left, const float
     STEREO_REQUIRE_PTR(disp);
     const float sgn = match_similarity ? 1.0f : -1.0f;
     hipStream_t st = as_stream(stream);
+    if (corr_mfma_enabled()) {
+        const int rc = stereo_corr_volume_mfma(left, right, vol, disp, B, C, H, W, D, sgn, st);
+        if (rc != STEREO_ERR_UNSUPPORTED) return rc;
+    }
     if ((W % 4 == 0) && aligned16(left) && aligned16(right) && aligned16(vol) && fits_grid_yz(H)) {
         int rc = STEREO_ERR_UNSUPPORTED;
         if (D <= 64) rc = launch_pipe<8, 8, EPI_BOTH>(left, right, vol, B, C, H, W, D, 1, sgn, st, disp);

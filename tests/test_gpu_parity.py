@@ -104,11 +104,36 @@ def test_volume_whole_row_workgroup_shape(S, oracle, wx, monkeypatch):
         close(S.build_gwc_volume(dev(L), dev(R), D, G), oracle.gwc_volume(L, R, D, G), **VOL_TOL)
 
 
+@pytest.mark.parametrize("mfma", ["1", "0"])
+@pytest.mark.parametrize("shape", [(1, 32, 5, 960, 192), (2, 12, 6, 520, 150), (1, 6, 9, 260, 97), (2, 32, 3, 300, 64),
+                                   (1, 5, 2, 36, 7), (1, 8, 2, 16, 16), (1, 32, 2, 1300, 33), (1, 3, 4, 8, 1)])
+def test_corr_volume_mfma_vs_valu_vs_oracle(S, oracle, shape, mfma, monkeypatch):
+    """A1 and A1+A4 (volume stored and regressed in one pass) on the f32 matrix cores (C <= 32, D <= 192, W % 4 == 0;
+    LDS skew sheet, persistent workgroups) and on the VALU kernels: both against the oracle -- every band-size class,
+    partial last tiles, D == W, both softmax signs, several tiles per persistent workgroup."""
+    monkeypatch.setenv("STEREO_CORR_MFMA", mfma)
+    B, C, H, W, D = shape
+    rng = np.random.default_rng(43)
+    L = rng.standard_normal((B, C, H, W), dtype=np.float32) * 2
+    R = rng.standard_normal((B, C, H, W), dtype=np.float32) * 2
+    ref = oracle.corr_volume(L, R, D)
+    close(S.CostVolume(D)(dev(L), dev(R)), ref, **VOL_TOL)
+    for sim in (True, False):
+        v, d = S.corr_volume_with_disparity(dev(L), dev(R), D, match_similarity=sim)
+        close(v, ref, **VOL_TOL)
+        close(d, oracle.soft_argmin(ref, sim), **DISP_TOL)
+    monkeypatch.setenv("STEREO_CM_TPW", "3")
+    v, d = S.corr_volume_with_disparity(dev(L), dev(R), D)
+    close(v, ref, **VOL_TOL)
+    close(d, oracle.soft_argmin(ref), **DISP_TOL)
+
+
 @pytest.mark.parametrize("cfg", ["24,8", "16,8", "12,8", "-8,12", "-12,8", "16,12"])
 def test_volume_kernel_variants(S, oracle, cfg, monkeypatch):
     """Every instantiated (disparities-per-wave, waves) variant of the pipelined volume kernel -- including the
     channel-pair packed one (negative dc) -- against the oracle, store and fused arg-min epilogues."""
     monkeypatch.setenv("STEREO_VOL_CFG", cfg)
+    monkeypatch.setenv("STEREO_CORR_MFMA", "0")   # these are the VALU kernels (the MFMA formulation has its own test)
     rng = np.random.default_rng(3)
     for (B, C, H, W, D, G) in ((1, 32, 5, 960, 192, 8), (2, 12, 6, 520, 150, 4), (1, 6, 9, 260, 97, 2)):
         L = rng.standard_normal((B, C, H, W), dtype=np.float32)
