@@ -217,8 +217,8 @@ def main():
         traffic = None  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
-            # the store variant of the volume builder (template tail ", 0>" = EPI_STORE) at G=8
-            cands = [v for k, v in pmc["kernels"].items() if k.startswith("gwc_volume") and k.endswith(", 0>")
+            # the store variant of the volume builder (third template argument 0 = EPI_STORE) at G=8
+            cands = [v for k, v in pmc["kernels"].items() if k.startswith("gwc_volume_pipe_kernel<16, 12, 0")
                      and v.get("hbm_write_bytes", 0) > 2e10]
             traffic = cands[0]["hbm_bytes_per_launch"] if cands else None
         except Exception:

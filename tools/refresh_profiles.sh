@@ -17,8 +17,8 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o run --output-for
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o run --output-format csv -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/pmc_write.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/pmc_mfma -o run --output-format csv -- python3 tools/kernel_bench.py --only A7_ > $O/pmc_mfma_a7.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/pmc_mfma8 -o run --output-format csv -- python3 tools/kernel_bench.py --only A8_ > $O/pmc_mfma_a8.log 2>&1
-python3 tools/pmc_summary.py $O/pmc_fetch gwc_volume group_mean lookup > $O/fetch.json
-python3 tools/pmc_summary.py $O/pmc_write gwc_volume group_mean lookup > $O/write.json
+python3 tools/pmc_summary.py $O/pmc_fetch gwc_volume corr_volume_mfma group_mean lookup > $O/fetch.json
+python3 tools/pmc_summary.py $O/pmc_write gwc_volume corr_volume_mfma group_mean lookup > $O/write.json
 python3 - $O $R <<'PY'
 import json, sys
 o, r = sys.argv[1], sys.argv[2]
