@@ -27,19 +27,22 @@
 
 namespace {
 
-constexpr int CM_NWV = 8;            // waves per workgroup
-constexpr int CM_TQW = 32 * CM_NWV;  // queries per workgroup tile
-constexpr int CM_RSTR = CM_TQW + 4;  // sheet row stride (floats): 16-B aligned rows, (RSTR + 1) odd -> conflict-free
-                                     // diagonal writes
-constexpr int CM_RING = 96;          // sheet rows: three 32-row blocks
-
-template <int NT, bool ARGMIN>
+// Workgroup shapes: (CM_NWV waves = 32 * CM_NWV queries, RINGB 32-row sheet blocks).
+//   (8, 3): 256-query tiles, 1-KiB row stores, three blocks (being read / complete / being written), one barrier per
+//           step; 158 KB of LDS at D = 192 -> one workgroup per CU.
+//   (4, 2): 128-query tiles, two blocks and a second barrier per step (the flushed block is rewritten by the next step);
+//           75 KB -> two workgroups per CU, whose phases interleave.
+template <int NT, bool ARGMIN, int CM_NWV, int RINGB>
 __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const float *__restrict__ L,
                                                                        const float *__restrict__ R,
                                                                        float *__restrict__ vol, float *__restrict__ disp,
                                                                        int C, int H, int W, int D, float inv_c, float sgn,
                                                                        int tiles_per_wg, int ntiles)
 {
+    constexpr int CM_TQW = 32 * CM_NWV;  // queries per workgroup tile
+    constexpr int CM_RSTR = CM_TQW + 4;  // sheet row stride (floats): 16-B aligned rows, (RSTR + 1) odd -> conflict-free
+                                         // diagonal writes
+    constexpr int CM_RING = 32 * RINGB;  // sheet rows
     constexpr int Dk = 32 * (NT - 1);
     constexpr int NK = CM_TQW + Dk;
     constexpr int KS = NK + 4;
@@ -56,8 +59,8 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
     const int nx = (W + CM_TQW - 1) / CM_TQW;
     const int dl = l31 - 4 * half;                   // d of register r at step s = 32 s + dl - i_r
     const float *kp = Ks + half * KS + 32 * wave + l31;
-    // sheet address of this lane's register r at step s: ((32 (s % 3) + dl - i_r) mod 96) * RSTR + 32 wave + l31
-    //   = lane_base + 32 (s % 3) * RSTR + (27 - i_r) * RSTR    with lane_base = (dl - 27) * RSTR + column  (may be < 0)
+    // sheet address of this lane's register r at step s: ((32 (s % RINGB) + dl - i_r) mod RING) * RSTR + 32 wave + l31
+    //   = lane_base + 32 (s % RINGB) * RSTR + (27 - i_r) * RSTR    with lane_base = (dl - 27) * RSTR + column  (may be < 0)
     const int lane_base = (dl - 27) * CM_RSTR + 32 * wave + l31;
 
     int tile = blockIdx.x * tiles_per_wg;
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int qi = tid + k * (CM_NWV * 64);
-            const int row = qi >> 6, c4 = qi & 63;
+            const int row = qi / (CM_TQW / 4), c4 = qi % (CM_TQW / 4);
             const int d = dbase + row, w = w0 + 4 * c4;
             if (d < D && w + 3 < W) {
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(Sh + (32 * blk + row) * CM_RSTR + 4 * c4);
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
         float m = -INFINITY, ssum = 0.0f, esc = 0.0f;
 #pragma unroll 1
         for (int s = 0; s < NT; ++s) {
-            const int sb = s % 3;  // ring block of the rows 32 s .. 32 s + 31
+            const int sb = s % RINGB;  // ring block of the rows 32 s .. 32 s + 31
             if (wave_on) {
                 f32x16 a;
 #pragma unroll
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
                 if (sb != 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) wp[(27 - ((r & 3) + 8 * (r >> 2))) * CM_RSTR] = a[r];
-                } else {  // the ring wraps: rows with dl < i_r are 96 rows up
+                } else {  // the ring wraps: rows with dl < i_r are RING rows up
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int ir = (r & 3) + 8 * (r >> 2);
@@ -204,8 +207,9 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
                     esc = fmaf(esc, alpha, fmaf((float)cb, ts, -ti));
                 }
             }
-            __syncthreads();  // step s is on the sheet: block (s-1) % 3 is complete
-            if (s >= 1) flush_block((s + 2) % 3, 32 * (s - 1), row_off, w0);
+            __syncthreads();  // step s is on the sheet: block (s-1) % RINGB is complete
+            if (s >= 1) flush_block((s + RINGB - 1) % RINGB, 32 * (s - 1), row_off, w0);
+            if (RINGB == 2) __syncthreads();  // two blocks: the flushed one is rewritten by the next step
         }
         // the last complete block: rows 32 (NT-2) .. Dk - 1 needed no further step?  No: they take entries from tile
         // NT-1 as well, which the loop has just written -> complete after its barrier.  (Rows >= Dk never exist.)
@@ -222,23 +226,24 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
     }
 }
 
-template <int NT, bool ARGMIN>
+template <int NT, bool ARGMIN, int NWV, int RINGB>
 int launch_cm(const float *L, const float *R, float *vol, float *disp, int B, int C, int H, int W, int D, float sgn,
               hipStream_t st)
 {
-    constexpr int Dk = 32 * (NT - 1);
-    const size_t lds = ((size_t)32 * (CM_TQW + Dk + 4) + (size_t)CM_RING * CM_RSTR) * sizeof(float);
-    auto kern = corr_volume_mfma_kernel<NT, ARGMIN>;
+    constexpr int Dk = 32 * (NT - 1), TQW = 32 * NWV;
+    const size_t lds = ((size_t)32 * (TQW + Dk + 4) + (size_t)32 * RINGB * (TQW + 4)) * sizeof(float);
+    auto kern = corr_volume_mfma_kernel<NT, ARGMIN, NWV, RINGB>;
     if (lds > 160 * 1024) return STEREO_ERR_UNSUPPORTED;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return STEREO_ERR_UNSUPPORTED;
-    const long long ntl = (long long)((W + CM_TQW - 1) / CM_TQW) * H * B;
+    const long long ntl = (long long)((W + TQW - 1) / TQW) * H * B;
     if (ntl >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
-    int tpw = (int)((ntl + 255) / 256);  // one resident workgroup per CU (LDS), each walking a run of tiles
+    const int resident = 256 * (int)((160 * 1024) / lds);  // persistent workgroups: as many as the LDS admits per CU
+    int tpw = (int)((ntl + resident - 1) / resident);
     if (const char *e = getenv("STEREO_CM_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;
     const int nwg = (int)((ntl + tpw - 1) / tpw);
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(CM_NWV * 64), lds, st, L, R, vol, disp, C, H, W, D, 1.0f / (float)C, sgn, tpw,
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(NWV * 64), lds, st, L, R, vol, disp, C, H, W, D, 1.0f / (float)C, sgn, tpw,
                        (int)ntl);
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
@@ -254,11 +259,18 @@ int stereo_corr_volume_mfma(const float *L, const float *R, float *vol, float *d
     if (C > 32 || D > 192 || D < 1 || W % 4 != 0 || !aligned16(L) || !aligned16(R) || !aligned16(vol)) return STEREO_ERR_UNSUPPORTED;
     if ((long long)32 * H * W >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
     const int nt = (D + 31) / 32 + 1;
-#define CM_CASE(NTV)                                                                                    \
-    return disp ? launch_cm<NTV, true>(L, R, vol, disp, B, C, H, W, D, sgn, st)                          \
-                : launch_cm<NTV, false>(L, R, vol, disp, B, C, H, W, D, sgn, st)
-    if (nt <= 3) { CM_CASE(3); }
-    if (nt <= 5) { CM_CASE(5); }
+    int small = 0;  // dev knob: STEREO_CM_SHAPE=4 -> 128-query tiles, two workgroups per CU
+    if (const char *e = getenv("STEREO_CM_SHAPE")) small = atoi(e) == 4;
+#define CM_CASE(NTV)                                                                                              \
+    do {                                                                                                          \
+        if (small)                                                                                                \
+            return disp ? launch_cm<NTV, true, 4, 2>(L, R, vol, disp, B, C, H, W, D, sgn, st)                      \
+                        : launch_cm<NTV, false, 4, 2>(L, R, vol, disp, B, C, H, W, D, sgn, st);                    \
+        return disp ? launch_cm<NTV, true, 8, 3>(L, R, vol, disp, B, C, H, W, D, sgn, st)                          \
+                    : launch_cm<NTV, false, 8, 3>(L, R, vol, disp, B, C, H, W, D, sgn, st);                        \
+    } while (0)
+    if (nt <= 3) CM_CASE(3);
+    if (nt <= 5) CM_CASE(5);
     CM_CASE(7);
 #undef CM_CASE
 }

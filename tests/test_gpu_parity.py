@@ -104,14 +104,15 @@ def test_volume_whole_row_workgroup_shape(S, oracle, wx, monkeypatch):
         close(S.build_gwc_volume(dev(L), dev(R), D, G), oracle.gwc_volume(L, R, D, G), **VOL_TOL)
 
 
-@pytest.mark.parametrize("mfma", ["1", "0"])
+@pytest.mark.parametrize("mfma", ["1", "4", "0"])
 @pytest.mark.parametrize("shape", [(1, 32, 5, 960, 192), (2, 12, 6, 520, 150), (1, 6, 9, 260, 97), (2, 32, 3, 300, 64),
                                    (1, 5, 2, 36, 7), (1, 8, 2, 16, 16), (1, 32, 2, 1300, 33), (1, 3, 4, 8, 1)])
 def test_corr_volume_mfma_vs_valu_vs_oracle(S, oracle, shape, mfma, monkeypatch):
     """A1 and A1+A4 (volume stored and regressed in one pass) on the f32 matrix cores (C <= 32, D <= 192, W % 4 == 0;
     LDS skew sheet, persistent workgroups) and on the VALU kernels: both against the oracle -- every band-size class,
     partial last tiles, D == W, both softmax signs, several tiles per persistent workgroup."""
-    monkeypatch.setenv("STEREO_CORR_MFMA", mfma)
+    monkeypatch.setenv("STEREO_CORR_MFMA", "0" if mfma == "0" else "1")
+    monkeypatch.setenv("STEREO_CM_SHAPE", "4" if mfma == "4" else "8")   # 128-query / two-block ring variant
     B, C, H, W, D = shape
     rng = np.random.default_rng(43)
     L = rng.standard_normal((B, C, H, W), dtype=np.float32) * 2
