@@ -32,12 +32,18 @@ namespace {
 //           step; 158 KB of LDS at D = 192 -> one workgroup per CU.
 //   (4, 2): 128-query tiles, two blocks and a second barrier per step (the flushed block is rewritten by the next step);
 //           75 KB -> two workgroups per CU, whose phases interleave.
-template <int NT, bool ARGMIN, int CM_NWV, int RINGB>
+// CPG2 > 0 adds the GROUP PASS in front (A3 + group mean + A4 in ONE kernel, cfg-2's whole volume stage): for each of
+// the G groups of 2 * CPG2 channels the same step loop runs with CPG2 MFMAs per key tile (the group's channel pairs) and
+// flushes into volg[b, g]; then the all-channel pass produces the mean volume and the disparity as before.  The key
+// tile and the Q registers are fetched once for both; the 25.5 GB group-wise volume leaves through the same
+// row-contiguous flush path (which sustains > 6 TB/s on its own) and is never read back.
+template <int NT, bool ARGMIN, int CM_NWV, int RINGB, int CPG2 = 0>
 __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const float *__restrict__ L,
                                                                        const float *__restrict__ R,
                                                                        float *__restrict__ vol, float *__restrict__ disp,
                                                                        int C, int H, int W, int D, float inv_c, float sgn,
-                                                                       int tiles_per_wg, int ntiles)
+                                                                       int tiles_per_wg, int ntiles,
+                                                                       float *__restrict__ volg, int G, float inv_cpg)
 {
     constexpr int CM_TQW = 32 * CM_NWV;  // queries per workgroup tile
     constexpr int CM_RSTR = CM_TQW + 4;  // sheet row stride (floats): 16-B aligned rows, (RSTR + 1) odd -> conflict-free
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
         }
     };
     // 32 complete sheet rows (block blk, disparities dbase ..) -> global, 1 KiB per wave store
-    auto flush_block = [&](int blk, int dbase, size_t row_off, int w0) {
+    auto flush_block = [&](float *__restrict__ dst, int blk, int dbase, size_t row_off, int w0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int qi = tid + k * (CM_NWV * 64);
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
             const int d = dbase + row, w = w0 + 4 * c4;
             if (d < D && w + 3 < W) {
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(Sh + (32 * blk + row) * CM_RSTR + 4 * c4);
-                st4(vol + row_off + (size_t)d * HWu + (unsigned)w, v);
+                st4(dst + row_off + (size_t)d * HWu + (unsigned)w, v);
             }
         }
     };
@@ -144,6 +150,51 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
         if (more) issue(tile + 1);
 
         const bool wave_on = w0 + 32 * wave < W;  // wave-uniform
+        // accumulator tile of key tile s -> sheet rows (32 s + dl - i_r) mod RING (rows outside [0, D) land in ring
+        // slots nobody reads)
+        auto sheet_write = [&](const f32x16 &a, int sb) {
+            float *wp = Sh + lane_base + 32 * sb * CM_RSTR;
+            if (sb != 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) wp[(27 - ((r & 3) + 8 * (r >> 2))) * CM_RSTR] = a[r];
+            } else {  // the ring wraps: rows with dl < i_r are RING rows up
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ir = (r & 3) + 8 * (r >> 2);
+                    float *p = wp + (27 - ir) * CM_RSTR;
+                    if (dl < ir) p += CM_RING * CM_RSTR;
+                    *p = a[r];
+                }
+            }
+        };
+        if (CPG2 > 0) {  // ---------------- group pass: volg[bb, g, :, hh, w0 ..]
+            float qg[16];  // Q scaled for a group mean (1 / channels per group)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) qg[t] = qv[t] * (inv_cpg / inv_c);
+#pragma unroll
+            for (int g = 0; g < 16 / (CPG2 > 0 ? CPG2 : 1); ++g) {
+                if (g < G) {  // workgroup-uniform
+                    const size_t goff = ((size_t)bb * G + g) * D * HWu + (size_t)hh * W;
+#pragma unroll 1
+                    for (int s = 0; s < NT; ++s) {
+                        if (wave_on) {
+                            f32x16 a;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+                            const float *kpt = kp + 32 * (NT - 1 - s) + 2 * g * CPG2 * KS;
+#pragma unroll
+                            for (int t = 0; t < CPG2; ++t)
+                                a = __builtin_amdgcn_mfma_f32_32x32x2f32(kpt[2 * t * KS], qg[g * CPG2 + t], a, 0, 0, 0);
+                            sheet_write(a, s % RINGB);
+                        }
+                        __syncthreads();
+                        if (s >= 1) flush_block(volg, (s + RINGB - 1) % RINGB, 32 * (s - 1), goff, w0);
+                        if (RINGB == 2) __syncthreads();
+                    }
+                    if (RINGB != 2) __syncthreads();  // the last flush's sheet reads vs the next pass's first writes
+                }
+            }
+        }
         float m = -INFINITY, ssum = 0.0f, esc = 0.0f;
 #pragma unroll 1
         for (int s = 0; s < NT; ++s) {
@@ -156,20 +207,7 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
 #pragma unroll
                 for (int t = 0; t < 16; ++t)
                     a = __builtin_amdgcn_mfma_f32_32x32x2f32(kpt[2 * t * KS], qv[t], a, 0, 0, 0);
-                // ---- volume entries -> sheet (rows outside [0, D) land in ring slots nobody reads)
-                float *wp = Sh + lane_base + 32 * sb * CM_RSTR;
-                if (sb != 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) wp[(27 - ((r & 3) + 8 * (r >> 2))) * CM_RSTR] = a[r];
-                } else {  // the ring wraps: rows with dl < i_r are RING rows up
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ir = (r & 3) + 8 * (r >> 2);
-                        float *p = wp + (27 - ir) * CM_RSTR;
-                        if (dl < ir) p += CM_RING * CM_RSTR;
-                        *p = a[r];
-                    }
-                }
+                sheet_write(a, sb);
                 if (ARGMIN) {
                     const int cb = 32 * s + dl;  // d of register r = cb - i_r
 #pragma unroll
@@ -208,7 +246,7 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
                 }
             }
             __syncthreads();  // step s is on the sheet: block (s-1) % RINGB is complete
-            if (s >= 1) flush_block((s + RINGB - 1) % RINGB, 32 * (s - 1), row_off, w0);
+            if (s >= 1) flush_block(vol, (s + RINGB - 1) % RINGB, 32 * (s - 1), row_off, w0);
             if (RINGB == 2) __syncthreads();  // two blocks: the flushed one is rewritten by the next step
         }
         // the last complete block: rows 32 (NT-2) .. Dk - 1 needed no further step?  No: they take entries from tile
@@ -226,13 +264,13 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
     }
 }
 
-template <int NT, bool ARGMIN, int NWV, int RINGB>
+template <int NT, bool ARGMIN, int NWV, int RINGB, int CPG2 = 0>
 int launch_cm(const float *L, const float *R, float *vol, float *disp, int B, int C, int H, int W, int D, float sgn,
-              hipStream_t st)
+              hipStream_t st, float *volg = nullptr, int G = 0)
 {
     constexpr int Dk = 32 * (NT - 1), TQW = 32 * NWV;
     const size_t lds = ((size_t)32 * (TQW + Dk + 4) + (size_t)32 * RINGB * (TQW + 4)) * sizeof(float);
-    auto kern = corr_volume_mfma_kernel<NT, ARGMIN, NWV, RINGB>;
+    auto kern = corr_volume_mfma_kernel<NT, ARGMIN, NWV, RINGB, CPG2>;
     if (lds > 160 * 1024) return STEREO_ERR_UNSUPPORTED;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -244,7 +282,7 @@ int launch_cm(const float *L, const float *R, float *vol, float *disp, int B, in
     if (const char *e = getenv("STEREO_CM_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;
     const int nwg = (int)((ntl + tpw - 1) / tpw);
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(NWV * 64), lds, st, L, R, vol, disp, C, H, W, D, 1.0f / (float)C, sgn, tpw,
-                       (int)ntl);
+                       (int)ntl, volg, G, CPG2 > 0 ? 1.0f / (float)(2 * CPG2) : 1.0f);
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }
@@ -273,4 +311,30 @@ int stereo_corr_volume_mfma(const float *L, const float *R, float *vol, float *d
     if (nt <= 5) CM_CASE(5);
     CM_CASE(7);
 #undef CM_CASE
+}
+
+// A3 + group mean + A4 fused (see the kernel's group pass).  volg [B,G,D,H,W], mean [B,D,H,W], disp [B,H,W].
+int stereo_gwc_mean_argmin_mfma(const float *L, const float *R, float *volg, float *mean, float *disp, int B, int C, int H,
+                                int W, int D, int G, float sgn, hipStream_t st)
+{
+    if (C > 32 || D > 192 || D < 1 || W % 4 != 0 || G < 1 || C % G != 0 || !aligned16(L) || !aligned16(R) ||
+        !aligned16(volg) || !aligned16(mean) || disp == nullptr)
+        return STEREO_ERR_UNSUPPORTED;
+    if ((long long)32 * H * W >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
+    const int cpg = C / G;
+    if (cpg % 2 != 0 || (cpg != 2 && cpg != 4 && cpg != 8 && cpg != 16)) return STEREO_ERR_UNSUPPORTED;
+    const int nt = (D + 31) / 32 + 1;
+#define CMG(NTV, P2) return launch_cm<NTV, true, 8, 3, P2>(L, R, mean, disp, B, C, H, W, D, sgn, st, volg, G)
+#define CMG_NT(NTV)            \
+    do {                       \
+        if (cpg == 2) CMG(NTV, 1); \
+        if (cpg == 4) CMG(NTV, 2); \
+        if (cpg == 8) CMG(NTV, 4); \
+        CMG(NTV, 8);           \
+    } while (0)
+    if (nt <= 3) CMG_NT(3);
+    if (nt <= 5) CMG_NT(5);
+    CMG_NT(7);
+#undef CMG_NT
+#undef CMG
 }

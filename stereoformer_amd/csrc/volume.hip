@@ -1028,6 +1028,12 @@ extern "C" int stereo_gwc_volume_soft_argmin_f32(const float *left, const float 
                                                  int match_similarity, void *stream)
 {
     if (D == 0 && B > 0 && H > 0 && W > 0) return STEREO_ERR_BAD_SHAPE;
+    if (B > 0 && C > 0 && H > 0 && W > 0 && G > 0 && left && right && vol && mean && disp && corr_mfma_enabled() &&
+        !getenv("STEREO_GWC_UNFUSED")) {  // one kernel for the whole volume stage where its envelope allows
+        const int rcf = stereo_gwc_mean_argmin_mfma(left, right, vol, mean, disp, B, C, H, W, D, G,
+                                                    match_similarity ? 1.0f : -1.0f, as_stream(stream));
+        if (rcf != STEREO_ERR_UNSUPPORTED) return rcf;
+    }
     const int rc = gwc_dispatch<EPI_STORE>(left, right, vol, B, C, H, W, D, G, 1.0f, stream);
     if (rc != STEREO_OK) return rc;
     if (B == 0 || C == 0 || H == 0 || W == 0) return STEREO_OK;
