@@ -147,19 +147,24 @@ def main():
 
     def step(i=None):
         with torch.no_grad():
-            if i is not None:
-                ev[i][0].record()
-            volg = S.build_gwc_volume(L, R, D, G)
-            if i is not None:
-                ev[i][1].record()
-                ev_read[i][0].record()
-            if args.reread:
+            if args.reread:   # the pre-fusion chain: volume kernel, then a reader over the 25.5 GB volume
+                if i is not None:
+                    ev[i][0].record()
+                volg = S.build_gwc_volume(L, R, D, G)
+                if i is not None:
+                    ev[i][1].record()
+                    ev_read[i][0].record()
                 disp, mean = S.group_mean_soft_argmin(volg, return_mean=True)
-            else:   # volg.mean(1) == correlation volume (identity I1): mean + disparity from the feature tiles,
-                    # the group-wise volume is written once and never read back
-                mean, disp = S.corr_volume_with_disparity(L, R, D)
-            if i is not None:
-                ev_read[i][1].record()
+                if i is not None:
+                    ev_read[i][1].record()
+            else:
+                # ONE kernel for the volume stage: group-wise volume (written once, never read back) + its group mean
+                # (== the all-channel correlation volume, identity I1) + the soft-argmin disparity
+                if i is not None:
+                    ev[i][0].record()
+                volg, disp, mean = S.build_gwc_volume_with_disparity(L, R, D, G, return_mean=True)
+                if i is not None:
+                    ev[i][1].record()
             return lookup(mean, disp.unsqueeze(1), True)
 
     def sync_all():
@@ -178,7 +183,7 @@ def main():
     elapsed = shard.max_over_ranks(elapsed, device=device)
 
     build_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-    read_ms = sum(a.elapsed_time(b) for a, b in ev_read) / args.steps
+    read_ms = sum(a.elapsed_time(b) for a, b in ev_read) / args.steps if args.reread else None
 
     # one RCCL gather of the disparity shards (the only data collective; outside the timed region)
     gathered = shard.gather_pairs(out, world * B_PER_GPU)
@@ -197,29 +202,32 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         fused_ms = e0.elapsed_time(e1) / 5
-        other_ms = None
+        other = {}
         with torch.no_grad():
-            volg = S.build_gwc_volume(L, R, D, G)
-            alt = (lambda: S.corr_volume_with_disparity(L, R, D)) if args.reread else \
-                  (lambda: S.group_mean_soft_argmin(volg, return_mean=True))
-            alt()
-            e0.record()
-            for _ in range(5):
-                alt()
-            e1.record()
-            torch.cuda.synchronize()
-            other_ms = e0.elapsed_time(e1) / 5
-            del volg
-
+            def t5(fn):
+                fn()
+                e0.record()
+                for _ in range(5):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return round(e0.elapsed_time(e1) / 5, 4)
+            other["gwc_volume_alone"] = t5(lambda: S.build_gwc_volume(L, R, D, G))
+            other["mean_volume_soft_argmin_from_features"] = t5(lambda: S.corr_volume_with_disparity(L, R, D))
+            if not args.reread:
+                volg = S.build_gwc_volume(L, R, D, G)
+                other["group_mean_soft_argmin_reread"] = t5(lambda: S.group_mean_soft_argmin(volg, return_mean=True))
+                del volg
     if rank == 0:
         n_pix = B_PER_GPU * H * W
-        gwc_bytes = 2 * n_pix * C * 4 + n_pix * G * D * 4  # 26.54 GB
+        gwc_bytes = 2 * n_pix * C * 4 + n_pix * G * D * 4  # A3 = 26.54 GB
+        if not args.reread:
+            gwc_bytes += n_pix * D * 4 + n_pix * 4         # + mean volume (8(d): A1's N*D*4) + disparity = 29.74 GB
         traffic = None  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
-            # the store variant of the volume builder (third template argument 0 = EPI_STORE) at G=8
-            cands = [v for k, v in pmc["kernels"].items() if k.startswith("gwc_volume_pipe_kernel<16, 12, 0")
-                     and v.get("hbm_write_bytes", 0) > 2e10]
+            pref = "gwc_volume_pipe_kernel<16, 12, 0" if os.environ.get("STEREO_CORR_MFMA") == "0" else "corr_volume_mfma_kernel"
+            cands = [v for k, v in pmc["kernels"].items() if k.startswith(pref) and v.get("hbm_write_bytes", 0) > 2e10]
             traffic = cands[0]["hbm_bytes_per_launch"] if cands else None
         except Exception:
             pass
@@ -242,17 +250,18 @@ def main():
             "config": {"workload": "cfg-2: SceneFlow 960x540 D=192 group-wise (G=8,C=32) LocalCostVolume + soft-argmin, "
                                    "batch=8 per GPU, all reference-API intermediates materialised"
                                    + (" (group mean by re-reading the volume)" if args.reread else
-                                      " (group mean + disparity from the feature tiles, identity I1: volume written once)"),
+                                      " (volume stage in one kernel: group mean + disparity from the feature tiles, identity I1; the volume is written "
+                                      "once and never read back)"),
                        "pairs_per_gpu": B_PER_GPU, "parallelism": f"pairs sharded over {world} GPU(s), no data collective"},
-            "roofline": {"bound": "hbm", "kernel": "gwc_volume_pipe_kernel<16,12,EPI_STORE> (A3 group-wise volume build)", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm",
+                         "kernel": ("gwc volume kernel (A3 group-wise volume build)" if args.reread else
+                                    "corr_volume_mfma_kernel<7,ARGMIN,8,3,CPG2=2> (A3 group-wise volume + group mean + A4 "
+                                    "soft-argmin in one launch)"), "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "algorithmic_bytes": gwc_bytes, "avg_launch_ms": round(build_ms, 4)},
-            "kernels_ms": {"gwc_build": round(build_ms, 4),
-                           ("group_mean_soft_argmin_reread" if args.reread else "mean_volume_soft_argmin_from_tiles"):
-                               round(read_ms, 4),
-                           ("mean_volume_soft_argmin_from_tiles" if args.reread else "group_mean_soft_argmin_reread"):
-                               None if other_ms is None else round(other_ms, 4),
-                           "fused_corr_soft_argmin_no_volume": None if fused_ms is None else round(fused_ms, 4)},
+            "kernels_ms": dict({("gwc_build" if args.reread else "volume_stage_fused"): round(build_ms, 4),
+                                "fused_corr_soft_argmin_no_volume": None if fused_ms is None else round(fused_ms, 4)},
+                               **({"group_mean_soft_argmin_reread": round(read_ms, 4)} if args.reread else {}), **other),
             "checksum": checksum,
         }
         if world == 1 and not args.no_cpu_baseline:

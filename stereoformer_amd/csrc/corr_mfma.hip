@@ -37,7 +37,7 @@ namespace {
 // flushes into volg[b, g]; then the all-channel pass produces the mean volume and the disparity as before.  The key
 // tile and the Q registers are fetched once for both; the 25.5 GB group-wise volume leaves through the same
 // row-contiguous flush path (which sustains > 6 TB/s on its own) and is never read back.
-template <int NT, bool ARGMIN, int CM_NWV, int RINGB, int CPG2 = 0>
+template <int NT, bool ARGMIN, int CM_NWV, int RINGB, int CPG2 = 0, bool MEANPASS = true>
 __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const float *__restrict__ L,
                                                                        const float *__restrict__ R,
                                                                        float *__restrict__ vol, float *__restrict__ disp,
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
         }
         float m = -INFINITY, ssum = 0.0f, esc = 0.0f;
 #pragma unroll 1
-        for (int s = 0; s < NT; ++s) {
+        for (int s = 0; MEANPASS && s < NT; ++s) {  // (MEANPASS = false: A3 alone, the group pass above was all)
             const int sb = s % RINGB;  // ring block of the rows 32 s .. 32 s + 31
             if (wave_on) {
                 f32x16 a;
@@ -264,13 +264,13 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
     }
 }
 
-template <int NT, bool ARGMIN, int NWV, int RINGB, int CPG2 = 0>
+template <int NT, bool ARGMIN, int NWV, int RINGB, int CPG2 = 0, bool MEANPASS = true>
 int launch_cm(const float *L, const float *R, float *vol, float *disp, int B, int C, int H, int W, int D, float sgn,
               hipStream_t st, float *volg = nullptr, int G = 0)
 {
     constexpr int Dk = 32 * (NT - 1), TQW = 32 * NWV;
     const size_t lds = ((size_t)32 * (TQW + Dk + 4) + (size_t)32 * RINGB * (TQW + 4)) * sizeof(float);
-    auto kern = corr_volume_mfma_kernel<NT, ARGMIN, NWV, RINGB, CPG2>;
+    auto kern = corr_volume_mfma_kernel<NT, ARGMIN, NWV, RINGB, CPG2, MEANPASS>;
     if (lds > 160 * 1024) return STEREO_ERR_UNSUPPORTED;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -314,23 +314,27 @@ int stereo_corr_volume_mfma(const float *L, const float *R, float *vol, float *d
 }
 
 // A3 + group mean + A4 fused (see the kernel's group pass).  volg [B,G,D,H,W], mean [B,D,H,W], disp [B,H,W].
+// mean == nullptr && disp == nullptr: A3 alone (group pass only).
 int stereo_gwc_mean_argmin_mfma(const float *L, const float *R, float *volg, float *mean, float *disp, int B, int C, int H,
                                 int W, int D, int G, float sgn, hipStream_t st)
 {
+    const bool only_groups = mean == nullptr && disp == nullptr;
     if (C > 32 || D > 192 || D < 1 || W % 4 != 0 || G < 1 || C % G != 0 || !aligned16(L) || !aligned16(R) ||
-        !aligned16(volg) || !aligned16(mean) || disp == nullptr)
+        !aligned16(volg) || (!only_groups && (!aligned16(mean) || mean == nullptr || disp == nullptr)))
         return STEREO_ERR_UNSUPPORTED;
     if ((long long)32 * H * W >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
     const int cpg = C / G;
-    if (cpg % 2 != 0 || (cpg != 2 && cpg != 4 && cpg != 8 && cpg != 16)) return STEREO_ERR_UNSUPPORTED;
+    if (cpg != 2 && cpg != 4 && cpg != 8 && cpg != 16) return STEREO_ERR_UNSUPPORTED;
     const int nt = (D + 31) / 32 + 1;
-#define CMG(NTV, P2) return launch_cm<NTV, true, 8, 3, P2>(L, R, mean, disp, B, C, H, W, D, sgn, st, volg, G)
-#define CMG_NT(NTV)            \
-    do {                       \
+#define CMG(NTV, P2)                                                                                          \
+    return only_groups ? launch_cm<NTV, false, 8, 3, P2, false>(L, R, mean, disp, B, C, H, W, D, sgn, st, volg, G) \
+                       : launch_cm<NTV, true, 8, 3, P2, true>(L, R, mean, disp, B, C, H, W, D, sgn, st, volg, G)
+#define CMG_NT(NTV)                \
+    do {                           \
         if (cpg == 2) CMG(NTV, 1); \
         if (cpg == 4) CMG(NTV, 2); \
         if (cpg == 8) CMG(NTV, 4); \
-        CMG(NTV, 8);           \
+        CMG(NTV, 8);               \
     } while (0)
     if (nt <= 3) CMG_NT(3);
     if (nt <= 5) CMG_NT(5);

@@ -97,6 +97,7 @@ def test_volume_whole_row_workgroup_shape(S, oracle, wx, monkeypatch):
     both against the oracle, incl. ragged last tile columns, W > 1024 (two workgroups per row), D not a multiple of
     the 48 disparities a wide workgroup covers, channels/group in {1, 2, 4}."""
     monkeypatch.setenv("STEREO_VOL_WX", wx)
+    monkeypatch.setenv("STEREO_CORR_MFMA", "0")   # the VALU store kernel's shapes (the MFMA group pass has its own test)
     rng = np.random.default_rng(17)
     for (B, C, H, W, D, G) in ((1, 32, 5, 960, 192, 8), (2, 8, 6, 1300, 100, 4), (1, 6, 9, 520, 97, 6), (1, 8, 3, 260, 40, 2)):
         L = rng.standard_normal((B, C, H, W), dtype=np.float32)
@@ -127,6 +128,29 @@ def test_corr_volume_mfma_vs_valu_vs_oracle(S, oracle, shape, mfma, monkeypatch)
     v, d = S.corr_volume_with_disparity(dev(L), dev(R), D)
     close(v, ref, **VOL_TOL)
     close(d, oracle.soft_argmin(ref), **DISP_TOL)
+
+
+@pytest.mark.parametrize("mode", ["fused", "groups_mfma_mean_separate", "valu"])
+@pytest.mark.parametrize("shape", [(1, 32, 5, 960, 192, 8), (2, 12, 6, 520, 150, 3), (1, 32, 3, 300, 64, 2), (1, 8, 4, 260, 97, 4),
+                                   (2, 16, 2, 36, 7, 1), (1, 24, 2, 1300, 40, 12)])
+def test_gwc_volume_group_pass_mfma(S, oracle, shape, mode, monkeypatch):
+    """A3 alone and A3 + group mean + A4 in ONE kernel (group pass on the matrix cores, channels per group in
+    {2, 4, 8, 16}) against the oracle, next to the two-kernel and the VALU paths."""
+    monkeypatch.setenv("STEREO_CORR_MFMA", "0" if mode == "valu" else "1")
+    if mode == "groups_mfma_mean_separate":
+        monkeypatch.setenv("STEREO_GWC_UNFUSED", "1")
+    B, C, H, W, D, G = shape
+    rng = np.random.default_rng(47)
+    L = rng.standard_normal((B, C, H, W), dtype=np.float32) * 2
+    R = rng.standard_normal((B, C, H, W), dtype=np.float32) * 2
+    ovol = oracle.gwc_volume(L, R, D, G)
+    omean = oracle.group_mean(ovol)
+    close(S.build_gwc_volume(dev(L), dev(R), D, G), ovol, **VOL_TOL)
+    for sim in (True, False):
+        vol, disp, mean = S.build_gwc_volume_with_disparity(dev(L), dev(R), D, G, return_mean=True, match_similarity=sim)
+        close(vol, ovol, **VOL_TOL)
+        close(mean, omean, **VOL_TOL)
+        close(disp, oracle.soft_argmin(omean, sim), **DISP_TOL)
 
 
 @pytest.mark.parametrize("cfg", ["24,8", "16,8", "12,8", "-8,12", "-12,8", "16,12"])
