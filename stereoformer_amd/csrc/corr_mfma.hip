@@ -272,9 +272,13 @@ int launch_cm(const float *L, const float *R, float *vol, float *disp, int B, in
     const size_t lds = ((size_t)32 * (TQW + Dk + 4) + (size_t)32 * RINGB * (TQW + 4)) * sizeof(float);
     auto kern = corr_volume_mfma_kernel<NT, ARGMIN, NWV, RINGB, CPG2, MEANPASS>;
     if (lds > 160 * 1024) return STEREO_ERR_UNSUPPORTED;
-    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return STEREO_ERR_UNSUPPORTED;
+    static bool lds_ok = false;  // per instantiation: the opt-in for > 64 KB of dynamic LDS is needed once
+    if (lds > 64 * 1024 && !lds_ok) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return STEREO_ERR_UNSUPPORTED;
+        lds_ok = true;
+    }
     const long long ntl = (long long)((W + TQW - 1) / TQW) * H * B;
     if (ntl >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
     const int resident = 256 * (int)((160 * 1024) / lds);  // persistent workgroups: as many as the LDS admits per CU

@@ -976,8 +976,9 @@ extern "C" int stereo_gwc_volume_f32(const float *left, const float *right, floa
                                      int D, int G, void *stream)
 {
     if (B > 0 && C > 0 && H > 0 && W > 0 && D > 0 && G > 0 && C % G == 0 && left && right && vol && corr_mfma_enabled()) {
-        const int rc = stereo_gwc_mean_argmin_mfma(left, right, vol, nullptr, nullptr, B, C, H, W, D, G, 1.0f,
-                                                   as_stream(stream));
+        const int rc = G == 1 ? stereo_corr_volume_mfma(left, right, vol, nullptr, B, C, H, W, D, 1.0f, as_stream(stream))
+                              : stereo_gwc_mean_argmin_mfma(left, right, vol, nullptr, nullptr, B, C, H, W, D, G, 1.0f,
+                                                            as_stream(stream));
         if (rc != STEREO_ERR_UNSUPPORTED) return rc;
     }
     return gwc_dispatch<EPI_STORE>(left, right, vol, B, C, H, W, D, G, 1.0f, stream);
