@@ -730,6 +730,42 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_online_kernel(const 
     }
 }
 
+// v5 launcher (also behind corr_soft_argmin: A1 + A4 without any volume is this kernel with mask 'zero', scale
+// +-1/C and no output tensor -- SURVEY 8(c) identity I3).  Envelope: C <= 32, D <= 256, W % 4 == 0, 16-B aligned.
+int launch_online(const float *left, const float *right, float *out, float *disp, int B, int C, int H, int W, int D,
+                  int mask_mode, float sc, hipStream_t st)
+{
+    if (C > 32 || D > 256 || D < 1 || W % 4 != 0 || !aligned16(left) || !aligned16(right) || (long long)32 * H * W >= (1LL << 31))
+        return STEREO_ERR_UNSUPPORTED;
+    const int nt = (D + 31) / 32 + 1;
+    // waves (32 queries each) per workgroup: 8 (256 queries, the halo is re-fetched 1.75x) unless the row
+    // is so short that half of them would idle.  (6 waves = 192 queries divides W = 960 exactly but
+    // measured slower: its register budget admits a single 6-wave workgroup per CU.)
+    int nwv = W > 128 ? 8 : 4;
+    if (const char *e = getenv("STEREO_ATT_NW")) nwv = atoi(e) == 8 ? 8 : 4;
+    // persistent workgroups: two resident per CU walk contiguous runs of tiles (row-major)
+    const int ntl = ((W + 32 * nwv - 1) / (32 * nwv)) * H * B;
+    int tpw = (ntl + 511) / 512;
+    if (const char *e = getenv("STEREO_ATT_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;
+    const int nwg = (ntl + tpw - 1) / tpw;
+#define ATT5N(NTV, NWVV)                                                                                        \
+    hipLaunchKernelGGL((cross_attention_online_kernel<NTV, NWVV>), dim3(nwg), dim3(NWVV * 64), 0, st, left, right, out, \
+                       disp, C, H, W, D, mask_mode, sc, tpw, ntl)
+#define ATT5(NTV)                    \
+    do {                             \
+        if (nwv == 8) ATT5N(NTV, 8); \
+        else ATT5N(NTV, 4);          \
+    } while (0)
+    if (nt <= 3) ATT5(3);
+    else if (nt <= 5) ATT5(5);
+    else if (nt <= 7) ATT5(7);
+    else ATT5(9);
+#undef ATT5N
+#undef ATT5
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
 }  // namespace
 
 extern "C" int stereo_cross_attention_f32(const float *left, const float *right, const float *value, float *out,
@@ -754,34 +790,9 @@ extern "C" int stereo_cross_attention_f32(const float *left, const float *right,
             const int same_kv = (out != nullptr && value == right && Cv == C) ? 1 : 0;
             dim3 grid4((W + A4_TQ - 1) / A4_TQ, H, B);
             const char *v5off = getenv("STEREO_ATT_V4");
-            if (C <= 32 && (out == nullptr || same_kv) && (long long)32 * H * W < (1LL << 31) &&
-                !(v5off && v5off[0] == '1')) {  // v5: online softmax
-                // waves (32 queries each) per workgroup: 8 (256 queries, the halo is re-fetched 1.75x) unless the row
-                // is so short that half of them would idle.  (6 waves = 192 queries divides W = 960 exactly but
-                // measured slower: its register budget admits a single 6-wave workgroup per CU.)
-                int nwv = W > 128 ? 8 : 4;
-                if (const char *e = getenv("STEREO_ATT_NW")) nwv = atoi(e) == 8 ? 8 : 4;
-                // persistent workgroups: two resident per CU walk contiguous runs of tiles (row-major)
-                const int ntl = ((W + 32 * nwv - 1) / (32 * nwv)) * H * B;
-                int tpw = (ntl + 511) / 512;
-                if (const char *e = getenv("STEREO_ATT_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;
-                const int nwg = (ntl + tpw - 1) / tpw;
-#define ATT5N(NTV, NWVV)                                                                                               \
-    hipLaunchKernelGGL((cross_attention_online_kernel<NTV, NWVV>), dim3(nwg), dim3(NWVV * 64), 0, as_stream(stream), left, \
-                       right, out, disp, C, H, W, D, mask_mode, sc, tpw, ntl)
-#define ATT5(NTV)                    \
-    do {                             \
-        if (nwv == 8) ATT5N(NTV, 8); \
-        else ATT5N(NTV, 4);          \
-    } while (0)
-                if (nt <= 3) ATT5(3);
-                else if (nt <= 5) ATT5(5);
-                else if (nt <= 7) ATT5(7);
-                else ATT5(9);
-#undef ATT5N
-#undef ATT5
-                STEREO_LAUNCH_CHECK();
-                return STEREO_OK;
+            if (C <= 32 && (out == nullptr || same_kv) && !(v5off && v5off[0] == '1')) {  // v5: online softmax
+                const int rc5 = launch_online(left, right, out, disp, B, C, H, W, D, mask_mode, sc, as_stream(stream));
+                if (rc5 != STEREO_ERR_UNSUPPORTED) return rc5;
             }
 #define ATT4(NTV)                                                                                                      \
     hipLaunchKernelGGL((cross_attention_reg_kernel<NTV, (NTV <= 7 ? 2 : 1)>), grid4, dim3(A4_NW * 64), 0, as_stream(stream), left, right, value, \
@@ -832,4 +843,11 @@ extern "C" int stereo_cross_attention_f32(const float *left, const float *right,
                        Cv, H, W, D, Dpad, mask_mode, scale);
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
+}
+
+// A1 + A4 with no volume at all, on the matrix cores (library-internal; STEREO_ERR_UNSUPPORTED outside the envelope).
+int stereo_corr_soft_argmin_mfma(const float *L, const float *R, float *disp, int B, int C, int H, int W, int D, float sgn,
+                                 hipStream_t st)
+{
+    return launch_online(L, R, nullptr, disp, B, C, H, W, D, STEREO_MASK_ZERO, sgn / (float)C, st);
 }

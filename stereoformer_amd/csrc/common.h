@@ -59,3 +59,6 @@ int stereo_corr_volume_mfma(const float *L, const float *R, float *vol, float *d
 // A3 + group mean + A4 in one kernel (even channels per group <= 16); same envelope, same return convention.
 int stereo_gwc_mean_argmin_mfma(const float *L, const float *R, float *volg, float *mean, float *disp, int B, int C, int H,
                                 int W, int D, int G, float sgn, hipStream_t st);
+// attention.hip: A1 + A4 without any volume (= cross-attention, mask 'zero', scale +-1/C, no output tensor).
+int stereo_corr_soft_argmin_mfma(const float *L, const float *R, float *disp, int B, int C, int H, int W, int D, float sgn,
+                                 hipStream_t st);

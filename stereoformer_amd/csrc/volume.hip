@@ -1053,5 +1053,10 @@ extern "C" int stereo_corr_soft_argmin_f32(const float *left, const float *right
                                            int W, int D, int match_similarity, void *stream)
 {
     if (D == 0 && B > 0 && H > 0 && W > 0) return STEREO_ERR_BAD_SHAPE;  // softmax over an empty axis
+    if (B > 0 && C > 0 && H > 0 && W > 0 && left && right && disp && corr_mfma_enabled()) {
+        const int rc = stereo_corr_soft_argmin_mfma(left, right, disp, B, C, H, W, D, match_similarity ? 1.0f : -1.0f,
+                                                    as_stream(stream));
+        if (rc != STEREO_ERR_UNSUPPORTED) return rc;
+    }
     return gwc_dispatch<EPI_ARGMIN>(left, right, disp, B, C, H, W, D, 1, match_similarity ? 1.0f : -1.0f, stream);
 }

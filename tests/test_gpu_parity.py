@@ -259,8 +259,10 @@ def test_gwc_volume_with_disparity(S, oracle, shape):
     close(cd, oracle.soft_argmin(oracle.corr_volume(L, R, D)), **DISP_TOL)
 
 
+@pytest.mark.parametrize("mfma", ["1", "0"])
 @pytest.mark.parametrize("shape", [(2, 32, 5, 300, 64), (1, 32, 2, 960, 192), (1, 6, 3, 37, 9), (1, 8, 2, 40, 200)])
-def test_fused_corr_soft_argmin(S, oracle, shape):
+def test_fused_corr_soft_argmin(S, oracle, shape, mfma, monkeypatch):
+    monkeypatch.setenv("STEREO_CORR_MFMA", mfma)   # "1": the attention v5 kernel (identity I3); "0": VALU arg-min epilogue
     B, C, H, W, D = shape
     rng = np.random.default_rng(13)
     L = rng.standard_normal((B, C, H, W), dtype=np.float32) * 2

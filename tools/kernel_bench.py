@@ -90,7 +90,8 @@ def main():
             del volg
         if want("A1A4_fused"):
             add("A1+A4 fused corr_soft_argmin cfg-2", timeit(lambda: S.corr_soft_argmin(L, R, D), args.reps),
-                (2 * N * C * 4 + N * 4) / 1e9, 2 * B * H * C * (D * W - D * (D - 1) / 2) / 1e9, bound="valu")
+                (2 * N * C * 4 + N * 4) / 1e9, 2 * B * H * C * (D * W - D * (D - 1) / 2) / 1e9, bound="mfma",
+                note="= cross-attention v5 kernel, mask zero, scale 1/C, no output tensor (identity I3)")
         if want("A2_"):
             L1, R1 = L[:1, :8].contiguous(), R[:1, :8].contiguous()
             n1 = H * W
