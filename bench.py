@@ -212,6 +212,12 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 return round(e0.elapsed_time(e1) / 5, 4)
+            if not args.reread:   # the shortcut the fused kernel takes, verified on this very batch: vol.mean(1) == mean
+                volg, _, mean_f = S.build_gwc_volume_with_disparity(L, R, D, G, return_mean=True)
+                other["identity_I1_max_abs(vol.mean(1) - mean)"] = max(
+                    float((volg[b_, :, :, r_].mean(0) - mean_f[b_, :, r_]).abs().max().item())
+                    for b_ in (0, B_PER_GPU - 1) for r_ in (0, H // 2, H - 1))
+                del volg, mean_f
             other["gwc_volume_alone"] = t5(lambda: S.build_gwc_volume(L, R, D, G))
             other["mean_volume_soft_argmin_from_features"] = t5(lambda: S.corr_volume_with_disparity(L, R, D))
             if not args.reread:
