@@ -154,10 +154,11 @@ class LowCNNGRULoop(nn.Module):
                                                  sample_points=sample_points)
         self._graphs = _GraphCache()
 
-    def forward(self, cost_volume, disp, left_image, right_image, iters=12, use_graph=False):
+    def forward(self, cost_volume, disp, left_image, right_image, iters=12, use_graph=False, graph_all_iterates=False):
         """cost_volume [B,D,h,w] (1/8 scale), disp [B,1,h,w] -> list of full-resolution disparities
-        (one per iteration, like the reference), or only the last one when ``use_graph``.  Differentiable
-        in grad mode (every custom op on the path has a HIP backward); the graph replay is inference-only."""
+        (one per iteration, like the reference), or only the last one when ``use_graph`` (all of them with
+        ``graph_all_iterates``).  Differentiable in grad mode (every custom op on the path has a HIP backward); the
+        graph replay is inference-only."""
         B, D, h, w = cost_volume.shape
         hidden = torch.zeros(B, 2 * self.update.hidden_dim, h, w, device=cost_volume.device)
         if use_graph:
@@ -166,11 +167,16 @@ class LowCNNGRULoop(nn.Module):
 
             def fn(ts):
                 d, hid = ts[1], torch.zeros_like(hidden)
-                for it in range(iters):   # only the last iterate is upsampled: earlier mask heads are skipped
-                    d, hid, mask = self.update(ts[0], d, ts[2], ts[3], hid, True, need_mask=it == iters - 1)
-                return [upsample_convex8(d, mask)]
+                outs = []
+                for it in range(iters):   # unless every iterate is wanted, only the last one is upsampled: the
+                    last = it == iters - 1  # earlier mask heads are skipped
+                    d, hid, mask = self.update(ts[0], d, ts[2], ts[3], hid, True, need_mask=last or graph_all_iterates)
+                    if last or graph_all_iterates:
+                        outs.append(upsample_convex8(d, mask))
+                return outs
 
-            key = (tuple(cost_volume.shape), tuple(left_image.shape), iters, cost_volume.device.index)
+            key = (tuple(cost_volume.shape), tuple(left_image.shape), iters, cost_volume.device.index,
+                   bool(graph_all_iterates))
             return self._graphs.run(key, fn, [cost_volume, disp, left_image, right_image])
         outs = []
         for _ in range(iters):

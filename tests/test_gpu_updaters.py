@@ -198,6 +198,10 @@ def test_lowcnn_gru_loop_graph_matches_eager(S):
     with torch.no_grad():
         eager = loop(vol, disp, left, right, iters=6)
         graphed = loop(vol, disp, left, right, iters=6, use_graph=True)
+        graphed_all = loop(vol, disp, left, right, iters=6, use_graph=True, graph_all_iterates=True)
+    assert len(graphed_all) == 6
+    for a_, b_ in zip(eager, graphed_all):
+        assert (a_ - b_).abs().max().item() < 1e-4
     with pytest.raises(RuntimeError, match="inference path"):
         loop(vol, disp, left, right, iters=6, use_graph=True)
     # and the same loop is trainable in grad mode
