@@ -272,12 +272,14 @@ int launch_cm(const float *L, const float *R, float *vol, float *disp, int B, in
     const size_t lds = ((size_t)32 * (TQW + Dk + 4) + (size_t)32 * RINGB * (TQW + 4)) * sizeof(float);
     auto kern = corr_volume_mfma_kernel<NT, ARGMIN, NWV, RINGB, CPG2, MEANPASS>;
     if (lds > 160 * 1024) return STEREO_ERR_UNSUPPORTED;
-    static bool lds_ok = false;  // per instantiation: the opt-in for > 64 KB of dynamic LDS is needed once
-    if (lds > 64 * 1024 && !lds_ok) {
+    static bool lds_ok[64] = {};  // per instantiation and device: the opt-in for > 64 KB of dynamic LDS is needed once
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (lds > 64 * 1024 && (dev < 0 || !lds_ok[dev])) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return STEREO_ERR_UNSUPPORTED;
-        lds_ok = true;
+        if (dev >= 0) lds_ok[dev] = true;
     }
     const long long ntl = (long long)((W + TQW - 1) / TQW) * H * B;
     if (ntl >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
