@@ -38,6 +38,61 @@ class _GwcVolumeFn(torch.autograd.Function):
         return gl, gr, None, None, None
 
 
+class _GwcWithDisparityFn(torch.autograd.Function):
+    """``(vol, disp, mean) = build_gwc_volume_with_disparity(L, R)`` with a backward that follows the fused forward:
+    whatever reaches the mean volume (its own cotangent plus the soft-argmin's) goes through ONE correlation-volume
+    backward over a [B,D,H,W] gradient; the G-times larger group-wise backward runs only when ``vol`` itself has a
+    consumer.  (The composition build_gwc_volume -> group_mean_soft_argmin would materialise and re-read a dense
+    [B,G,D,H,W] gradient even when only the disparity is used.)"""
+
+    @staticmethod
+    def forward(ctx, left, right, max_disp, num_groups, match_similarity):
+        B, C, H, W = left.shape
+        D, G = int(max_disp), int(num_groups)
+        vol = torch.empty((B, G, D, H, W), device=left.device, dtype=torch.float32)
+        disp = torch.empty((B, H, W), device=left.device, dtype=torch.float32)
+        mean = torch.empty((B, D, H, W), device=left.device, dtype=torch.float32)
+        with torch.cuda.device(left.device):
+            N.call("stereo_gwc_volume_soft_argmin_f32", N.ptr(left), N.ptr(right), N.ptr(vol), N.ptr(mean), N.ptr(disp), B, C, H,
+                   W, D, G, 1 if match_similarity else 0, N.stream_ptr(left.device))
+        ctx.save_for_backward(left, right, mean)
+        ctx.cfg = (D, G, bool(match_similarity))
+        ctx.set_materialize_grads(False)  # an unused output must not become a 25 GB tensor of zeros
+        return vol, disp, mean
+
+    @staticmethod
+    def backward(ctx, g_vol, g_disp, g_mean):
+        left, right, mean = ctx.saved_tensors
+        D, G, sim = ctx.cfg
+        B, C, H, W = left.shape
+        dev = left.device
+        gm = None
+        with torch.cuda.device(dev):
+            if g_disp is not None:  # soft-argmin backward on the mean volume
+                gm = torch.empty_like(mean)
+                N.call("stereo_soft_argmin_bwd_f32", N.ptr(mean), N.ptr(N.dev_f32(g_disp, "fused volume backward: grad_disp")),
+                       N.ptr(None), N.ptr(gm), B, D, H, W, 1 if sim else 0, N.stream_ptr(dev))
+            if g_mean is not None:
+                g_mean = N.dev_f32(g_mean, "fused volume backward: grad_mean")
+                gm = g_mean if gm is None else gm + g_mean
+            gl = gr = None
+
+            def vol_bwd(gv, groups):
+                a = torch.empty_like(left) if ctx.needs_input_grad[0] else None
+                b = torch.empty_like(right) if ctx.needs_input_grad[1] else None
+                N.call("stereo_gwc_volume_bwd_f32", N.ptr(left), N.ptr(right), N.ptr(gv), N.ptr(a), N.ptr(b), B, C, H, W, D,
+                       groups, N.stream_ptr(dev))
+                return a, b
+
+            if gm is not None:  # mean == all-channel correlation volume (identity I1): its backward is the G = 1 one
+                gl, gr = vol_bwd(gm.contiguous(), 1)
+            if g_vol is not None:
+                a, b = vol_bwd(N.dev_f32(g_vol, "fused volume backward: grad_vol"), G)
+                gl = a if gl is None else (gl + a if a is not None else gl)
+                gr = b if gr is None else (gr + b if b is not None else gr)
+        return gl, gr, None, None, None
+
+
 def _gwc_forward(L, R, maxdisp, num_groups):
     B, C, H, W = L.shape
     vol = torch.empty((B, num_groups, maxdisp, H, W), device=L.device, dtype=torch.float32)
@@ -150,13 +205,15 @@ def build_gwc_volume_with_disparity(refimg_fea, targetimg_fea, maxdisp, num_grou
 
     ``vol.mean(1)`` over equally sized groups is the all-channel correlation volume (SURVEY 8(c) identity I1), so
     the disparity and the mean come from the LDS-staged feature tiles while the group-wise volume is being
-    produced: the [B,G,D,H,W] volume is written once and never read back (cfg-2: 25.5 GB of reads saved).  In grad
-    mode the call is the composition of the two differentiable HIP ops."""
-    from .estimation import group_mean_soft_argmin
+    produced: the [B,G,D,H,W] volume is written once and never read back (cfg-2: 25.5 GB of reads saved).
+    Differentiable: the backward follows the fused forward (see ``_GwcWithDisparityFn``)."""
     if _wants_grad(refimg_fea, targetimg_fea):
-        vol = build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups)
-        out = group_mean_soft_argmin(vol, return_mean=return_mean, match_similarity=match_similarity)
-        return (vol, *out) if return_mean else (vol, out)
+        with torch.no_grad():
+            L, R = _pair(refimg_fea, targetimg_fea, "build_gwc_volume_with_disparity")
+        assert L.shape[1] % num_groups == 0  # GWC_Cost_Volume.py:7
+        vol, disp, mean = _GwcWithDisparityFn.apply(refimg_fea.contiguous(), targetimg_fea.contiguous(), int(maxdisp),
+                                                    int(num_groups), bool(match_similarity))
+        return (vol, disp, mean) if return_mean else (vol, disp)
     L, R = _pair(refimg_fea, targetimg_fea, "build_gwc_volume_with_disparity")
     assert L.shape[1] % num_groups == 0  # GWC_Cost_Volume.py:7
     B, C, H, W = L.shape

@@ -266,3 +266,30 @@ def test_raft_stereo_loop_gradients_g12(S, golden):
         got = g_ if g_.numel() < 20000 else g_.flatten()[::37]
         # MIOpen's weight-gradient kernels sum in a box / algorithm dependent order (2.3e-3 seen on one conv)
         assert rel(got, ref) < 5e-3, (n_, rel(got, ref))
+
+
+def test_fused_volume_stage_backward_matches_composition(S):
+    """build_gwc_volume_with_disparity in grad mode (fused forward, backward through the mean volume) against the
+    composition build_gwc_volume -> group_mean_soft_argmin, for losses on the disparity + mean only and on all three."""
+    torch.manual_seed(9)
+    B, C, H, W, D, G = 2, 16, 5, 72, 40, 4
+    L0, R0 = torch.randn(B, C, H, W, device="cuda"), torch.randn(B, C, H, W, device="cuda")
+    cd, cm, cv = torch.randn(B, H, W, device="cuda"), torch.randn(B, D, H, W, device="cuda"), torch.randn(B, G, D, H, W, device="cuda")
+    for use_vol in (False, True):
+        grads = []
+        for fused in (True, False):
+            L, R = L0.clone().requires_grad_(True), R0.clone().requires_grad_(True)
+            if fused:
+                vol, disp, mean = S.build_gwc_volume_with_disparity(L, R, D, G, return_mean=True)
+            else:
+                vol = S.build_gwc_volume(L, R, D, G)
+                disp, mean = S.group_mean_soft_argmin(vol, return_mean=True)
+            loss = (disp * cd).sum() + (mean * cm).sum() + ((vol * cv).sum() if use_vol else 0.0)
+            grads.append(torch.autograd.grad(loss, [L, R]))
+        for a, b in zip(grads[0], grads[1]):
+            close(a, b.cpu().numpy(), rtol=1e-4, atol=5e-5)
+    # only the disparity used: gradients still flow, nothing else is materialised
+    L = L0.clone().requires_grad_(True)
+    _, disp = S.build_gwc_volume_with_disparity(L, R0, D, G)
+    (gl,) = torch.autograd.grad((disp * cd).sum(), [L])
+    assert torch.isfinite(gl).all() and gl.abs().max().item() > 0
