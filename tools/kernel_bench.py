@@ -206,6 +206,23 @@ def main():
                 timeit(lambda: torch.autograd.grad(vg, (L1g, R1g), cg, retain_graph=True), 3, 1),
                 (2 * n2 * G * D * 4 + 4 * n2 * C * 4) / 1e9)
             del vg, cg
+            # one training step of the cfg-2 chain at B=2 (features -> volume stage -> local lookup -> scalar loss)
+            lk = S.LocalCostVolume(2, 20)
+
+            def train_step(fused):
+                Lt, Rt = L[:2].detach().requires_grad_(True), R[:2].detach().requires_grad_(True)
+                if fused:
+                    _, dsp2, mean2 = S.build_gwc_volume_with_disparity(Lt, Rt, D, G, return_mean=True)
+                else:
+                    vol2 = S.build_gwc_volume(Lt, Rt, D, G)
+                    dsp2, mean2 = S.group_mean_soft_argmin(vol2, return_mean=True)
+                out2 = lk(mean2, dsp2.unsqueeze(1), True)
+                torch.autograd.grad(out2.mean(), (Lt, Rt))
+
+            for fused in (True, False):
+                add(f"train step cfg-2 chain B=2 fwd+bwd ({'fused volume stage' if fused else 'composition of the separate ops'})",
+                    timeit(lambda: train_step(fused), 3, 1), None,
+                    note="features -> group-wise volume + mean + disparity -> LocalCostVolume -> loss; gradients w.r.t. both features")
             torch.set_grad_enabled(False)
         if want("loop_raft"):
             loop = S.RAFTStereoLoop([128, 128, 128]).eval().cuda()
