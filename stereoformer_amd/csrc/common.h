@@ -53,7 +53,7 @@ __device__ __forceinline__ float sample_tap(const float *__restrict__ v, size_t 
 }
 
 // corr_mfma.hip: A1 (+ A4 when disp != nullptr) on the f32 matrix cores.  Library-internal (not part of the C ABI);
-// returns STEREO_ERR_UNSUPPORTED outside its envelope (C <= 32, D <= 192, W % 4 == 0, 16-B aligned).
+// returns STEREO_ERR_UNSUPPORTED outside its envelope (C <= 32, D <= 256, W % 4 == 0, 16-B aligned).
 int stereo_corr_volume_mfma(const float *L, const float *R, float *vol, float *disp, int B, int C, int H, int W, int D,
                             float sgn, hipStream_t st);
 // A3 + group mean + A4 in one kernel (even channels per group <= 16); same envelope, same return convention.

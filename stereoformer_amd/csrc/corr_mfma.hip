@@ -20,7 +20,8 @@
 //   * ARGMIN: the online softmax of attention.hip's v5 kernel runs on the same accumulators (packed-f32 VALU, one
 //     xor-32 exchange per tile) and the disparity leaves at the end of the tile.
 // Persistent workgroups walk runs of tiles; the next tile's K quads / Q values are prefetched into registers under the
-// current tile's MFMAs.  C <= 32 (one MFMA K-tile), D <= 192 (LDS: 58 KB keys + 100 KB sheet), W % 4 == 0.
+// current tile's MFMAs.  C <= 32 (one MFMA K-tile), W % 4 == 0, D <= 192 (LDS: 58 KB keys + 100 KB sheet; up to 256 for
+// A1 / A1+A4 with six waves per workgroup).
 #include <stdlib.h>
 
 #include "common.h"
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
     constexpr int Dk = 32 * (NT - 1);
     constexpr int NK = CM_TQW + Dk;
     constexpr int KS = NK + 4;
-    constexpr int RMAX = 32 / CM_NWV;          // staged rows per wave
+    constexpr int RMAX = (32 + CM_NWV - 1) / CM_NWV;  // staged rows per wave (row = wave, wave + NWV, ... < 32)
     constexpr int NPASS = (NK / 4 + 63) / 64;  // 16-B quads per lane and row
     extern __shared__ f32x4 smem4[];
     f32x4 *Ks4 = smem4;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
             const int row = wave + rr * CM_NWV;
 #pragma unroll
             for (int pp = 0; pp < NPASS; ++pp) {
-                const bool ok = ((okbits >> pp) & 1u) && row < C;
+                const bool ok = ((okbits >> pp) & 1u) && row < C && row < 32;
                 rk[rr][pp] = ld4(Rb + (ok ? (unsigned)row * HWu + (unsigned)(kbase + 4 * (lane + 64 * pp)) : 0u));
             }
         }
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
             const int row = wave + rr * CM_NWV;
 #pragma unroll
             for (int pp = 0; pp < NPASS; ++pp) {
-                if (lane + 64 * pp < NK / 4)
+                if (row < 32 && lane + 64 * pp < NK / 4)
                     Ks4[(row * KS) / 4 + lane + 64 * pp] =
                         (((okbits >> pp) & 1u) && row < C) ? rk[rr][pp] : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
@@ -300,9 +301,12 @@ int launch_cm(const float *L, const float *R, float *vol, float *disp, int B, in
 int stereo_corr_volume_mfma(const float *L, const float *R, float *vol, float *disp, int B, int C, int H, int W, int D,
                             float sgn, hipStream_t st)
 {
-    if (C > 32 || D > 192 || D < 1 || W % 4 != 0 || !aligned16(L) || !aligned16(R) || !aligned16(vol)) return STEREO_ERR_UNSUPPORTED;
+    if (C > 32 || D > 256 || D < 1 || W % 4 != 0 || !aligned16(L) || !aligned16(R) || !aligned16(vol)) return STEREO_ERR_UNSUPPORTED;
     if ((long long)32 * H * W >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
     const int nt = (D + 31) / 32 + 1;
+    if (nt > 7)  // 192 < D <= 256: six waves (192 queries) keep key tile + sheet inside the 160 KB of LDS
+        return disp ? launch_cm<9, true, 6, 3>(L, R, vol, disp, B, C, H, W, D, sgn, st)
+                    : launch_cm<9, false, 6, 3>(L, R, vol, disp, B, C, H, W, D, sgn, st);
     int small = 0;  // dev knob: STEREO_CM_SHAPE=4 -> 128-query tiles, two workgroups per CU
     if (const char *e = getenv("STEREO_CM_SHAPE")) small = atoi(e) == 4;
 #define CM_CASE(NTV)                                                                                              \
@@ -331,7 +335,7 @@ int stereo_gwc_mean_argmin_mfma(const float *L, const float *R, float *volg, flo
     if ((long long)32 * H * W >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
     const int cpg = C / G;
     if (cpg != 2 && cpg != 4 && cpg != 8 && cpg != 16) return STEREO_ERR_UNSUPPORTED;
-    const int nt = (D + 31) / 32 + 1;
+    const int nt = (D + 31) / 32 + 1;  // (D <= 192 here: the fused launch is instantiated for the 8-wave shape only)
 #define CMG(NTV, P2)                                                                                          \
     return only_groups ? launch_cm<NTV, false, 8, 3, P2, false>(L, R, mean, disp, B, C, H, W, D, sgn, st, volg, G) \
                        : launch_cm<NTV, true, 8, 3, P2, true>(L, R, mean, disp, B, C, H, W, D, sgn, st, volg, G)

@@ -107,7 +107,8 @@ def test_volume_whole_row_workgroup_shape(S, oracle, wx, monkeypatch):
 
 @pytest.mark.parametrize("mfma", ["1", "4", "0"])
 @pytest.mark.parametrize("shape", [(1, 32, 5, 960, 192), (2, 12, 6, 520, 150), (1, 6, 9, 260, 97), (2, 32, 3, 300, 64),
-                                   (1, 5, 2, 36, 7), (1, 8, 2, 16, 16), (1, 32, 2, 1300, 33), (1, 3, 4, 8, 1)])
+                                   (1, 5, 2, 36, 7), (1, 8, 2, 16, 16), (1, 32, 2, 1300, 33), (1, 3, 4, 8, 1),
+                                   (1, 16, 3, 1248, 256), (1, 8, 2, 400, 230)])
 def test_corr_volume_mfma_vs_valu_vs_oracle(S, oracle, shape, mfma, monkeypatch):
     """A1 and A1+A4 (volume stored and regressed in one pass) on the f32 matrix cores (C <= 32, D <= 192, W % 4 == 0;
     LDS skew sheet, persistent workgroups) and on the VALU kernels: both against the oracle -- every band-size class,
