@@ -1,5 +1,7 @@
 // Backward kernels for the cfg-2 chain: soft-argmin, correlation / group-wise volume,
 // local cost-volume lookup.  Same conventions as the forward kernels: fp32, NCHW, lanes along W.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -658,6 +660,14 @@ extern "C" int stereo_gwc_volume_bwd_f32(const float *left, const float *right, 
     STEREO_REQUIRE_PTR(right);
     if (D > 0) STEREO_REQUIRE_PTR(grad_vol);
     if (grad_left == nullptr && grad_right == nullptr) return STEREO_OK;
+    {
+        const char *e = getenv("STEREO_CORR_MFMA");  // dev/test knob: "0" forces the VALU kernels
+        if (G == 1 && D > 0 && !(e && e[0] == '0')) {
+            const int rc = stereo_corr_volume_bwd_mfma(left, right, grad_vol, grad_left, grad_right, B, C, H, W, D,
+                                                       as_stream(stream));
+            if (rc != STEREO_ERR_UNSUPPORTED) return rc;
+        }
+    }
     if (!fits_grid_yz(H) || !fits_grid_yz((long long)B * G) || D > 4096) return STEREO_ERR_UNSUPPORTED;
     const int CPG = C / G;
     const int Dpad = (D + BDC - 1) / BDC * BDC;

@@ -62,3 +62,6 @@ int stereo_gwc_mean_argmin_mfma(const float *L, const float *R, float *volg, flo
 // attention.hip: A1 + A4 without any volume (= cross-attention, mask 'zero', scale +-1/C, no output tensor).
 int stereo_corr_soft_argmin_mfma(const float *L, const float *R, float *disp, int B, int C, int H, int W, int D, float sgn,
                                  hipStream_t st);
+// corr_mfma_bwd.hip: backward of A1 (G = 1) on the f32 matrix cores; either output may be null.
+int stereo_corr_volume_bwd_mfma(const float *left, const float *right, const float *grad_vol, float *grad_left,
+                                float *grad_right, int B, int C, int H, int W, int D, hipStream_t st);

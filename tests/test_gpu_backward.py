@@ -293,3 +293,35 @@ def test_fused_volume_stage_backward_matches_composition(S):
     _, disp = S.build_gwc_volume_with_disparity(L, R0, D, G)
     (gl,) = torch.autograd.grad((disp * cd).sum(), [L])
     assert torch.isfinite(gl).all() and gl.abs().max().item() > 0
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 3, 960, 192), (2, 12, 4, 520, 150), (1, 6, 5, 260, 97), (2, 32, 2, 300, 64),
+                                   (1, 5, 2, 36, 7), (1, 8, 2, 16, 16), (1, 3, 2, 8, 1)])
+def test_corr_volume_backward_mfma_vs_valu_vs_torch(S, shape, monkeypatch):
+    """A1 backward on the matrix cores (gradient rows read along the sheet's diagonals; dR in mirrored / sheared
+    coordinates) against the VALU backward and against torch autograd of the shifted-product formula."""
+    B, C, H, W, D = shape
+    torch.manual_seed(21)
+    L0, R0 = torch.randn(B, C, H, W, device="cuda"), torch.randn(B, C, H, W, device="cuda")
+    cot = torch.randn(B, D, H, W, device="cuda")
+    got = {}
+    for mfma in ("1", "0"):
+        monkeypatch.setenv("STEREO_CORR_MFMA", mfma)
+        L, R = L0.clone().requires_grad_(True), R0.clone().requires_grad_(True)
+        vol = S.CostVolume(D)(L, R)
+        got[mfma] = torch.autograd.grad((vol * cot).sum(), [L, R])
+    Lr, Rr = L0.clone().requires_grad_(True), R0.clone().requires_grad_(True)
+    ref = torch.zeros(B, D, H, W, device="cuda")
+    planes = []
+    for d in range(D):
+        if d < W:
+            pl = torch.zeros(B, H, W, device="cuda")
+            pl = torch.cat([pl[..., :d], (Lr[..., d:] * Rr[..., :W - d]).mean(1)], -1) if d > 0 else (Lr * Rr).mean(1)
+        else:
+            pl = torch.zeros(B, H, W, device="cuda")
+        planes.append(pl)
+    ref = torch.stack(planes, 1)
+    gref = torch.autograd.grad((ref * cot).sum(), [Lr, Rr])
+    for k in ("1", "0"):
+        for a, b in zip(got[k], gref):
+            close(a, b.cpu().numpy(), rtol=1e-4, atol=5e-5)
