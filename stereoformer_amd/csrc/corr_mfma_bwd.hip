@@ -33,6 +33,8 @@ __device__ __forceinline__ f32x4 load_rev4(const float *__restrict__ row, int of
     if (hi >= 3 && hi < W) {
         const f32x4u t = *reinterpret_cast<const f32x4u *>(row + (hi - 3));
         v = (f32x4){t[3], t[2], t[1], t[0]};
+    } else if (hi - 3 >= W || hi < 0) {
+        // entirely outside the row (the sheared gradient's v + d >= W corner, or past the left edge): zeros, no loads
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

@@ -184,7 +184,7 @@ def main():
             add("bwd A1 corr volume cfg-2 (dL + dR)",
                 timeit(lambda: torch.autograd.grad(vol_g, (Lg, Rg), cot, retain_graph=True), 5, 1),
                 (2 * N * D * 4 + 4 * N * C * 4) / 1e9, 2 * 2 * B * H * C * (D * W - D * (D - 1) / 2) / 1e9,
-                note="reads grad volume twice (dL, dR)")
+                note="two launches (dL, dR), each reads the gradient volume once; f32 MFMA + LDS sheet")
             del vol_g, cot
             vd = S.CostVolume(D)(L, R).detach().requires_grad_(True)
             dsp = S.DisparityEstimation(D)(vd)
