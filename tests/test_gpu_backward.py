@@ -296,7 +296,7 @@ def test_fused_volume_stage_backward_matches_composition(S):
 
 
 @pytest.mark.parametrize("shape", [(1, 32, 3, 960, 192), (2, 12, 4, 520, 150), (1, 6, 5, 260, 97), (2, 32, 2, 300, 64),
-                                   (1, 5, 2, 36, 7), (1, 8, 2, 16, 16), (1, 3, 2, 8, 1)])
+                                   (1, 5, 2, 36, 7), (1, 8, 2, 16, 16), (1, 3, 2, 8, 1), (1, 8, 2, 64, 100)])
 def test_corr_volume_backward_mfma_vs_valu_vs_torch(S, shape, monkeypatch):
     """A1 backward on the matrix cores (gradient rows read along the sheet's diagonals; dR in mirrored / sheared
     coordinates) against the VALU backward and against torch autograd of the shifted-product formula."""

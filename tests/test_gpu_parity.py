@@ -108,7 +108,7 @@ def test_volume_whole_row_workgroup_shape(S, oracle, wx, monkeypatch):
 @pytest.mark.parametrize("mfma", ["1", "4", "0"])
 @pytest.mark.parametrize("shape", [(1, 32, 5, 960, 192), (2, 12, 6, 520, 150), (1, 6, 9, 260, 97), (2, 32, 3, 300, 64),
                                    (1, 5, 2, 36, 7), (1, 8, 2, 16, 16), (1, 32, 2, 1300, 33), (1, 3, 4, 8, 1),
-                                   (1, 16, 3, 1248, 256), (1, 8, 2, 400, 230)])
+                                   (1, 16, 3, 1248, 256), (1, 8, 2, 400, 230), (1, 8, 2, 64, 100), (3, 4, 1, 4, 3)])
 def test_corr_volume_mfma_vs_valu_vs_oracle(S, oracle, shape, mfma, monkeypatch):
     """A1 and A1+A4 (volume stored and regressed in one pass) on the f32 matrix cores (C <= 32, D <= 192, W % 4 == 0;
     LDS skew sheet, persistent workgroups) and on the VALU kernels: both against the oracle -- every band-size class,
@@ -133,7 +133,7 @@ def test_corr_volume_mfma_vs_valu_vs_oracle(S, oracle, shape, mfma, monkeypatch)
 
 @pytest.mark.parametrize("mode", ["fused", "groups_mfma_mean_separate", "valu"])
 @pytest.mark.parametrize("shape", [(1, 32, 5, 960, 192, 8), (2, 12, 6, 520, 150, 3), (1, 32, 3, 300, 64, 2), (1, 8, 4, 260, 97, 4),
-                                   (2, 16, 2, 36, 7, 1), (1, 24, 2, 1300, 40, 12)])
+                                   (2, 16, 2, 36, 7, 1), (1, 24, 2, 1300, 40, 12), (1, 8, 2, 64, 100, 2), (2, 32, 1, 8, 5, 16)])
 def test_gwc_volume_group_pass_mfma(S, oracle, shape, mode, monkeypatch):
     """A3 alone and A3 + group mean + A4 in ONE kernel (group pass on the matrix cores, channels per group in
     {2, 4, 8, 16}) against the oracle, next to the two-kernel and the VALU paths."""
