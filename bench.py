@@ -8,33 +8,77 @@ group-mean + soft-argmin + LocalCostVolume(r=2,S=20) refinement, batch 8 per GPU
 feature channels, fp32.  A "step" is one pass of that chain over one batch of 8 pairs with
 the features already resident in HBM; every intermediate the reference API materialises
 (the [8,8,192,540,960] group-wise volume, 25.5 GB, and the [8,192,540,960] mean volume) is
-materialised here too.  For N>1 (launched by torch.distributed.run, one rank per GPU) the
-pairs shard over ranks with no data-path collective ("weak" scaling: 8 pairs per GPU);
-RCCL carries only the barrier / max-over-ranks timing and one final gather of the disparity
-shards.
+materialised here too.
 
-The JSON line also carries `roofline` (the dominant kernel: the group-wise volume build,
-HBM-write bound) and `cpu_baseline` (the C oracle, OpenMP, on a bounded sample).
+N>1: the pairs shard over ranks with no data-path collective ("weak" scaling: 8 pairs per
+GPU); RCCL carries only the barrier / max-over-ranks timing and one final gather of the
+disparity shards.  `python bench.py --gpus N` from a bare shell starts its own N ranks
+(`torch.distributed.run`, one process per GPU) as a CHILD process before anything in this
+process touches the GPU, relays rank 0's JSON line and exits with the child's code; when
+WORLD_SIZE is already set (the launcher started us) it runs as one rank.
+
+The JSON line carries `roofline` (the dominant kernel: the fused volume stage, HBM-write
+bound; every per-step HIP-event time of it is kept), `cpu_baseline` (the C oracle, OpenMP,
+on a bounded sample) and `other_configs` (BASELINE configs[2..4], compact, sharded the same way).
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
-
 B_PER_GPU, C, H, W, D, G = 8, 32, 540, 960, 192, 8
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the compact cfg-3/4/5 entries (headline line only)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="run the N-rank code path with every rank on cuda:0 over gloo (1-GPU boxes; timings are "
+                         "NOT a valid measurement -- the ranks share one GPU; N <= 6)")
+    ap.add_argument("--rehearse-on-cpu", action="store_true",
+                    help="launcher / sharding / reduction plumbing only, over gloo, no GPU work at all (CPU tests)")
+    ap.add_argument("--reread", action="store_true",
+                    help="group-mean + soft-argmin by re-reading the 25.5 GB volume (the pre-fusion chain)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks as a child `torch.distributed.run` (never an exec,
+    and before this process has made any GPU call), relay its output, return its exit code."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:          # rank 0 prints the one JSON line; relay everything as it comes
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def synth_pairs(batch, seed, device):
     """L = randn L2-normalised over C, scaled by 0.5*sqrt(C); R = L shifted by a
     smooth disparity field in [0, 0.8 D] + 0.05 noise."""
+    import torch
+
     g = torch.Generator(device=device).manual_seed(seed)
     L = torch.randn(batch, C, H, W, device=device, generator=g)
     L = L / L.norm(dim=1, keepdim=True).clamp_min(1e-6) * (0.5 * C ** 0.5)
@@ -59,14 +103,25 @@ def usable_cpus():
     return n
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(seed):
-    """The C oracle (a port, OpenMP) on ONE pair of the same workload, same chain."""
+    """The C oracle (a port, OpenMP) on ONE pair of the same workload, same chain: at every usable core (the reported
+    `value`) and at 8 threads (to sit beside BASELINE.md's 8-thread figure of the real reference, 0.17 pairs/s)."""
     import numpy as np
+    import torch
 
     import oracle
 
     cores = usable_cpus()
-    os.environ["OMP_NUM_THREADS"] = str(cores)
     path = None
     try:  # -march=native build on this host; falls back to the portable library
         path = oracle.build(force=True, native=True, out=os.path.join("/tmp", f"libstereo_oracle_native_{os.getpid()}.so"))
@@ -75,19 +130,28 @@ def cpu_baseline(seed):
         lib = oracle.load()
     Lt, Rt = synth_pairs(1, seed, "cpu")
     L, R = Lt.numpy(), Rt.numpy()
-    times = []
     refined = None
-    t_all = time.perf_counter()
-    for _ in range(3):
-        t0 = time.perf_counter()
-        volg = oracle.gwc_volume(L, R, D, G, lib=lib)
-        mean = oracle.group_mean(volg, lib=lib)
-        disp = oracle.soft_argmin(mean, lib=lib)
-        refined = oracle.local_lookup(mean, disp[:, None], 2.0, 20, True, lib=lib)
-        times.append(time.perf_counter() - t0)
-        del volg, mean
-        if time.perf_counter() - t_all > 25:
-            break
+
+    def chain_seconds(threads, budget_s, runs):
+        nonlocal refined
+        oracle.set_threads(threads, lib=lib)
+        times = []
+        t_all = time.perf_counter()
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            volg = oracle.gwc_volume(L, R, D, G, lib=lib)
+            mean = oracle.group_mean(volg, lib=lib)
+            disp = oracle.soft_argmin(mean, lib=lib)
+            refined = oracle.local_lookup(mean, disp[:, None], 2.0, 20, True, lib=lib)
+            times.append(time.perf_counter() - t0)
+            del volg, mean
+            if time.perf_counter() - t_all > budget_s:
+                break
+        return times
+
+    times = chain_seconds(cores, 15, 3)
+    times8 = chain_seconds(min(8, cores), 8, 2) if cores != 8 else times
+    oracle.set_threads(cores, lib=lib)
     if path and os.path.exists(path):
         os.remove(path)
     best = min(times)
@@ -101,38 +165,72 @@ def cpu_baseline(seed):
     return {"value": round(1.0 / best, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
             "sample": f"1 pair 960x540 D=192 G=8 (gwc -> group-mean -> soft-argmin -> local lookup), "
                       f"best of {len(times)} runs, C oracle with OpenMP",
-            "ms_per_pair": round(best * 1e3, 1),
+            "ms_per_pair": round(best * 1e3, 1), "cpu_model": cpu_model(),
+            "at_8_threads": {"value": round(1.0 / min(times8), 4), "ms_per_pair": round(min(times8) * 1e3, 1),
+                             "threads": min(8, cores),
+                             "beside": "BASELINE.md section 2: the real reference (PyTorch CPU, 8 threads, build container) "
+                                       "runs this chain at ~0.17 pairs/s"},
             "gpu_vs_oracle_disparity": {"max_abs": float(err.max()), "mean_abs": float(err.mean()), "bar": 1e-3}}
 
 
+def spread(ms):
+    """Every per-step HIP-event time of one launch, summarised so a single run shows ramp vs steady state."""
+    n = len(ms)
+    k = min(5, n)
+    return {"min": round(min(ms), 4), "median": round(statistics.median(ms), 4), "max": round(max(ms), 4),
+            "mean": round(sum(ms) / n, 4), "first5_mean": round(sum(ms[:k]) / k, 4),
+            "last5_mean": round(sum(ms[-k:]) / k, 4), "per_step": [round(x, 3) for x in ms]}
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="run the N-rank code path with every rank on cuda:0 over gloo (1-GPU boxes; timings are "
-                         "NOT a valid measurement -- the ranks share one GPU)")
-    ap.add_argument("--reread", action="store_true",
-                    help="group-mean + soft-argmin by re-reading the 25.5 GB volume (the pre-fusion chain)")
-    args = ap.parse_args()
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args, argv))
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with nproc-per-node {args.gpus} "
-                         f"(WORLD_SIZE={world})")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+
+    if args.rehearse_on_cpu:
+        # plumbing only: launcher -> ranks -> sharding -> max-over-ranks -> gather -> rank 0's line.  No GPU, no kernels.
+        from stereoformer_amd import shard
+        if world > 1:
+            dist.init_process_group("gloo")
+        sl = shard.pair_slice(world * B_PER_GPU, rank, world)
+        local = torch.arange(sl.start, sl.stop, dtype=torch.float32).view(-1, 1)
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (rank + 1))
+        elapsed = time.perf_counter() - t0
+        per_rank = shard.all_ranks(elapsed)
+        elapsed_max = shard.max_over_ranks(elapsed)
+        gathered = shard.gather_pairs(local, world * B_PER_GPU)
+        if rank == 0:
+            print(json.dumps({"metric": "plumbing rehearsal (no GPU work)", "value": None, "unit": "pairs/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "data": "REHEARSAL on CPU over gloo: launcher and sharding plumbing only; not a measurement",
+                              "per_rank_ms": [round(x * 1e3, 3) for x in per_rank],
+                              "max_rank_ms": round(elapsed_max * 1e3, 3),
+                              "pairs_gathered": int(gathered.shape[0]),
+                              "checksum": float(gathered.sum().item())}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 and args.rehearse_on_one_gpu:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
     elif world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
     import stereoformer_amd as S
@@ -144,6 +242,7 @@ def main():
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     ev_read = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev_look = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
         with torch.no_grad():
@@ -165,7 +264,12 @@ def main():
                 volg, disp, mean = S.build_gwc_volume_with_disparity(L, R, D, G, return_mean=True)
                 if i is not None:
                     ev[i][1].record()
-            return lookup(mean, disp.unsqueeze(1), True)
+            if i is not None:
+                ev_look[i][0].record()
+            out = lookup(mean, disp.unsqueeze(1), True)
+            if i is not None:
+                ev_look[i][1].record()
+            return out
 
     def sync_all():
         if world > 1:
@@ -179,19 +283,24 @@ def main():
     for i in range(args.steps):
         out = step(i)
     sync_all()
-    elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(elapsed, device=device)
+    elapsed_local = time.perf_counter() - t0
+    per_rank = shard.all_ranks(elapsed_local, device=device)
+    elapsed = shard.max_over_ranks(elapsed_local, device=device)
 
-    build_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    build_steps = [a.elapsed_time(b) for a, b in ev]
+    build_ms = sum(build_steps) / args.steps
     read_ms = sum(a.elapsed_time(b) for a, b in ev_read) / args.steps if args.reread else None
+    look_steps = [a.elapsed_time(b) for a, b in ev_look]
 
     # one RCCL gather of the disparity shards (the only data collective; outside the timed region)
     gathered = shard.gather_pairs(out, world * B_PER_GPU)
     assert gathered.shape[0] == world * B_PER_GPU
     checksum = float(gathered.double().sum().item())
+    del gathered
 
     # secondary, untimed-in-`value` numbers: the fused no-materialisation path
     fused_ms = None
+    other = {}
     if rank == 0:
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -202,7 +311,6 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         fused_ms = e0.elapsed_time(e1) / 5
-        other = {}
         with torch.no_grad():
             def t5(fn):
                 fn()
@@ -224,17 +332,24 @@ def main():
                 volg = S.build_gwc_volume(L, R, D, G)
                 other["group_mean_soft_argmin_reread"] = t5(lambda: S.group_mean_soft_argmin(volg, return_mean=True))
                 del volg
+    del out
+    res = None
     if rank == 0:
         n_pix = B_PER_GPU * H * W
         gwc_bytes = 2 * n_pix * C * 4 + n_pix * G * D * 4  # A3 = 26.54 GB
         if not args.reread:
             gwc_bytes += n_pix * D * 4 + n_pix * 4         # + mean volume (8(d): A1's N*D*4) + disparity = 29.74 GB
-        traffic = None  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
+        traffic, traffic_source = None, None  # HBM bytes per launch: NOT observed in this run -- read from the committed PMC passes
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
-            pref = "gwc_volume_pipe_kernel<16, 12, 0" if os.environ.get("STEREO_CORR_MFMA") == "0" else "corr_volume_mfma_kernel"
-            cands = [v for k, v in pmc["kernels"].items() if k.startswith(pref) and v.get("hbm_write_bytes", 0) > 2e10]
-            traffic = cands[0]["hbm_bytes_per_launch"] if cands else None
+            pmc_path = os.path.join("profiles", "pmc_traffic_latest.json")
+            pmc = json.load(open(os.path.join(ROOT, pmc_path)))
+            pref = "corr_volume_mfma_kernel"
+            cands = [v for k, v in pmc["kernels"].items() if k.startswith(pref) and v.get("hbm_write_bytes", 0) > 2e10
+                     and (("true" in k.split(",")[1]) != bool(args.reread))]
+            if cands:
+                traffic = cands[0]["hbm_bytes_per_launch"]
+                traffic_source = (f"{pmc_path} (builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, "
+                                  "FETCH_SIZE x2 per the gfx950 guide; NOT collected in this run)")
         except Exception:
             pass
         achieved = gwc_bytes / (build_ms * 1e-3) / 1e9
@@ -248,6 +363,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "ms_per_pair": round(elapsed / args.steps * 1e3 / B_PER_GPU, 4),
+            "per_rank_ms_per_step": [round(x / args.steps * 1e3, 3) for x in per_rank],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -258,23 +374,42 @@ def main():
                                    + (" (group mean by re-reading the volume)" if args.reread else
                                       " (volume stage in one kernel: group mean + disparity from the feature tiles, identity I1; the volume is written "
                                       "once and never read back)"),
-                       "pairs_per_gpu": B_PER_GPU, "parallelism": f"pairs sharded over {world} GPU(s), no data collective"},
+                       "pairs_per_gpu": B_PER_GPU, "total_pairs_per_step": world * B_PER_GPU,
+                       "parallelism": f"pairs sharded over {world} GPU(s), no data collective"},
             "roofline": {"bound": "hbm",
                          "kernel": ("gwc volume kernel (A3 group-wise volume build)" if args.reread else
                                     "corr_volume_mfma_kernel<7,ARGMIN,8,3,CPG2=2> (A3 group-wise volume + group mean + A4 "
                                     "soft-argmin in one launch)"), "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "algorithmic_bytes": gwc_bytes, "avg_launch_ms": round(build_ms, 4)},
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "algorithmic_bytes": gwc_bytes, "avg_launch_ms": round(build_ms, 4),
+                         "launch_ms": spread(build_steps),
+                         "frac_at_min_launch": round(gwc_bytes / (min(build_steps) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "frac_at_max_launch": round(gwc_bytes / (max(build_steps) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels_ms": dict({("gwc_build" if args.reread else "volume_stage_fused"): round(build_ms, 4),
+                                "local_lookup": round(sum(look_steps) / len(look_steps), 4),
                                 "fused_corr_soft_argmin_no_volume": None if fused_ms is None else round(fused_ms, 4)},
                                **({"group_mean_soft_argmin_reread": round(read_ms, 4)} if args.reread else {}), **other),
             "checksum": checksum,
         }
+    del L, R
+    torch.cuda.empty_cache()
+
+    others = None
+    if not args.no_other_configs and not args.reread:
+        from tools import bench_configs
+        others = bench_configs.run_all(device, rank, world, cpu=(world == 1 and not args.no_cpu_baseline),
+                                       rehearsal=args.rehearse_on_one_gpu)
+    if rank == 0:
+        res["other_configs"] = others
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(1234)
+            try:
+                res["cpu_baseline"] = cpu_baseline(1234)
+            except Exception as e:  # the headline line must still come out
+                res["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

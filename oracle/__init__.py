@@ -55,6 +55,11 @@ def load(path: str | None = None):
     return lib
 
 
+def set_threads(n: int, lib=None) -> None:
+    """OpenMP thread count for the following oracle calls (cpu_baseline reports the count it used)."""
+    (lib or load()).oracle_set_threads(_i(int(n)))
+
+
 def _c(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 

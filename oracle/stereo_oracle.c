@@ -23,6 +23,20 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* bench.py's cpu_baseline leg times the oracle at a stated thread count. */
+void oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 #define I4(b, c, h, w, C, H, W) \
     ((((size_t)(b) * (size_t)(C) + (size_t)(c)) * (size_t)(H) + (size_t)(h)) * (size_t)(W) + (size_t)(w))
 

@@ -61,3 +61,14 @@ def sum_over_ranks(value: float, device=None, group=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=None if dist.get_backend(group) == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return float(t.item())
+
+
+def all_ranks(value: float, device=None, group=None) -> list[float]:
+    """Every rank's scalar, in rank order, on every rank (per-rank step times beside the max)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    world = dist.get_world_size(group)
+    t = torch.zeros(world, dtype=torch.float64, device=None if dist.get_backend(group) == "gloo" else device)
+    t[dist.get_rank(group)] = value
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return [float(x) for x in t.tolist()]

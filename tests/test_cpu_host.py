@@ -128,3 +128,26 @@ def test_two_rank_sharding_over_gloo(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` from a bare shell (no launcher, WORLD_SIZE unset): the parent starts the two ranks as a
+    child process before touching any GPU, relays rank 0's JSON line and returns the child's exit code.  On CPU the ranks
+    run the plumbing only (gloo): launcher, pair sharding, per-rank times, max over ranks, gather."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-cpu"], env=env,
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["pairs_gathered"] == 16 and d["checksum"] == float(sum(range(16)))
+    assert len(d["per_rank_ms"]) == 2 and d["max_rank_ms"] == max(d["per_rank_ms"])
+    assert d["per_rank_ms"][1] > d["per_rank_ms"][0]          # rank r sleeps (r+1) x 10 ms: the max is rank 1's
+    # a mismatching launcher is refused with a non-zero exit code that the parent passes on
+    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-cpu"], env=env2,
+                        capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r2.returncode != 0

@@ -1,40 +1,58 @@
 #!/usr/bin/env python3
-"""Whole-chain pairs/s for the BASELINE.json configs that are NOT the headline line of bench.py (configs[2..4]), one JSON
-line each, same fields as bench.py (N=1, synthetic inputs of the config's shapes, random-init weights, fp32):
+"""Whole-chain pairs/s for the BASELINE.json configs that are NOT the headline line of bench.py (configs[2..4]).
 
-  cfg-3  SceneFlow 960x540 D=192  CrossAttentionCostVolume (epipolar cross-attention + regression), batch 8
-  cfg-4  SceneFlow 960x540 D=192  IterativeLocalCostVolume loop, 16 iterations, batch 8 per GPU (RAFT-style update
-         operator at 1/4 resolution; and the LowCNN GRU updater at 1/8 resolution)
+  cfg-3  SceneFlow 960x540 D=192  CrossAttentionCostVolume (epipolar cross-attention + regression), batch 8 per GPU
+  cfg-4  SceneFlow 960x540 D=192  IterativeLocalCostVolume loop, 16 iterations, batch 8 per GPU -> 64 pairs over 8 GPUs
+         (RAFT-style update operator at 1/4 resolution; and the LowCNN GRU updater at 1/8 resolution)
   cfg-5  KITTI 1242x375 -> 1248x384, D=256: cross-attention at 1/4 resolution (band 64) initialising the 16-iteration
-         loop, batch 4 per GPU
+         loop, batch 4 per GPU -> 32 pairs over 8 GPUs
 
-The feature extractors are out of scope: the chains start from the tensors the extractors hand over.
+`bench.py` calls `run_all()` after its headline workload and attaches the compact entries as `other_configs`; with N ranks
+every rank runs its own shard of pairs (no data-path collective) and the time is the slowest rank's, exactly as for the
+headline.  The feature extractors are out of scope: the chains start from the tensors the extractors hand over.
 `roofline` describes the dominant HAND-WRITTEN kernel of the chain, timed alone with HIP events; the loops themselves are
-bounded by MIOpen's fp32 convolutions.   python tools/bench_configs.py [--steps K] > profiles/rNN_bench_configs.jsonl"""
+bounded by MIOpen's fp32 convolutions.  `cpu_baseline` (rank 0, N=1): the C oracle, plus torch-CPU convolutions for the
+update blocks, on a bounded sample scaled to one pair.
+
+    python tools/bench_configs.py [--steps K] [--only cfg3|cfg4|cfg5] > profiles/rNN_bench_configs.jsonl
+"""
 import argparse
+import contextlib
 import json
 import os
 import sys
 import time
 
 import torch
+import torch.distributed as dist
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import stereoformer_amd as S  # noqa: E402
+from stereoformer_amd import shard  # noqa: E402
 
 MFMA_F32_PEAK = 157.3  # TFLOP/s dense f32 MFMA (MI355X_MICROARCH.md)
 
 
-def timed(fn, steps, warmup=2):
+def _sync(world):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def timed(fn, steps, warmup, world, device):
+    """barrier + synchronize on both sides of exactly `steps` calls; returns (slowest rank's seconds per step, every
+    rank's ms per step)."""
     with torch.no_grad():
         for _ in range(warmup):
             fn()
-        torch.cuda.synchronize()
+        _sync(world)
         t0 = time.perf_counter()
         for _ in range(steps):
             fn()
-        torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps
+        _sync(world)
+    sec = (time.perf_counter() - t0) / steps
+    per_rank = shard.all_ranks(sec, device=device)
+    return shard.max_over_ranks(sec, device=device), [round(x * 1e3, 3) for x in per_rank]
 
 
 def event_ms(fn, reps=5):
@@ -49,21 +67,22 @@ def event_ms(fn, reps=5):
     return e0.elapsed_time(e1) / reps
 
 
-def line(workload, pairs, sec, steps, roofline, extra=None):
-    out = {"metric": "stereo pairs/s", "value": round(pairs / sec, 2), "unit": "pairs/s", "n_gpus": 1, "steps": steps,
-           "warmup": 2, "ms_per_step": round(sec * 1e3, 3), "ms_per_pair": round(sec * 1e3 / pairs, 4),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": workload, "pairs_per_gpu": pairs}, "roofline": roofline, "cpu_baseline": None}
+def entry(name, workload, pairs_per_gpu, world, sec, per_rank, steps, warmup, roofline, cpu=None, extra=None):
+    out = {"config": name, "workload": workload, "value": round(pairs_per_gpu * world / sec, 2), "unit": "pairs/s",
+           "n_gpus": world, "pairs_per_gpu": pairs_per_gpu, "total_pairs_per_step": pairs_per_gpu * world,
+           "steps": steps, "warmup": warmup, "ms_per_step": round(sec * 1e3, 3), "per_rank_ms_per_step": per_rank,
+           "scaling": "weak", "dtype": "f32", "data": "synthetic", "roofline": roofline, "cpu_baseline": cpu}
     if extra:
         out.update(extra)
-    print(json.dumps(out), flush=True)
+    return out
 
 
-def raft_inputs(B, Hq, Wq, dev):
-    f1 = torch.randn(B, 256, Hq, Wq, device=dev)
-    f2 = torch.randn(B, 256, Hq, Wq, device=dev)
-    nets = [torch.tanh(torch.randn(B, 128, Hq >> i, Wq >> i, device=dev)) for i in range(3)]
-    inps = [[torch.randn(B, 128, Hq >> i, Wq >> i, device=dev) for _ in range(3)] for i in range(3)]
+def raft_inputs(B, Hq, Wq, dev, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+    f1, f2 = rn(B, 256, Hq, Wq), rn(B, 256, Hq, Wq)
+    nets = [torch.tanh(rn(B, 128, Hq >> i, Wq >> i)) for i in range(3)]
+    inps = [[rn(B, 128, Hq >> i, Wq >> i) for _ in range(3)] for i in range(3)]
     return f1, f2, nets, inps
 
 
@@ -76,82 +95,290 @@ def allpairs_roofline(f1, f2):
             "traffic": None, "avg_launch_ms": round(ms, 4)}
 
 
+# ----------------------------------------------------------------------------------------------------------- CPU legs
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@contextlib.contextmanager
+def _cpu_ops():
+    """BASELINE LEG ONLY: run the host modules (update blocks) on the CPU by routing their custom ops to the C oracle
+    (numpy) -- convolutions / pooling stay torch-CPU.  Never active on the measured GPU path."""
+    import oracle
+    from stereoformer_amd import update_dlc, update_raft
+
+    t = torch.from_numpy
+
+    def gru_reset(h, rc, cr=None):
+        return t(oracle.gru_reset(_np(h), _np(rc), None if cr is None else _np(cr)))
+
+    def gru_blend(h, zc, qc, cz=None, cq=None, softsign=False):
+        return t(oracle.gru_blend(_np(h), _np(zc), _np(qc), None if cz is None else _np(cz),
+                                  None if cq is None else _np(cq), softsign))
+
+    def resize(x, size, align_corners, scale=1.0):
+        return t(oracle.resize_bilinear(_np(x), (int(size[0]), int(size[1])), bool(align_corners))) * scale
+
+    def interp(x, dest):
+        return resize(x, dest.shape[2:], True)
+
+    def disp_warp(img, disp, padding_mode="border", check_positive=False):
+        w, m = oracle.disp_warp(_np(img), _np(disp), padding_mode)
+        return t(w), t(m)
+
+    def uncertainty_volume(vol, disp):
+        return t(oracle.uncertainty_volume(_np(vol), _np(disp)))
+
+    def bounds_lookup(vol, disp, bounds, S_, consider_valid=True):
+        b = _np(bounds)
+        return t(oracle.bounds_lookup(_np(vol), _np(disp), b[:, :1], b[:, 1:], S_, consider_valid))
+
+    patches = [(update_raft, "gru_reset", gru_reset), (update_raft, "gru_blend", gru_blend), (update_raft, "interp", interp),
+               (update_dlc, "gru_reset", gru_reset), (update_dlc, "gru_blend", gru_blend),
+               (update_dlc, "resize_bilinear", resize), (update_dlc, "disp_warp", disp_warp),
+               (update_dlc, "uncertainty_volume", uncertainty_volume), (update_dlc, "bounds_lookup", bounds_lookup)]
+    saved = [(m, n, getattr(m, n)) for m, n, _ in patches]
+    try:
+        for m, n, f in patches:
+            setattr(m, n, f)
+        yield oracle
+    finally:
+        for m, n, f in saved:
+            setattr(m, n, f)
+
+
+def _cores():
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_cross_attention(C, H, W, D, mask, scale, rows):
+    """oracle cross-attention on `rows` rows of ONE pair, scaled to the H rows of a pair (rows are independent)."""
+    import numpy as np
+    import oracle
+    rng = np.random.default_rng(0)
+    L = rng.standard_normal((1, C, rows, W), dtype=np.float32)
+    R = rng.standard_normal((1, C, rows, W), dtype=np.float32)
+    oracle.cross_attention(L[:, :, :2], R[:, :, :2], None, D, mask, scale)
+    t0 = time.perf_counter()
+    oracle.cross_attention(L, R, None, D, mask, scale)
+    return (time.perf_counter() - t0) * H / rows
+
+
+def cpu_raft_loop(Hq, Wq, iters, measured_iters=2, flow_init=None):
+    """ONE pair: oracle all-pairs + pyramid, then `measured_iters` iterations of (oracle lookup + update block with torch-CPU
+    convolutions and oracle gate math), scaled to `iters` iterations; + the convex upsampling once."""
+    import numpy as np
+    torch.manual_seed(0)
+    f1, f2, nets, inps = raft_inputs(1, Hq, Wq, "cpu", 0)
+    with _cpu_ops() as oracle, torch.no_grad():
+        block = S.BasicMultiUpdateBlock_LZH(4, 4, 3, 2, [128, 128, 128]).eval()
+        t0 = time.perf_counter()
+        pyr = oracle.corr_pyramid(oracle.allpairs_corr(_np(f1), _np(f2)), 4)
+        t_corr = time.perf_counter() - t0
+        coords0 = np.stack(np.meshgrid(np.arange(Wq, dtype=np.float32), np.arange(Hq, dtype=np.float32)), 0)[None]
+        coords1 = coords0.copy() if flow_init is None else coords0 + flow_init
+        mask = None
+        t0 = time.perf_counter()
+        for _ in range(measured_iters):
+            corr = torch.from_numpy(oracle.corr_lookup(pyr, coords1, 4, 4))
+            flow = torch.from_numpy(coords1 - coords0)
+            nets, mask, delta = block(nets, inps, corr, flow)
+            d = _np(delta).copy()
+            d[:, 1] = 0
+            coords1 = coords1 + d
+        t_iter = (time.perf_counter() - t0) / measured_iters
+        t0 = time.perf_counter()
+        oracle.upsample_convex(coords1 - coords0, _np(mask), 4)
+        t_up = time.perf_counter() - t0
+    return t_corr + iters * t_iter + t_up, {"allpairs_pyramid_s": round(t_corr, 3), "per_iteration_s": round(t_iter, 3),
+                                            "upsample_s": round(t_up, 4)}
+
+
+def cpu_lowcnn_loop(iters, measured_iters=2):
+    torch.manual_seed(0)
+    vol = torch.randn(1, 24, 72, 120)
+    disp = torch.rand(1, 1, 72, 120) * 20
+    li, ri = torch.randn(1, 3, 576, 960), torch.randn(1, 3, 576, 960)
+    with _cpu_ops() as oracle, torch.no_grad():
+        upd = S.DisparityUpdateDLCWithMask(24, 32, 20).eval()
+        hidden = torch.zeros(1, 64, 72, 120)
+        t0 = time.perf_counter()
+        for _ in range(measured_iters):
+            disp, hidden, mask = upd(vol, disp, li, ri, hidden, True)
+        t_iter = (time.perf_counter() - t0) / measured_iters
+        t0 = time.perf_counter()
+        oracle.upsample_convex(_np(disp), _np(mask), 8)
+        t_up = time.perf_counter() - t0
+    return iters * t_iter + t_up, {"per_iteration_s": round(t_iter, 3), "upsample_s": round(t_up, 4)}
+
+
+def _cpu_entry(seconds_per_pair, sample, detail=None):
+    e = {"value": round(1.0 / seconds_per_pair, 4), "unit": "pairs/s", "cores": _cores(), "kind": "port",
+         "sample": sample, "ms_per_pair": round(seconds_per_pair * 1e3, 1)}
+    if detail:
+        e["detail"] = detail
+    return e
+
+
+def _guard(fn):
+    try:
+        return fn()
+    except Exception as e:  # a baseline leg must never take the measured entries down with it
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+# ----------------------------------------------------------------------------------------------------------- configs
+def cfg3(dev, rank, world, steps, warmup, cpu):
+    B, C, H, W, D = 8, 32, 540, 960, 192
+    g = torch.Generator(device=dev).manual_seed(300 + rank)
+    L = torch.randn(B, C, H, W, device=dev, generator=g)
+    R = torch.randn(B, C, H, W, device=dev, generator=g)
+    att = S.CrossAttentionCostVolume(D, "zero", "sqrt_c")
+    sec, per_rank = timed(lambda: att(L, R), steps, warmup, world, dev)
+    roof = None
+    if rank == 0:
+        ms = event_ms(lambda: att(L, R))
+        band = D * W - D * (D - 1) / 2
+        flops = 2 * 2 * B * H * C * band
+        tf = flops / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "cross_attention_online_kernel<7,8> (A7)", "achieved": round(tf, 2),
+                "peak": MFMA_F32_PEAK, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK, 4), "traffic": None,
+                "avg_launch_ms": round(ms, 4), "algorithmic_flops": flops}
+    del L, R
+    cb = None
+    if cpu and rank == 0:
+        cb = _guard(lambda: _cpu_entry(cpu_cross_attention(C, H, W, D, "zero", "sqrt_c", 90),
+                                       "90 of the 540 rows of 1 pair (rows are independent), scaled x6; C oracle, OpenMP"))
+    return entry("cfg-3", "SceneFlow 960x540 D=192 CrossAttentionCostVolume (QK^T / softmax / PV on f32 MFMA) + disparity "
+                 "regression, batch=8 per GPU", B, world, sec, per_rank, steps, warmup, roof, cb)
+
+
+def cfg4(dev, rank, world, steps, warmup, cpu, mixed=False):
+    B, Hq, Wq = 8, 136, 240  # 544x960 / 4
+    f1, f2, nets, inps = raft_inputs(B, Hq, Wq, dev, 400 + rank)
+    roof = allpairs_roofline(f1, f2) if rank == 0 else None
+    torch.manual_seed(4)
+    out = []
+    for mp in ((False, True) if mixed else (False,)):
+        loop = S.RAFTStereoLoop([128, 128, 128], mixed_precision=mp, channels_last=True).eval().to(dev)
+        fn = lambda: loop(f1, f2, [n.clone() for n in nets], inps, iters=16, test_mode=True, use_graph=True)
+        sec, per_rank = timed(fn, steps, warmup, world, dev)
+        cb = None
+        if cpu and rank == 0 and not mp:
+            def leg():
+                s, d = cpu_raft_loop(Hq, Wq, 16)
+                return _cpu_entry(s, "1 pair: all-pairs + pyramid once, 2 measured iterations scaled to 16, upsampling once; C oracle "
+                                     "+ torch-CPU convolutions", d)
+            cb = _guard(leg)
+        out.append(entry("cfg-4" + (" (fp16 autocast convs)" if mp else ""),
+                         "SceneFlow 960x540 (padded 544) IterativeLocalCostVolume loop (RAFT-style update operator at 1/4 "
+                         "resolution, NHWC through the update block): all-pairs pyramid + 16 x (lookup + update block + coords) + "
+                         "convex upsampling, batch=8 per GPU (64 pairs over 8 GPUs)"
+                         + (", update-block convolutions under fp16 autocast (the reference's mixed_precision flag; NOT the "
+                            "parity configuration)" if mp else ", fp32"), B, world, sec, per_rank, steps, warmup, roof, cb,
+                         {"bounded_by": "MIOpen convolutions of the update block (1.2 TFLOP per iteration for 8 pairs)",
+                          "dtype": "f32 (+ f16 convs)" if mp else "f32"}))
+        del loop
+    del f1, f2, nets, inps
+    g = torch.Generator(device=dev).manual_seed(450 + rank)
+    vol = torch.randn(B, 24, 72, 120, device=dev, generator=g)
+    disp = torch.rand(B, 1, 72, 120, device=dev, generator=g) * 20
+    li = torch.randn(B, 3, 576, 960, device=dev, generator=g)
+    ri = torch.randn(B, 3, 576, 960, device=dev, generator=g)
+    lp = S.LowCNNGRULoop(24, 32, 20).eval().to(dev)
+    n = max(steps, 10)
+    sec, per_rank = timed(lambda: lp(vol, disp, li, ri, iters=16, use_graph=True), n, warmup, world, dev)
+    roof2 = None
+    if rank == 0:
+        bnd = torch.rand(B, 2, 72, 120, device=dev) * 3
+        ms = event_ms(lambda: S.bounds_lookup(vol, disp, bnd, 20, True))
+        roof2 = {"bound": "hbm", "kernel": "lookup_kernel<BOUNDS> (A11 sampler; latency-scale at this size)", "achieved": None,
+                 "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None, "avg_launch_ms": round(ms, 4)}
+    cb = None
+    if cpu and rank == 0:
+        def leg2():
+            s, d = cpu_lowcnn_loop(16)
+            return _cpu_entry(s, "1 pair: 2 measured iterations scaled to 16, upsampling once; C oracle + torch-CPU convolutions", d)
+        cb = _guard(leg2)
+    out.append(entry("cfg-4 (LowCNN GRU updater)", "16 x DisparityUpdateDLCWithMask (baseline_dynamic_gru) at 1/8 resolution "
+                     "[8,24,72,120] + convex upsampling x8 of the last iterate, batch=8 per GPU, fp32", B, world, sec, per_rank, n,
+                     warmup, roof2, cb, {"bounded_by": "MIOpen convolutions (Winograd / GEMM) of the updater"}))
+    return out
+
+
+def cfg5(dev, rank, world, steps, warmup, cpu):
+    B, Hq, Wq, Dq = 4, 96, 312, 64  # 384x1248 / 4, D = 256 / 4
+    f1, f2, nets, inps = raft_inputs(B, Hq, Wq, dev, 500 + rank)
+    att = S.CrossAttentionCostVolume(Dq, "neginf", "sqrt_c")
+    torch.manual_seed(5)
+    loop = S.RAFTStereoLoop([128, 128, 128], channels_last=True).eval().to(dev)
+
+    def chain():
+        _, d = att(f1, f2, need_out=False)
+        init = torch.cat([-d.unsqueeze(1), torch.zeros_like(d.unsqueeze(1))], 1)  # raft_stereo.py:163-164
+        return loop(f1, f2, [n.clone() for n in nets], inps, iters=16, flow_init=init, test_mode=True, use_graph=True)
+
+    sec, per_rank = timed(chain, steps, warmup, world, dev)
+    roof = None
+    if rank == 0:
+        ms = event_ms(lambda: att(f1, f2, need_out=False))
+        band = Dq * Wq - Dq * (Dq - 1) / 2
+        tf = 2 * B * Hq * 256 * band / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "cross-attention kernel at C=256 (A7, disparity only: QK^T half)",
+                "achieved": round(tf, 2), "peak": MFMA_F32_PEAK, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK, 4),
+                "traffic": None, "avg_launch_ms": round(ms, 4)}
+    cb = None
+    if cpu and rank == 0:
+        def leg():
+            a = cpu_cross_attention(256, Hq, Wq, Dq, "neginf", "sqrt_c", 24)
+            s, d = cpu_raft_loop(Hq, Wq, 16)
+            d["cross_attention_s"] = round(a, 3)
+            return _cpu_entry(a + s, "1 pair: cross-attention on 24 of 96 rows scaled x4 + all-pairs once + 2 measured loop iterations "
+                                     "scaled to 16; C oracle + torch-CPU convolutions", d)
+        cb = _guard(leg)
+    return entry("cfg-5", "KITTI 1242x375 (padded 1248x384) D=256: cross-attention at 1/4 resolution [4,256,96,312] (band 64) "
+                 "-> initial disparity -> 16-iteration IterativeLocalCostVolume loop, batch=4 per GPU (32 pairs over 8 GPUs), fp32",
+                 B, world, sec, per_rank, steps, warmup, roof, cb, {"bounded_by": "MIOpen convolutions of the update block"})
+
+
+def run_all(dev, rank=0, world=1, cpu=False, rehearsal=False, steps=3, warmup=2, only=None, mixed=False):
+    """Compact entries for cfg-3/4/5.  A failing config is reported in place, it never raises into the headline line."""
+    want = lambda n: only is None or only in n
+    out = []
+    for name, fn in (("cfg3", lambda: [cfg3(dev, rank, world, max(steps, 10), warmup, cpu)]),
+                     ("cfg4", lambda: cfg4(dev, rank, world, steps, warmup, cpu, mixed)),
+                     ("cfg5", lambda: [cfg5(dev, rank, world, steps, warmup, cpu)])):
+        if not want(name):
+            continue
+        try:
+            res = fn()
+        except Exception as e:
+            res = [{"config": name, "error": f"{type(e).__name__}: {e}"}]
+        if rehearsal:
+            for r in res:
+                r["data"] = "synthetic (REHEARSAL: all ranks share cuda:0; not a measurement)"
+        out.extend(res)
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--cpu", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    torch.manual_seed(0)
-    want = lambda n: args.only is None or args.only in n
-
-    if want("cfg3"):
-        B, C, H, W, D = 8, 32, 540, 960, 192
-        L = torch.randn(B, C, H, W, device=dev)
-        R = torch.randn(B, C, H, W, device=dev)
-        att = S.CrossAttentionCostVolume(D, "zero", "sqrt_c")
-        sec = timed(lambda: att(L, R), max(args.steps, 10))
-        ms = event_ms(lambda: att(L, R))
-        band = D * W - D * (D - 1) / 2
-        tf = 2 * 2 * B * H * C * band / (ms * 1e-3) / 1e12
-        line("cfg-3: SceneFlow 960x540 D=192 CrossAttentionCostVolume (QK^T / softmax / PV on f32 MFMA) + disparity "
-             "regression, batch=8", B, sec, max(args.steps, 10),
-             {"bound": "mfma", "kernel": "cross_attention_online_kernel<7,8> (A7)", "achieved": round(tf, 2),
-              "peak": MFMA_F32_PEAK, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK, 4), "traffic": None,
-              "avg_launch_ms": round(ms, 4), "algorithmic_flops": 2 * 2 * B * H * C * band})
-        del L, R
-
-    if want("cfg4"):
-        B, Hq, Wq = 8, 136, 240  # 544x960 / 4
-        f1, f2, nets, inps = raft_inputs(B, Hq, Wq, dev)
-        roof = allpairs_roofline(f1, f2)
-        for mp in (False, True):
-            loop = S.RAFTStereoLoop([128, 128, 128], mixed_precision=mp, channels_last=True).eval().cuda()
-            fn = lambda: loop(f1, f2, [n.clone() for n in nets], inps, iters=16, test_mode=True, use_graph=True)
-            sec = timed(fn, args.steps)
-            line("cfg-4: SceneFlow 960x540 (padded 544) IterativeLocalCostVolume loop (RAFT-style update operator at 1/4 "
-                 "resolution, NHWC through the update block): all-pairs pyramid + 16 x (lookup + update block + coords) + convex "
-                 "upsampling, batch=8 per GPU"
-                 + (", update-block convolutions under fp16 autocast (the reference's mixed_precision flag; NOT the "
-                    "parity configuration)" if mp else ", fp32"), B, sec, args.steps, roof,
-                 {"bounded_by": "MIOpen convolutions of the update block (1.2 TFLOP per iteration for 8 pairs)",
-                  "dtype": "f32 (+ f16 convs)" if mp else "f32"})
-        del f1, f2, nets, inps
-        vol = torch.randn(B, 24, 72, 120, device=dev)
-        disp = torch.rand(B, 1, 72, 120, device=dev) * 20
-        li = torch.randn(B, 3, 576, 960, device=dev)
-        ri = torch.randn(B, 3, 576, 960, device=dev)
-        lp = S.LowCNNGRULoop(24, 32, 20).eval().cuda()
-        sec = timed(lambda: lp(vol, disp, li, ri, iters=16, use_graph=True), max(args.steps, 10))
-        ms = event_ms(lambda: S.bounds_lookup(vol, disp, torch.rand(B, 2, 72, 120, device=dev) * 3, 20, True))
-        line("cfg-4 (LowCNN GRU updater, baseline_dynamic_gru): 16 x DisparityUpdateDLCWithMask at 1/8 resolution "
-             "[8,24,72,120] + convex upsampling x8 of the last iterate, batch=8 per GPU, fp32", B, sec, max(args.steps, 10),
-             {"bound": "hbm", "kernel": "lookup_kernel<BOUNDS> (A11 sampler; latency-scale at this size)", "achieved": None,
-              "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None, "avg_launch_ms": round(ms, 4)},
-             {"bounded_by": "MIOpen convolutions (Winograd / GEMM) of the updater"})
-        del vol, disp, li, ri
-
-    if want("cfg5"):
-        B, Hq, Wq, Dq = 4, 96, 312, 64  # 384x1248 / 4, D = 256 / 4
-        f1, f2, nets, inps = raft_inputs(B, Hq, Wq, dev)
-        att = S.CrossAttentionCostVolume(Dq, "neginf", "sqrt_c")
-        loop = S.RAFTStereoLoop([128, 128, 128], channels_last=True).eval().cuda()
-
-        def chain():
-            _, d = att(f1, f2, need_out=False)
-            init = torch.cat([-d.unsqueeze(1), torch.zeros_like(d.unsqueeze(1))], 1)  # raft_stereo.py:163-164
-            return loop(f1, f2, [n.clone() for n in nets], inps, iters=16, flow_init=init, test_mode=True, use_graph=True)
-
-        sec = timed(chain, args.steps)
-        ms = event_ms(lambda: att(f1, f2, need_out=False))
-        band = Dq * Wq - Dq * (Dq - 1) / 2
-        tf = 2 * B * Hq * 256 * band / (ms * 1e-3) / 1e12
-        line("cfg-5: KITTI 1242x375 (padded 1248x384) D=256: cross-attention at 1/4 resolution [4,256,96,312] (band 64) "
-             "-> initial disparity -> 16-iteration IterativeLocalCostVolume loop, batch=4 per GPU, fp32", B, sec, args.steps,
-             {"bound": "mfma", "kernel": "cross_attention_reg_kernel<3> (A7, C=256: HBM-leaning at 0.49 GB I/O)",
-              "achieved": round(tf, 2), "peak": MFMA_F32_PEAK, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK, 4),
-              "traffic": None, "avg_launch_ms": round(ms, 4)},
-             {"bounded_by": "MIOpen convolutions of the update block"})
+    torch.cuda.set_device(0)
+    for e in run_all(dev, 0, 1, cpu=args.cpu, steps=args.steps, only=args.only, mixed=True):
+        print(json.dumps(e), flush=True)
 
 
 if __name__ == "__main__":
