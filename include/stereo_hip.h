@@ -10,8 +10,11 @@
  * Conventions
  *   - all tensors fp32, contiguous NCHW, DEVICE pointers owned by the caller;
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*;
- *     NULL = the default stream); no internal sync, no global state, no
- *     allocation: safe to capture into a hipGraph and re-entrant;
+ *     NULL = the default stream); no internal sync, no allocation, no state
+ *     carried between calls (the only process-wide data are the test hooks of
+ *     stereo_test_option and a once-per-device opt-in flag for large LDS
+ *     tiles, both atomics): safe to capture into a hipGraph, re-entrant and
+ *     callable from several host threads;
  *   - return value: STEREO_OK or a negative STEREO_ERR_* code; on error no
  *     kernel has been launched;
  *   - zero-sized problems (any extent == 0) return STEREO_OK and launch nothing.
@@ -38,6 +41,13 @@ extern "C" {
 
 int stereo_abi_version(void);
 const char *stereo_strerror(int code);
+
+/* TEST HOOK, not part of the product contract: steers which kernel serves the following calls so that the test-suite
+ * can run a fallback kernel on a shape the fast path would take ("corr_mfma" 0/1, "gwc_fused" 0/1, "att_kernel" 0/2/4,
+ * "att_waves" 0/4/8, "prob_single_pass" 0/1) or make small inputs walk the persistent multi-tile loops
+ * ("tiles_per_wg" n).  Process-wide atomics; value < 0 restores the default.  The library reads no environment
+ * variable.  Returns STEREO_ERR_BAD_SHAPE for an unknown name. */
+int stereo_test_option(const char *name, int value);
 
 /* A1  CostVolume.forward 'correlation'  models/utils/build_cost_volume.py:39-47
  *     left,right [B,C,H,W] -> vol [B,D,H,W];  vol[b,d,h,w] = mean_c L*R(w-d), 0 for w<d */

@@ -7,6 +7,7 @@ call raises.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 
@@ -24,6 +25,7 @@ _ll = ctypes.c_longlong
 SIGNATURES = {
     "stereo_abi_version": [],
     "stereo_strerror": [_i],
+    "stereo_test_option": [ctypes.c_char_p, _i],
     "stereo_corr_volume_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_diff_volume_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_concat_volume_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -103,6 +105,21 @@ def check(rc: int, name: str) -> None:
 
 def call(name: str, *args) -> None:
     check(getattr(load(), name)(*args), name)
+
+
+@contextlib.contextmanager
+def test_options(**opts):
+    """TEST HOOK (``stereo_test_option``): steer which kernel serves the calls inside the ``with`` block, e.g.
+    ``test_options(corr_mfma=0)`` runs the VALU fallback on a shape the matrix-core kernel would take.  Defaults are
+    restored on exit.  Not part of the product surface; the library reads no environment variable."""
+    lib = load()
+    try:
+        for k, v in opts.items():
+            check(lib.stereo_test_option(k.encode(), int(v)), f"stereo_test_option({k})")
+        yield
+    finally:
+        for k in opts:
+            lib.stereo_test_option(k.encode(), -1)
 
 
 def stream_ptr(device: torch.device | None = None) -> ctypes.c_void_p:

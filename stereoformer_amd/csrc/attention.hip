@@ -7,101 +7,13 @@
 //   they are excluded);  disp[w] = sum_d P[d]*d;  out[:,w] = sum_d P[d]*V[:,w-d].
 //
 // Kernels in this file, newest last (the dispatcher at the bottom picks the newest that applies):
-//   v1  VALU/LDS: one workgroup per (row, 64 queries), band logits in LDS.  Last-resort fallback.
 //   v2  f32 MFMA for both contractions, probabilities through an LDS score sheet (ragged W, D > 256).
 //   v4  scores stay in the MFMA accumulators, two-pass softmax (any C / Cv / value tensor).
 //   v5  v4 + online softmax + persistent prefetching workgroups (C <= 32, value = right features).
 // The [B,H,W,D] score tensor is never materialised in HBM by any of them.
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
-
-constexpr int TQ = 64;   // queries per workgroup
-constexpr int CK = 32;   // channels per staging round
-
-__global__ __launch_bounds__(256) void cross_attention_kernel(const float *__restrict__ L, const float *__restrict__ R,
-                                                              const float *__restrict__ V, float *__restrict__ out,
-                                                              float *__restrict__ disp, int C, int Cv, int H, int W,
-                                                              int D, int Dpad, int mask_mode, float scale)
-{
-    extern __shared__ f32x4 smem4[];
-    float *Ls = reinterpret_cast<float *>(smem4);  // [CK][TQ]
-    const int RS = TQ + Dpad;
-    float *Rs = Ls + CK * TQ;   // [CK][RS]   (re-used for the value tile)
-    float *P = Rs + CK * RS;    // [Dpad][TQ] logits, then probabilities
-
-    const int w0 = blockIdx.x * TQ, h = blockIdx.y, b = blockIdx.z;
-    const int tid = threadIdx.x;
-    const int wq = tid % TQ, sub = tid / TQ;  // 4 sub-lanes per query
-    const size_t HW = (size_t)H * W;
-
-    for (int idx = tid; idx < Dpad * TQ; idx += 256) P[idx] = 0.0f;
-
-    // ---- logits: P[d][w] = sum_c L[c][w0+w] * R[c][w0+w-d]
-    for (int c0 = 0; c0 < C; c0 += CK) {
-        const int ncc = (C - c0) < CK ? (C - c0) : CK;
-        __syncthreads();
-        for (int idx = tid; idx < ncc * TQ; idx += 256) {
-            const int c = idx / TQ, x = idx - c * TQ;
-            Ls[c * TQ + x] = (w0 + x < W) ? L[((size_t)b * C + c0 + c) * HW + (size_t)h * W + w0 + x] : 0.0f;
-        }
-        for (int idx = tid; idx < ncc * RS; idx += 256) {
-            const int c = idx / RS, x = idx - c * RS;
-            const int w = w0 - Dpad + x;
-            Rs[c * RS + x] = (w >= 0 && w < W) ? R[((size_t)b * C + c0 + c) * HW + (size_t)h * W + w] : 0.0f;
-        }
-        __syncthreads();
-        for (int d = sub; d < D; d += 256 / TQ) {
-            float acc = 0.0f;
-            const float *rp = Rs + Dpad + wq - d;
-            for (int c = 0; c < ncc; ++c) acc = fmaf(Ls[c * TQ + wq], rp[c * RS], acc);
-            P[d * TQ + wq] += acc;
-        }
-    }
-    __syncthreads();
-    // ---- masked softmax over the band, one query per lane of the first wave
-    if (tid < TQ) {
-        const int w = w0 + tid;
-        float m = -INFINITY;
-        for (int d = 0; d < D; ++d) {
-            float x = P[d * TQ + tid] * scale;
-            if (w - d < 0) x = mask_mode == STEREO_MASK_ZERO ? 0.0f : -INFINITY;
-            P[d * TQ + tid] = x;
-            m = fmaxf(m, x);
-        }
-        float s = 0.0f;
-        for (int d = 0; d < D; ++d) s += fast_exp(P[d * TQ + tid] - m);
-        const float inv = 1.0f / s;
-        float e = 0.0f;
-        for (int d = 0; d < D; ++d) {
-            const float p = fast_exp(P[d * TQ + tid] - m) * inv;
-            P[d * TQ + tid] = p;
-            e = fmaf(p, (float)d, e);
-        }
-        if (disp && w < W) disp[((size_t)b * H + h) * W + w] = e;
-    }
-    if (out == nullptr) return;
-    // ---- out[c][w] = sum_d P[d][w] * V[c][w-d]
-    for (int c0 = 0; c0 < Cv; c0 += CK) {
-        const int ncc = (Cv - c0) < CK ? (Cv - c0) : CK;
-        __syncthreads();
-        for (int idx = tid; idx < ncc * RS; idx += 256) {
-            const int c = idx / RS, x = idx - c * RS;
-            const int w = w0 - Dpad + x;
-            Rs[c * RS + x] = (w >= 0 && w < W) ? V[((size_t)b * Cv + c0 + c) * HW + (size_t)h * W + w] : 0.0f;
-        }
-        __syncthreads();
-        for (int c = sub; c < ncc; c += 256 / TQ) {
-            float acc = 0.0f;
-            const float *vp = Rs + c * RS + Dpad + wq;
-            for (int d = 0; d < D; ++d) acc = fmaf(P[d * TQ + wq], vp[-d], acc);
-            if (w0 + wq < W) out[((size_t)b * Cv + c0 + c) * HW + (size_t)h * W + w0 + wq] = acc;
-        }
-    }
-}
-
 
 // ---------------------------------------------------------------------------
 // staging helper of the LDS-score-sheet kernel (v2) below
@@ -742,11 +654,11 @@ int launch_online(const float *left, const float *right, float *out, float *disp
     // is so short that half of them would idle.  (6 waves = 192 queries divides W = 960 exactly but
     // measured slower: its register budget admits a single 6-wave workgroup per CU.)
     int nwv = W > 128 ? 8 : 4;
-    if (const char *e = getenv("STEREO_ATT_NW")) nwv = atoi(e) == 8 ? 8 : 4;
+    if (stereo_opt(OPT_ATT_WAVES) == 4 || stereo_opt(OPT_ATT_WAVES) == 8) nwv = stereo_opt(OPT_ATT_WAVES);  // test hook
     // persistent workgroups: two resident per CU walk contiguous runs of tiles (row-major)
     const int ntl = ((W + 32 * nwv - 1) / (32 * nwv)) * H * B;
     int tpw = (ntl + 511) / 512;
-    if (const char *e = getenv("STEREO_ATT_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;
+    if (stereo_opt(OPT_TILES_PER_WG) > 0) tpw = stereo_opt(OPT_TILES_PER_WG);  // test hook: short persistent runs
     const int nwg = (ntl + tpw - 1) / tpw;
 #define ATT5N(NTV, NWVV)                                                                                        \
     hipLaunchKernelGGL((cross_attention_online_kernel<NTV, NWVV>), dim3(nwg), dim3(NWVV * 64), 0, st, left, right, out, \
@@ -783,14 +695,13 @@ extern "C" int stereo_cross_attention_f32(const float *left, const float *right,
     if (!fits_grid_yz(H) || !fits_grid_yz(B)) return STEREO_ERR_UNSUPPORTED;
     {   // v4: register-resident scores (aligned, W % 4 == 0, band <= 256 after rounding up to a multiple of 32)
         const bool vec = (W % 4 == 0) && aligned16(left) && aligned16(right) && (out == nullptr || aligned16(value));
-        const char *v2on = getenv("STEREO_ATT_V2");  // dev/test knob: force the LDS-score-sheet kernel below
-        if (vec && D <= 256 && !(v2on && v2on[0] == '1')) {
+        const int forced = stereo_opt(OPT_ATT_KERNEL);  // test hook: 2 = the LDS-score-sheet kernel below, 4 = v4
+        if (vec && D <= 256 && forced != 2) {
             const int nt = (D + 31) / 32 + 1;
             const float sc = scale_mode == STEREO_SCALE_MEAN ? 1.0f / (float)C : 1.0f / sqrtf((float)C);
             const int same_kv = (out != nullptr && value == right && Cv == C) ? 1 : 0;
             dim3 grid4((W + A4_TQ - 1) / A4_TQ, H, B);
-            const char *v5off = getenv("STEREO_ATT_V4");
-            if (C <= 32 && (out == nullptr || same_kv) && !(v5off && v5off[0] == '1')) {  // v5: online softmax
+            if (C <= 32 && (out == nullptr || same_kv) && forced != 4) {  // v5: online softmax
                 const int rc5 = launch_online(left, right, out, disp, B, C, H, W, D, mask_mode, sc, as_stream(stream));
                 if (rc5 != STEREO_ERR_UNSUPPORTED) return rc5;
             }
@@ -818,10 +729,9 @@ extern "C" int stereo_cross_attention_f32(const float *left, const float *right,
 #define ATT_K(N) (vec ? cross_attention_mfma_kernel<N, true> : cross_attention_mfma_kernel<N, false>)
             auto kern = npt <= 8 ? ATT_K(8) : npt <= 16 ? ATT_K(16) : npt <= 24 ? ATT_K(24) : npt <= 32 ? ATT_K(32) : ATT_K(64);
 #undef ATT_K
-            if (lds2 > 64 * 1024 &&
-                hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds2) != hipSuccess)
-                return STEREO_ERR_UNSUPPORTED;
+            static std::atomic<unsigned long long> lds_done[10] = {};
+            const int slot = (npt <= 8 ? 0 : npt <= 16 ? 1 : npt <= 24 ? 2 : npt <= 32 ? 3 : 4) * 2 + (vec ? 1 : 0);
+            if (!lds_opt_in(kern, lds2, lds_done[slot])) return STEREO_ERR_UNSUPPORTED;
             const float scale2 = scale_mode == STEREO_SCALE_MEAN ? 1.0f / (float)C : 1.0f / sqrtf((float)C);
             dim3 grid2((W + A2_TQ - 1) / A2_TQ, H, B);
             hipLaunchKernelGGL(kern, grid2, dim3(A2_NT), lds2, as_stream(stream), left, right, value, out, disp, C, Cv, H,
@@ -830,19 +740,7 @@ extern "C" int stereo_cross_attention_f32(const float *left, const float *right,
             return STEREO_OK;
         }
     }
-    const int Dpad = (D + 3) / 4 * 4;
-    const size_t lds = ((size_t)CK * TQ + (size_t)CK * (TQ + Dpad) + (size_t)Dpad * TQ) * sizeof(float);
-    if (lds > 160 * 1024) return STEREO_ERR_UNSUPPORTED;
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(cross_attention_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return STEREO_ERR_UNSUPPORTED;
-    const float scale = scale_mode == STEREO_SCALE_MEAN ? 1.0f / (float)C : 1.0f / sqrtf((float)C);
-    dim3 grid((W + TQ - 1) / TQ, H, B);
-    hipLaunchKernelGGL(cross_attention_kernel, grid, dim3(256), lds, as_stream(stream), left, right, value, out, disp, C,
-                       Cv, H, W, D, Dpad, mask_mode, scale);
-    STEREO_LAUNCH_CHECK();
-    return STEREO_OK;
+    return STEREO_ERR_UNSUPPORTED;  // band too long for the LDS score sheet (D > ~380)
 }
 
 // A1 + A4 with no volume at all, on the matrix cores (library-internal; STEREO_ERR_UNSUPPORTED outside the envelope).

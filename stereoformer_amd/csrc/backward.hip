@@ -1,6 +1,5 @@
 // Backward kernels for the cfg-2 chain: soft-argmin, correlation / group-wise volume,
 // local cost-volume lookup.  Same conventions as the forward kernels: fp32, NCHW, lanes along W.
-#include <stdlib.h>
 
 #include "common.h"
 
@@ -661,8 +660,7 @@ extern "C" int stereo_gwc_volume_bwd_f32(const float *left, const float *right, 
     if (D > 0) STEREO_REQUIRE_PTR(grad_vol);
     if (grad_left == nullptr && grad_right == nullptr) return STEREO_OK;
     {
-        const char *e = getenv("STEREO_CORR_MFMA");  // dev/test knob: "0" forces the VALU kernels
-        if (G == 1 && D > 0 && !(e && e[0] == '0')) {
+        if (G == 1 && D > 0 && stereo_opt(OPT_CORR_MFMA) != 0) {
             const int rc = stereo_corr_volume_bwd_mfma(left, right, grad_vol, grad_left, grad_right, B, C, H, W, D,
                                                        as_stream(stream));
             if (rc != STEREO_ERR_UNSUPPORTED) return rc;

@@ -11,6 +11,38 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Test hooks (stereo_test_option in include/stereo_hip.h): process-wide relaxed atomics, read once per launch.  They
+// only steer WHICH kernel serves a call (forcing a fallback onto a shape the fast path would take, or a short
+// persistent run so that small test inputs exercise the multi-tile loop); no environment variable is read anywhere.
+enum StereoOpt {
+    OPT_CORR_MFMA = 0,   // 1 (default): matrix-core volume kernels where their envelope allows; 0: VALU kernels
+    OPT_GWC_FUSED,       // 1 (default): A3 + group mean + A4 in one launch; 0: separate launches
+    OPT_ATT_KERNEL,      // 0 (default): newest applicable; 2: LDS-score-sheet kernel; 4: two-pass register kernel
+    OPT_ATT_WAVES,       // 0 (default): by row length; 4 / 8: waves per workgroup of the online-softmax kernel
+    OPT_TILES_PER_WG,    // 0 (default): sized to the resident workgroups; n > 0: tiles per persistent workgroup
+    OPT_PROB_SINGLE_PASS,  // 1 (default): softmax column in registers (D <= 192); 0: two-pass kernel
+    OPT_COUNT
+};
+int stereo_opt(int which);
+
+// > 64 KB of dynamic LDS needs a one-time opt-in per kernel and device; idempotent, so a benign race between host
+// threads (DataParallel replicas) at worst sets it twice.  `done` is a per-instantiation bit mask over devices.
+#include <atomic>
+template <typename K>
+static inline bool lds_opt_in(K kern, size_t bytes, std::atomic<unsigned long long> &done)
+{
+    if (bytes <= 64 * 1024) return true;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const bool track = dev >= 0 && dev < 64;
+    if (track && (done.load(std::memory_order_acquire) >> dev & 1ull)) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess)
+        return false;
+    if (track) done.fetch_or(1ull << dev, std::memory_order_release);
+    return true;
+}
+
 #define STEREO_REQUIRE_PTR(p) \
     do {                      \
         if ((p) == nullptr) return STEREO_ERR_NULL_POINTER; \

@@ -22,17 +22,13 @@
 // Persistent workgroups walk runs of tiles; the next tile's K quads / Q values are prefetched into registers under the
 // current tile's MFMAs.  C <= 32 (one MFMA K-tile), W % 4 == 0, D <= 192 (LDS: 58 KB keys + 100 KB sheet; up to 256 for
 // A1 / A1+A4 with six waves per workgroup).
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
 
-// Workgroup shapes: (CM_NWV waves = 32 * CM_NWV queries, RINGB 32-row sheet blocks).
-//   (8, 3): 256-query tiles, 1-KiB row stores, three blocks (being read / complete / being written), one barrier per
-//           step; 158 KB of LDS at D = 192 -> one workgroup per CU.
-//   (4, 2): 128-query tiles, two blocks and a second barrier per step (the flushed block is rewritten by the next step);
-//           75 KB -> two workgroups per CU, whose phases interleave.
+// Workgroup shape: CM_NWV waves = 32 * CM_NWV queries, a ring of RINGB = 3 32-row sheet blocks (being read / complete /
+// being written), one barrier per step, 1-KiB row stores; 158 KB of LDS at D = 192 -> one workgroup per CU.  (A
+// 128-query shape with a two-block ring fits two workgroups per CU but measured slower, 1.20 vs 1.13 ms for A1.)
 // CPG2 > 0 adds the GROUP PASS in front (A3 + group mean + A4 in ONE kernel, cfg-2's whole volume stage): for each of
 // the G groups of 2 * CPG2 channels the same step loop runs with CPG2 MFMAs per key tile (the group's channel pairs) and
 // flushes into volg[b, g]; then the all-channel pass produces the mean volume and the disparity as before.  The key
@@ -190,9 +186,8 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
                         }
                         __syncthreads();
                         if (s >= 1) flush_block(volg, (s + RINGB - 1) % RINGB, 32 * (s - 1), goff, w0);
-                        if (RINGB == 2) __syncthreads();
                     }
-                    if (RINGB != 2) __syncthreads();  // the last flush's sheet reads vs the next pass's first writes
+                    __syncthreads();  // the last flush's sheet reads vs the next pass's first writes
                 }
             }
         }
@@ -248,7 +243,6 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
             }
             __syncthreads();  // step s is on the sheet: block (s-1) % RINGB is complete
             if (s >= 1) flush_block(vol, (s + RINGB - 1) % RINGB, 32 * (s - 1), row_off, w0);
-            if (RINGB == 2) __syncthreads();  // two blocks: the flushed one is rewritten by the next step
         }
         // the last complete block: rows 32 (NT-2) .. Dk - 1 needed no further step?  No: they take entries from tile
         // NT-1 as well, which the loop has just written -> complete after its barrier.  (Rows >= Dk never exist.)
@@ -273,20 +267,13 @@ int launch_cm(const float *L, const float *R, float *vol, float *disp, int B, in
     const size_t lds = ((size_t)32 * (TQW + Dk + 4) + (size_t)32 * RINGB * (TQW + 4)) * sizeof(float);
     auto kern = corr_volume_mfma_kernel<NT, ARGMIN, NWV, RINGB, CPG2, MEANPASS>;
     if (lds > 160 * 1024) return STEREO_ERR_UNSUPPORTED;
-    static bool lds_ok[64] = {};  // per instantiation and device: the opt-in for > 64 KB of dynamic LDS is needed once
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
-    if (lds > 64 * 1024 && (dev < 0 || !lds_ok[dev])) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return STEREO_ERR_UNSUPPORTED;
-        if (dev >= 0) lds_ok[dev] = true;
-    }
+    static std::atomic<unsigned long long> lds_done{0};  // per instantiation: a bit per device
+    if (!lds_opt_in(kern, lds, lds_done)) return STEREO_ERR_UNSUPPORTED;
     const long long ntl = (long long)((W + TQW - 1) / TQW) * H * B;
     if (ntl >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
     const int resident = 256 * (int)((160 * 1024) / lds);  // persistent workgroups: as many as the LDS admits per CU
     int tpw = (int)((ntl + resident - 1) / resident);
-    if (const char *e = getenv("STEREO_CM_TPW")) tpw = atoi(e) > 0 ? atoi(e) : tpw;
+    if (stereo_opt(OPT_TILES_PER_WG) > 0) tpw = stereo_opt(OPT_TILES_PER_WG);  // test hook: short persistent runs
     const int nwg = (int)((ntl + tpw - 1) / tpw);
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(NWV * 64), lds, st, L, R, vol, disp, C, H, W, D, 1.0f / (float)C, sgn, tpw,
                        (int)ntl, volg, G, CPG2 > 0 ? 1.0f / (float)(2 * CPG2) : 1.0f);
@@ -307,16 +294,9 @@ int stereo_corr_volume_mfma(const float *L, const float *R, float *vol, float *d
     if (nt > 7)  // 192 < D <= 256: six waves (192 queries) keep key tile + sheet inside the 160 KB of LDS
         return disp ? launch_cm<9, true, 6, 3>(L, R, vol, disp, B, C, H, W, D, sgn, st)
                     : launch_cm<9, false, 6, 3>(L, R, vol, disp, B, C, H, W, D, sgn, st);
-    int small = 0;  // dev knob: STEREO_CM_SHAPE=4 -> 128-query tiles, two workgroups per CU
-    if (const char *e = getenv("STEREO_CM_SHAPE")) small = atoi(e) == 4;
-#define CM_CASE(NTV)                                                                                              \
-    do {                                                                                                          \
-        if (small)                                                                                                \
-            return disp ? launch_cm<NTV, true, 4, 2>(L, R, vol, disp, B, C, H, W, D, sgn, st)                      \
-                        : launch_cm<NTV, false, 4, 2>(L, R, vol, disp, B, C, H, W, D, sgn, st);                    \
-        return disp ? launch_cm<NTV, true, 8, 3>(L, R, vol, disp, B, C, H, W, D, sgn, st)                          \
-                    : launch_cm<NTV, false, 8, 3>(L, R, vol, disp, B, C, H, W, D, sgn, st);                        \
-    } while (0)
+#define CM_CASE(NTV)                                                                     \
+    return disp ? launch_cm<NTV, true, 8, 3>(L, R, vol, disp, B, C, H, W, D, sgn, st) \
+                : launch_cm<NTV, false, 8, 3>(L, R, vol, disp, B, C, H, W, D, sgn, st)
     if (nt <= 3) CM_CASE(3);
     if (nt <= 5) CM_CASE(5);
     CM_CASE(7);

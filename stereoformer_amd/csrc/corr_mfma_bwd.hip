@@ -12,7 +12,6 @@
 //     dR~[c, u] = 1/C * sum_d g~[d, u] * L~[c, u - d],   g~[d, u] = g[d, (W-1+d) - u],   L~[c, x] = L[c, W-1-x]
 // so FLIP = true only changes how the sheet and the feature tile are FILLED (row d of g is read backwards from column
 // W-1+d: contiguous, 4-byte aligned) and where the result is stored.  C <= 32, D <= 192, W % 4 == 0.
-#include <stdlib.h>
 
 #include "common.h"
 
@@ -178,15 +177,8 @@ int launch_cb(const float *G, const float *X, float *dOut, int B, int C, int H, 
     const size_t lds = ((size_t)32 * (CB_TQW + Dk + 4) + (size_t)CB_RING * CB_RSTR) * sizeof(float);
     auto kern = corr_volume_bwd_mfma_kernel<NT, FLIP>;
     if (lds > 160 * 1024) return STEREO_ERR_UNSUPPORTED;
-    static bool lds_ok[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
-    if (lds > 64 * 1024 && (dev < 0 || !lds_ok[dev])) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return STEREO_ERR_UNSUPPORTED;
-        if (dev >= 0) lds_ok[dev] = true;
-    }
+    static std::atomic<unsigned long long> lds_done{0};
+    if (!lds_opt_in(kern, lds, lds_done)) return STEREO_ERR_UNSUPPORTED;
     const long long ntl = (long long)((W + CB_TQW - 1) / CB_TQW) * H * B;
     if (ntl >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
     const int tpw = (int)((ntl + 1023) / 1024);  // ~4 workgroups per CU over the launch (one resident at a time)

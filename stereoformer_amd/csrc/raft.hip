@@ -8,8 +8,6 @@
 // low-precision split).  A <-> fmap1 (rows = w1), B <-> fmap2 (cols = w2): both
 // operands are read straight from the [C][W] layout, 32 consecutive pixels per
 // half-wave, and every accumulator register stores a 128-B row segment.
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
@@ -78,33 +76,20 @@ __global__ __launch_bounds__(256) void allpairs_kernel(const float *__restrict__
 // the previous chunk is on the matrix cores, then committed to the other LDS buffer: one barrier per
 // chunk.  MFMA operands are conflict-free ds_read_b32 (lanes along w).
 constexpr int AP_KC = 16;
-constexpr int AP_MAX_FUSED = 5;  // pooled levels produced inside a 32-column MFMA tile (2^5 = 32)
-// Measured on MI355X at [8,256,136,240], 4 levels: pooling in the epilogue (cross-lane adds + narrow
-// strided stores) 0.631 ms vs all-pairs + 4 streaming pool launches 0.583 ms -> the fused form is kept
-// (bit-identical, covered by tests through STEREO_FUSE_PYRAMID=1) but is not the default.
-static bool fuse_pyramid()
-{
-    const char *e = getenv("STEREO_FUSE_PYRAMID");
-    return e && e[0] == '1';
-}
-#define AP_FUSE_PYRAMID fuse_pyramid()
-
 struct PyrOut {
     float *p[STEREO_MAX_LEVELS];
     int w[STEREO_MAX_LEVELS];
-    int nfused;  // levels 1..nfused are written by the all-pairs epilogue
 };
 
 // f32 MFMA and VALU instructions serialise on a gfx950 SIMD (tools/mfma_coexec.hip), so the epilogue's instruction
-// count is paid in MFMA time: FUSE = false (default) is the lean form -- one multiply (or, when sqrt(C) is not a power
-// of two, one true division) and one store per output, 32-bit offsets from a workgroup-uniform base, no bounds tests on
-// interior tiles.  FUSE = true additionally produces pooled levels with cross-lane adds (opt-in, slower).
-template <bool FUSE>
+// count is paid in MFMA time: one multiply (or, when sqrt(C) is not a power of two, one true division) and one store
+// per output, 32-bit offsets from a workgroup-uniform base, no bounds tests on interior tiles.  (Pooling the pyramid
+// levels in this epilogue with cross-lane adds was bit-identical but slower than one streaming pass over level 0:
+// 0.631 vs 0.583 ms at [8,256,136,240].)
 __global__ __launch_bounds__(256) void allpairs_lds_kernel(const float *__restrict__ f1, const float *__restrict__ f2,
-                                                           PyrOut pyr, int C, int H, int W1, int W2, float sqrt_c,
-                                                           float inv_sqrt_c, int mul_exact)
+                                                           float *__restrict__ out, int C, int H, int W1, int W2,
+                                                           float sqrt_c, float inv_sqrt_c, int mul_exact)
 {
-    float *__restrict__ out = pyr.p[0];
     __shared__ float As[2][AP_KC][128];
     __shared__ float Bs[2][AP_KC][128];
     const int bh = blockIdx.z;
@@ -173,59 +158,30 @@ __global__ __launch_bounds__(256) void allpairs_lds_kernel(const float *__restri
     }
     const int jb0 = N0 + nw + l31, jb1 = jb0 + 32;
     auto scaled = [&](float v) { return mul_exact ? v * inv_sqrt_c : v / sqrt_c; };  // corr.py:110 divides by sqrt(C)
-    if (!FUSE) {
-        // launcher: W1 * W2 < 2^31, so a row block's offsets fit 32 bits next to the uniform 64-bit base
-        float *ob = out + (size_t)bh * W1 * W2;
-        const unsigned off0 = (unsigned)(M0 + mw + 4 * half) * (unsigned)W2 + (unsigned)jb0;
-        const bool interior = M0 + 128 <= W1 && N0 + 128 <= W2;  // workgroup-uniform
-        if (interior) {
+    // launcher: W1 * W2 < 2^31, so a row block's offsets fit 32 bits next to the uniform 64-bit base
+    float *ob = out + (size_t)bh * W1 * W2;
+    const unsigned off0 = (unsigned)(M0 + mw + 4 * half) * (unsigned)W2 + (unsigned)jb0;
+    const bool interior = M0 + 128 <= W1 && N0 + 128 <= W2;  // workgroup-uniform
+    if (interior) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned o = off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)W2;
-                ob[o] = scaled(acc00[r]);
-                ob[o + 32] = scaled(acc01[r]);
-                ob[o + 32u * (unsigned)W2] = scaled(acc10[r]);
-                ob[o + 32u * (unsigned)W2 + 32] = scaled(acc11[r]);
-            }
-        } else {
-            const bool okj0 = jb0 < W2, okj1 = jb1 < W2;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int w1a = M0 + mw + 4 * half + (r & 3) + 8 * (r >> 2);
-                const unsigned o = off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)W2;
-                if (w1a < W1 && okj0) ob[o] = scaled(acc00[r]);
-                if (w1a < W1 && okj1) ob[o + 32] = scaled(acc01[r]);
-                if (w1a + 32 < W1 && okj0) ob[o + 32u * (unsigned)W2] = scaled(acc10[r]);
-                if (w1a + 32 < W1 && okj1) ob[o + 32u * (unsigned)W2 + 32] = scaled(acc11[r]);
-            }
+        for (int r = 0; r < 16; ++r) {
+            const unsigned o = off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)W2;
+            ob[o] = scaled(acc00[r]);
+            ob[o + 32] = scaled(acc01[r]);
+            ob[o + 32u * (unsigned)W2] = scaled(acc10[r]);
+            ob[o + 32u * (unsigned)W2 + 32] = scaled(acc11[r]);
         }
-        return;
-    }
-    // fused epilogue: level 0 plus the first pooled levels.  Level l+1 = mean of adjacent pairs of level l
-    // (corr.py:70-76): adjacent columns are adjacent lanes, so each level is one cross-lane add on the
-    // already rounded level-l value -- bit-identical to pooling the stored level.
-    const size_t rowbase = (size_t)bh * W1;
-    auto emit = [&](float v, int w1, int jb) {
-        if (w1 < W1 && jb < W2) out[(rowbase + w1) * W2 + jb] = v;
-        float cur = v;
+    } else {
+        const bool okj0 = jb0 < W2, okj1 = jb1 < W2;
 #pragma unroll
-        for (int l = 1; l <= AP_MAX_FUSED; ++l) {
-            if (l <= pyr.nfused) {  // uniform
-                const float other = __shfl_xor(cur, 1 << (l - 1));
-                cur = (cur + other) * 0.5f;
-                const int j = jb >> l;
-                if ((l31 & ((1 << l) - 1)) == 0 && w1 < W1 && j < pyr.w[l]) pyr.p[l][(rowbase + w1) * pyr.w[l] + j] = cur;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int w1a = M0 + mw + 4 * half + (r & 3) + 8 * (r >> 2);
+            const unsigned o = off0 + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)W2;
+            if (w1a < W1 && okj0) ob[o] = scaled(acc00[r]);
+            if (w1a < W1 && okj1) ob[o + 32] = scaled(acc01[r]);
+            if (w1a + 32 < W1 && okj0) ob[o + 32u * (unsigned)W2] = scaled(acc10[r]);
+            if (w1a + 32 < W1 && okj1) ob[o + 32u * (unsigned)W2 + 32] = scaled(acc11[r]);
         }
-    };
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int w1a = M0 + mw + row, w1b = w1a + 32;
-        emit(scaled(acc00[r]), w1a, jb0);
-        emit(scaled(acc01[r]), w1a, jb1);
-        emit(scaled(acc10[r]), w1b, jb0);
-        emit(scaled(acc11[r]), w1b, jb1);
     }
 }
 
@@ -405,25 +361,13 @@ extern "C" int stereo_allpairs_pyramid_f32(const float *fmap1, const float *fmap
     if (!fits_grid_yz((long long)B * H) || !fits_grid_yz((W1 + 127) / 128)) return STEREO_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);
     dim3 grid((W2 + 127) / 128, (W1 + 127) / 128, (unsigned)(B * H));
-    int first_unpooled = 1;  // first level still to be produced by the pooling kernel
-    if (W1 % 4 == 0 && W2 % 4 == 0 && aligned16(fmap1) && aligned16(fmap2)) {
-        PyrOut pyr;
-        pyr.nfused = 0;
-        for (int i = 0, w = W2; i <= num_levels && i < STEREO_MAX_LEVELS; ++i, w /= 2) {
-            pyr.p[i] = levels[i];
-            pyr.w[i] = w;
-            if (AP_FUSE_PYRAMID && i >= 1 && i <= AP_MAX_FUSED && w > 0) pyr.nfused = i;
-        }
-        first_unpooled = pyr.nfused + 1;
+    int first_unpooled = 1;  // first level still to be produced by the pooling kernels
+    if (W1 % 4 == 0 && W2 % 4 == 0 && aligned16(fmap1) && aligned16(fmap2) && (long long)W1 * W2 < (1LL << 31)) {
         const float sq = sqrtf((float)C);
         int e2 = 0;
         const int mul_exact = frexpf(sq, &e2) == 0.5f ? 1 : 0;  // sqrt(C) a power of two: x * (1/sqrt) == x / sqrt
-        if (pyr.nfused > 0 || (long long)W1 * W2 >= (1LL << 31))
-            hipLaunchKernelGGL(allpairs_lds_kernel<true>, grid, dim3(256), 0, st, fmap1, fmap2, pyr, C, H, W1, W2, sq,
-                               1.0f / sq, mul_exact);
-        else
-            hipLaunchKernelGGL(allpairs_lds_kernel<false>, grid, dim3(256), 0, st, fmap1, fmap2, pyr, C, H, W1, W2, sq,
-                               1.0f / sq, mul_exact);
+        hipLaunchKernelGGL(allpairs_lds_kernel, grid, dim3(256), 0, st, fmap1, fmap2, levels[0], C, H, W1, W2, sq,
+                           1.0f / sq, mul_exact);
     } else {
         hipLaunchKernelGGL(allpairs_kernel, grid, dim3(256), 0, st, fmap1, fmap2, levels[0], C, H, W1, W2,
                            sqrtf((float)C));
@@ -440,7 +384,6 @@ extern "C" int stereo_allpairs_pyramid_f32(const float *fmap1, const float *fmap
             if (((1 << NL) >> i) >= 4 && (W2 >> i) % 4 != 0) ok = false;
         if (ok) {
             PyrOut pyr;
-            pyr.nfused = 0;
             for (int i = 0, w = W2; i <= NL; ++i, w /= 2) pyr.p[i] = levels[i], pyr.w[i] = w;
             const long long ng = rows * (W2 >> NL);
             if (NL == 4) hipLaunchKernelGGL(avgpool_pyramid_kernel<4>, dim3(grid_for(ng)), dim3(256), 0, st, levels[0], pyr, W2, ng);

@@ -5,8 +5,6 @@
 // along W), keeping an online-softmax state (running max, sum, d-weighted sum)
 // per pixel: the volume is read exactly once.  The with-prob variant re-reads
 // the (then L2/MALL-warm) column to write the normalised probabilities.
-#include <stdio.h>
-#include <stdlib.h>
 
 #include "common.h"
 
@@ -312,16 +310,13 @@ extern "C" int stereo_soft_argmin_f32(const float *vol, float *disp, float *prob
     const bool vec = (HW % 4 == 0) && aligned16(vol) && aligned16(disp) && (prob == nullptr || aligned16(prob));
     if (vec) {
         const long long n = (long long)B * (HW / 4);
-        if (prob && D <= 192 && fits_grid_yz(B) && !getenv("STEREO_PROB_TWOPASS")) {
-            int cfg = 0;  // dev knob: 1 forces the 8-wave / 1 KiB-segment shape for D > 96
-            if (const char *e = getenv("STEREO_PROB_CFG")) cfg = atoi(e);
+        if (prob && D <= 192 && fits_grid_yz(B) && stereo_opt(OPT_PROB_SINGLE_PASS) != 0) {
 #define PROB_LAUNCH(JV, NWVV, SPL)                                                                                   \
     hipLaunchKernelGGL((soft_argmin_prob_regs_kernel<JV, NWVV, SPL>),                                                \
                        dim3((unsigned)((HW / 4 + 64 / SPL - 1) / (64 / SPL)), (unsigned)B), dim3(NWVV * 64), 0, st, \
                        vol, disp, prob, D, HW, sgn)
             if (D <= 48) PROB_LAUNCH(12, 4, 1);
             else if (D <= 96) PROB_LAUNCH(24, 4, 1);
-            else if (cfg == 1) PROB_LAUNCH(24, 8, 1);
             else PROB_LAUNCH(24, 4, 2);
 #undef PROB_LAUNCH
         } else if (prob)
@@ -357,9 +352,8 @@ extern "C" int stereo_group_mean_soft_argmin_f32(const float *volg, float *vol_m
     hipStream_t st = as_stream(stream);
     const bool vec =
         (HW % 4 == 0) && aligned16(volg) && aligned16(disp) && (vol_mean == nullptr || aligned16(vol_mean));
-    int cfg_u = 1, cfg_nt = 1, cfg_cap = 1 << 20;  // measured best on MI355X (tools/gm_sweep.sh): 1 plane x G loads, nt
-    int cfg_nts = 0;
-    if (const char *e = getenv("STEREO_GM_CFG")) sscanf(e, "%d,%d,%d,%d", &cfg_u, &cfg_nt, &cfg_cap, &cfg_nts);  // dev tuning knob
+    // measured best on MI355X: 1 plane x G non-temporal loads per step, plain stores
+    constexpr int cfg_cap = 1 << 20, cfg_nts = 0;
 #define GM_LAUNCH(V, U, WM, NTV)                                                                                      \
     hipLaunchKernelGGL((group_mean_soft_argmin_kernel<V, U, WM, NTV>), dim3(gm_grid), dim3(256), 0, st, volg, vol_mean, \
                        disp, G, D, HW, n, sgn, 1.0f / (float)G, pow2 ? 0 : 1, cfg_nts)
@@ -369,16 +363,9 @@ extern "C" int stereo_group_mean_soft_argmin_f32(const float *volg, float *vol_m
         if (gb > 256LL * cfg_cap) gb = 256LL * cfg_cap;
         const unsigned gm_grid = (unsigned)gb;
         if (vol_mean) {
-            if (cfg_u == 4 && cfg_nt) GM_LAUNCH(4, 4, true, true);
-            else if (cfg_u == 4) GM_LAUNCH(4, 4, true, false);
-            else if (cfg_u == 1 && cfg_nt) GM_LAUNCH(4, 1, true, true);
-            else if (cfg_u == 1) GM_LAUNCH(4, 1, true, false);
-            else if (cfg_nt) GM_LAUNCH(4, 2, true, true);
-            else GM_LAUNCH(4, 2, true, false);
+            GM_LAUNCH(4, 1, true, true);
         } else {
-            if (cfg_u == 1 && cfg_nt) GM_LAUNCH(4, 1, false, true);
-            else if (cfg_nt) GM_LAUNCH(4, 2, false, true);
-            else GM_LAUNCH(4, 2, false, false);
+            GM_LAUNCH(4, 1, false, true);
         }
     } else {
         const unsigned gm_grid = grid_for((long long)B * HW);

@@ -9,11 +9,7 @@
 // pass does not exist here).
 //   gwc_volume_kernel       generic (ragged W, D > 256): one (batch, group) per workgroup, a barrier per chunk
 //   gwc_volume_pipe_kernel  the fast path: software pipeline over rows x groups x chunks (default)
-//   gwc_volume_pk_kernel    channel-pair packed FMA experiment (opt-in, STEREO_VOL_CFG=-dc,nw)
 // Epilogues: store the volume, fold it into a soft-argmin (A1+A4, nothing stored), or both.
-#include <stdio.h>
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
@@ -202,43 +198,36 @@ __global__ __launch_bounds__(NT) void gwc_volume_kernel(const float *__restrict_
 // group overlaps the next group's loads the same way.  NWV waves per workgroup, each owning DC
 // disparities; the store variant may split the disparity range over several small workgroups so
 // that more independent workgroups share a CU (barriers and phases of different workgroups overlap).
-template <int DC, int NWV, int EPI, int WX = 1, int CCM = CCMAX>
+template <int DC, int NWV, int EPI>
 __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *__restrict__ L,
                                                                    const float *__restrict__ R,
                                                                    float *__restrict__ vol, float *__restrict__ aux,
                                                                    int C, int H, int W, int D, int G, int CPG, int Dpad,
                                                                    int CC, float inv_cpg, int exact_div, float sgn,
-                                                                   int nparts, int RB, int nt)
+                                                                   int nparts, int RB)
 {
-    // WX waves side by side along W (WX * 256 pixels per workgroup), NWV / WX disparity strips.  WX = 4 makes a
-    // workgroup's stores whole 3840-B image rows per plane instead of 1-KiB pieces (6.1 vs 5.6 TB/s as a pure store
-    // stream, tools/hbm_ceiling.hip); it is the store-only shape (the soft-argmin epilogues need all of D in one
-    // workgroup).  CCM = channels per staged chunk (bounds the prefetch registers: 4 for the wide shape).
-    static_assert(WX == 1 || EPI == EPI_STORE, "the wide workgroup shape is store-only");
-    static_assert(NWV % WX == 0, "waves = WX x disparity strips");
     constexpr bool DO_STORE = EPI == EPI_STORE || EPI == EPI_BOTH;
     constexpr bool DO_ARGMIN = EPI == EPI_ARGMIN || EPI == EPI_BOTH;
-    constexpr int TWG = TW * WX;  // pixels per workgroup
+    constexpr int TWG = TW;  // pixels per workgroup
     extern __shared__ f32x4 smem4[];
     float *Rs = reinterpret_cast<float *>(smem4);  // [CC][RS]
     const int RS = TWG + Dpad;
     float *Ls = Rs + CC * RS;  // [CC][TWG]
 
     constexpr int NTV = NWV * 64;
-    constexpr int NSR = (CCM * (TWG + 256) / 4 + NTV - 1) / NTV;  // staging slots per lane: right tile (Dpad <= 256)
-    constexpr int NSL = (CCM * TWG / 4 + NTV - 1) / NTV;          //                         left tile
+    constexpr int NSR = (CCMAX * (TWG + 256) / 4 + NTV - 1) / NTV;  // staging slots per lane: right tile (Dpad <= 256)
+    constexpr int NSL = (CCMAX * TWG / 4 + NTV - 1) / NTV;          //                         left tile
     static_assert(NSR <= 8 && NSL <= 8, "okmask holds 8 + 8 slot bits");
     const int w0 = blockIdx.x * TWG, h0 = blockIdx.y * RB;  // RB consecutive rows per workgroup
     const int nrows = (H - h0) < RB ? (H - h0) : RB;
     const int b = blockIdx.z / nparts, dpart = blockIdx.z - b * nparts;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wx = wave % WX, wd = wave / WX;  // tile column / disparity strip of this wave
-    const int wl = (wx * 64 + lane) * 4;
+    const int wl = lane * 4;
     const size_t HW = (size_t)H * W;
     const float *Lb = L + (size_t)b * C * HW;
     const float *Rb = R + (size_t)b * C * HW;
 
-    const int d0 = (dpart * (NWV / WX) + wd) * DC;
+    const int d0 = (dpart * NWV + wave) * DC;
     const bool active = d0 < D;  // wave-uniform
 
     const int rq = RS / 4, lq = TWG / 4;
@@ -406,14 +395,14 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
             const int w = w0 + wl;
             if (DO_STORE) {
                 float *vbase = vol + (((size_t)b * G + g) * D) * HW + (size_t)h * W;
-                const bool interior = (w0 + wx * TW >= d0 + DC - 1) && (w0 + (wx + 1) * TW <= W) && (d0 + DC <= D);  // wave-uniform
+                const bool interior = (w0 >= d0 + DC - 1) && (w0 + TW <= W) && (d0 + DC <= D);  // wave-uniform
                 if (interior) {  // no w<d zeros, no ragged edge: straight scaled stores
 #pragma unroll
                     for (int dd = 0; dd < DC; ++dd) {
                         f32x4 o;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) o[i] = acc[dd][i] * mscale;
-                        if (nt) st4_nt(vbase + (size_t)(d0 + dd) * HW + w, o); else st4(vbase + (size_t)(d0 + dd) * HW + w, o);
+                        st4(vbase + (size_t)(d0 + dd) * HW + w, o);
                     }
                 } else {
 #pragma unroll
@@ -463,328 +452,40 @@ __global__ __launch_bounds__(NWV * 64) void gwc_volume_pipe_kernel(const float *
     }
 }
 
-// ---------------------------------------------------------------------------
-// Channel-pair packed variant: the FMA stream is v_pk_fma_f32 with NO operand shuffles.
-// fp32 VALU peak on CDNA4 needs the packed form (one v_fma_f32 and one v_pk_fma_f32 both hold the
-// SIMD for 4 cycles); pairing two PIXELS (what the SLP vectoriser does with the kernel above) makes
-// every odd disparity read a mis-aligned register pair -> one v_pk_mov per 4 FMAs.  Here the two
-// halves of a packed register are two CHANNELS: LDS holds the tiles channel-interleaved
-// ([pair][x][2]), so any window offset is an aligned pair, and each lane keeps two partial sums
-// (even / odd channels) per output that are added in the epilogue.  Same software pipeline as
-// above (two LDS buffers, one barrier per item, next item's global loads in flight), extended over
-// rows and over disparity passes (NWV*DC disparities per pass).
 template <int DC, int NWV, int EPI>
-__global__ __launch_bounds__(NWV * 64) void gwc_volume_pk_kernel(const float *__restrict__ L,
-                                                                 const float *__restrict__ R,
-                                                                 float *__restrict__ vol, int C, int H, int W, int D,
-                                                                 int G, int CPG, int Dpad, int CP, float inv_cpg,
-                                                                 int exact_div, float sgn, int RB)
-{
-    extern __shared__ f32x4 smem4[];
-    constexpr int NTV = NWV * 64;
-    const int RS = TW + Dpad;                       // pixels per right-tile row
-    const int BUF = CP * (RS + TW) * 2;             // floats per buffer: [CP][RS][2] + [CP][TW][2]
-    float *S0 = reinterpret_cast<float *>(smem4);
-
-    const int w0 = blockIdx.x * TW, h0 = blockIdx.y * RB, b = blockIdx.z;
-    const int nrows = (H - h0) < RB ? (H - h0) : RB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wl = lane * 4;
-    const size_t HW = (size_t)H * W;
-    const float *Lb = L + (size_t)b * C * HW;
-    const float *Rb = R + (size_t)b * C * HW;
-
-    // staging slot of this lane: one (channel pair, pixel quad) of the right tile and one of the left tile
-    const int rq = RS / 4, lq = TW / 4;
-    const int rcp = tid / rq, rx = (tid - rcp * rq) * 4;
-    const int lcp = tid / lq, lx = (tid - lcp * lq) * 4;
-    f32x4 pr0, pr1, pl0, pl1;  // even / odd channel of the pair
-    unsigned okmask = 0;       // applied at commit time: keeps the loads in flight
-    auto issue_loads = [&](int h, int cbase, int ncc) {
-        const float *Rrow = Rb + (size_t)h * W, *Lrow = Lb + (size_t)h * W;
-        {
-            const int w = w0 - Dpad + rx, c = 2 * rcp;
-            const bool okw = rcp < CP && w >= 0 && w + 3 < W;
-            const bool ok0 = okw && c < ncc, ok1 = okw && c + 1 < ncc;
-            pr0 = ld4(Rrow + (size_t)(cbase + (ok0 ? c : 0)) * HW + (ok0 ? w : 0));
-            pr1 = ld4(Rrow + (size_t)(cbase + (ok1 ? c + 1 : 0)) * HW + (ok1 ? w : 0));
-            okmask = (ok0 ? 1u : 0u) | (ok1 ? 2u : 0u);
-        }
-        {
-            const int w = w0 + lx, c = 2 * lcp;
-            const bool okw = lcp < CP && w + 3 < W;
-            const bool ok0 = okw && c < ncc, ok1 = okw && c + 1 < ncc;
-            pl0 = ld4(Lrow + (size_t)(cbase + (ok0 ? c : 0)) * HW + (ok0 ? w : 0));
-            pl1 = ld4(Lrow + (size_t)(cbase + (ok1 ? c + 1 : 0)) * HW + (ok1 ? w : 0));
-            okmask |= (ok0 ? 4u : 0u) | (ok1 ? 8u : 0u);
-        }
-    };
-    auto commit = [&](int buf) {
-        float *rs = S0 + buf * BUF, *ls = rs + CP * RS * 2;
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        if (!(okmask & 1u)) pr0 = zero;
-        if (!(okmask & 2u)) pr1 = zero;
-        if (!(okmask & 4u)) pl0 = zero;
-        if (!(okmask & 8u)) pl1 = zero;
-        // layout [pair][plane][quad][4]: plane 0 = pixels (4q, 4q+1) x 2 channels, plane 1 = pixels (4q+2, 4q+3):
-        // every ds_read_b128 of a wave then has a 16-byte lane stride (conflict-free); a 32-byte stride
-        // ([x][2] interleave) costs a 2-way bank conflict on each read.
-        if (rcp < CP) {
-            float *d = rs + rcp * 2 * RS + rx;  // quad rx/4 -> float offset rx
-            *reinterpret_cast<f32x4 *>(d) = (f32x4){pr0[0], pr1[0], pr0[1], pr1[1]};
-            *reinterpret_cast<f32x4 *>(d + RS) = (f32x4){pr0[2], pr1[2], pr0[3], pr1[3]};
-        }
-        if (lcp < CP) {
-            float *d = ls + lcp * 2 * TW + lx;
-            *reinterpret_cast<f32x4 *>(d) = (f32x4){pl0[0], pl1[0], pl0[1], pl1[1]};
-            *reinterpret_cast<f32x4 *>(d + TW) = (f32x4){pl0[2], pl1[2], pl0[3], pl1[3]};
-        }
-    };
-
-    float sm_m[4], sm_s[4], sm_e[4];  // EPI_ARGMIN state
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sm_m[i] = -INFINITY, sm_s[i] = 0.0f, sm_e[i] = 0.0f;
-
-    const int CCH = 2 * CP;                          // channels per item
-    const int nchunk = (CPG + CCH - 1) / CCH;
-    const int npass = (D + NWV * DC - 1) / (NWV * DC);
-    const int per_pass = G * nchunk, per_row = npass * per_pass;
-    const int nitems = nrows * per_row;
-    auto item_loads = [&](int item) {
-        const int r2 = item / per_row, i2 = (item - r2 * per_row) % per_pass;
-        const int g2 = i2 / nchunk, ck2 = i2 - g2 * nchunk;
-        const int c2 = ck2 * CCH;
-        issue_loads(h0 + r2, g2 * CPG + c2, (CPG - c2) < CCH ? (CPG - c2) : CCH);
-    };
-    item_loads(0);
-    commit(0);
-    if (nitems > 1) item_loads(1);
-    __syncthreads();
-
-    f32x2 acc[DC][4];
-    for (int it = 0; it < nitems; ++it) {
-        const int r = it / per_row, ir = it - r * per_row;
-        const int pass = ir / per_pass, ip = ir - pass * per_pass;
-        const int g = ip / nchunk, ck = ip - g * nchunk;
-        const int h = h0 + r;
-        const int c0 = ck * CCH;
-        const int npair = (((CPG - c0) < CCH ? (CPG - c0) : CCH) + 1) >> 1;
-        const int d0 = (pass * NWV + wave) * DC;
-        const bool active = d0 < D;  // wave-uniform
-        if (ck == 0) {
-#pragma unroll
-            for (int dd = 0; dd < DC; ++dd)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[dd][i] = (f32x2){0.f, 0.f};
-        }
-        const float *Rcur = S0 + (it & 1) * BUF, *Lcur = Rcur + CP * RS * 2;
-        if (active) {
-            const float *rwin = Rcur + (Dpad + wl - d0 - DC);  // window origin (quad-aligned pixel index = float offset)
-            const float *lwin = Lcur + wl;
-            for (int cp = 0; cp < npair; ++cp) {
-                f32x2 lv[4], win[DC + 4];
-                {
-                    const f32x4 t0 = *reinterpret_cast<const f32x4 *>(lwin + cp * 2 * TW);
-                    const f32x4 t1 = *reinterpret_cast<const f32x4 *>(lwin + cp * 2 * TW + TW);
-                    lv[0] = (f32x2){t0[0], t0[1]};
-                    lv[1] = (f32x2){t0[2], t0[3]};
-                    lv[2] = (f32x2){t1[0], t1[1]};
-                    lv[3] = (f32x2){t1[2], t1[3]};
-                }
-#pragma unroll
-                for (int q = 0; q < (DC + 4) / 4; ++q) {
-                    const f32x4 t0 = *reinterpret_cast<const f32x4 *>(rwin + cp * 2 * RS + 4 * q);
-                    const f32x4 t1 = *reinterpret_cast<const f32x4 *>(rwin + cp * 2 * RS + RS + 4 * q);
-                    win[4 * q + 0] = (f32x2){t0[0], t0[1]};
-                    win[4 * q + 1] = (f32x2){t0[2], t0[3]};
-                    win[4 * q + 2] = (f32x2){t1[0], t1[1]};
-                    win[4 * q + 3] = (f32x2){t1[2], t1[3]};
-                }
-#pragma unroll
-                for (int dd = 0; dd < DC; ++dd) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc[dd][i] = __builtin_elementwise_fma(lv[i], win[DC + i - dd], acc[dd][i]);
-                }
-            }
-        }
-        if (it + 1 < nitems) commit((it + 1) & 1);  // after the math, before the stores (see the kernel above)
-        if (it + 2 < nitems) item_loads(it + 2);
-        if (ck == nchunk - 1 && active) {  // group finished for this pass: epilogue
-            const int w = w0 + wl;
-            if (EPI == EPI_STORE) {
-                float *vbase = vol + (((size_t)b * G + g) * D) * HW + (size_t)h * W;
-                const bool interior = (w0 >= d0 + DC - 1) && (w0 + TW <= W) && (d0 + DC <= D);  // wave-uniform
-#pragma unroll
-                for (int dd = 0; dd < DC; ++dd) {
-                    const int d = d0 + dd;
-                    f32x4 o;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float sum = acc[dd][i][0] + acc[dd][i][1];
-                        const float m = exact_div ? sum / (float)CPG : sum * inv_cpg;
-                        o[i] = (interior || w + i >= d) ? m : 0.0f;
-                    }
-                    if (interior || (d < D && w + 3 < W)) st4(vbase + (size_t)d * HW + w, o);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float x[DC];
-                    float cm = sm_m[i];
-#pragma unroll
-                    for (int dd = 0; dd < DC; ++dd) {
-                        const float sum = acc[dd][i][0] + acc[dd][i][1];
-                        const float m = exact_div ? sum / (float)CPG : sum * inv_cpg;
-                        x[dd] = (w + i >= d0 + dd) ? sgn * m : sgn * 0.0f;
-                        if (d0 + dd < D) cm = fmaxf(cm, x[dd]);
-                    }
-                    const float sc = (sm_m[i] == cm) ? 1.0f : fast_exp(sm_m[i] - cm);
-                    float ss = sm_s[i] * sc, ee = sm_e[i] * sc;
-#pragma unroll
-                    for (int dd = 0; dd < DC; ++dd)
-                        if (d0 + dd < D) {
-                            const float p = fast_exp(x[dd] - cm);
-                            ss += p;
-                            ee = fmaf(p, (float)(d0 + dd), ee);
-                        }
-                    sm_m[i] = cm, sm_s[i] = ss, sm_e[i] = ee;
-                }
-            }
-        }
-        if (EPI == EPI_ARGMIN && ir == per_row - 1) {  // row finished: combine the waves' softmax states
-            float *stt = S0 + 2 * BUF;                  // [3][NWV][TW], its own LDS region
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                stt[(0 * NWV + wave) * TW + wl + i] = sm_m[i];
-                stt[(1 * NWV + wave) * TW + wl + i] = sm_s[i];
-                stt[(2 * NWV + wave) * TW + wl + i] = sm_e[i];
-                sm_m[i] = -INFINITY, sm_s[i] = 0.0f, sm_e[i] = 0.0f;
-            }
-            __syncthreads();
-            if (tid < TW && w0 + tid < W) {
-                float M = -INFINITY;
-#pragma unroll
-                for (int k = 0; k < NWV; ++k) M = fmaxf(M, stt[(0 * NWV + k) * TW + tid]);
-                float S = 0.0f, E = 0.0f;
-#pragma unroll
-                for (int k = 0; k < NWV; ++k) {
-                    const float mk = stt[(0 * NWV + k) * TW + tid];
-                    const float sc = (mk == -INFINITY) ? 0.0f : fast_exp(mk - M);
-                    S = fmaf(stt[(1 * NWV + k) * TW + tid], sc, S);
-                    E = fmaf(stt[(2 * NWV + k) * TW + tid], sc, E);
-                }
-                vol[((size_t)b * H + h) * W + w0 + tid] = E / S;
-            }
-        }
-        __syncthreads();  // all waves: done reading buffer it&1, buffer (it+1)&1 fully written
-    }
-}
-
-template <int DC, int NWV, int EPI>
-int launch_pk(const float *L, const float *R, float *vol, int B, int C, int H, int W, int D, int G, float sgn,
-              hipStream_t st)
-{
-    const int CPG = C / G;
-    const int Dpad = ((D + DC - 1) / DC) * DC;
-    int CP = (CPG + 1) / 2;                          // channel pairs staged per item
-    if (CP > 4) CP = 4;
-    // staging: one (pair, quad) slot per lane
-    if (CP * ((TW + Dpad) / 4) > NWV * 64 || CP * (TW / 4) > NWV * 64) return STEREO_ERR_UNSUPPORTED;
-    size_t lds = (size_t)2 * CP * (size_t)(TW + Dpad + TW) * 2 * sizeof(float);
-    if (EPI == EPI_ARGMIN) lds += (size_t)3 * NWV * TW * sizeof(float);
-    if (lds > 160 * 1024 || !fits_grid_yz(B)) return STEREO_ERR_UNSUPPORTED;
-    int RB = 4;
-    if (const char *e = getenv("STEREO_VOL_ROWS")) RB = atoi(e) > 0 ? atoi(e) : RB;
-    while (RB > 1 && (long long)((H + RB - 1) / RB) * ((W + TW - 1) / TW) * B < 2048) RB >>= 1;
-    auto kern = gwc_volume_pk_kernel<DC, NWV, EPI>;
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-        return STEREO_ERR_UNSUPPORTED;
-    const bool pow2 = (CPG & (CPG - 1)) == 0;
-    dim3 grid((W + TW - 1) / TW, (H + RB - 1) / RB, (unsigned)B);
-    hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, st, L, R, vol, C, H, W, D, G, CPG, Dpad, CP, 1.0f / (float)CPG,
-                       pow2 ? 0 : 1, sgn, RB);
-    STEREO_LAUNCH_CHECK();
-    return STEREO_OK;
-}
-
-template <int DC, int NWV, int EPI, int WX = 1, int CCM = CCMAX>
 int launch_pipe(const float *L, const float *R, float *vol, int B, int C, int H, int W, int D, int G, float sgn,
                 hipStream_t st, float *aux = nullptr)
 {
     const int CPG = C / G;
     const int Dpad = ((D + DC - 1) / DC) * DC;
-    constexpr int TWG = TW * WX, NST = NWV / WX;  // pixels per workgroup, disparity strips per workgroup
-    const int CC = CPG < CCM ? CPG : CCM;
-    size_t lds = (size_t)2 * CC * (size_t)(TWG + Dpad + TWG) * sizeof(float);  // two staging buffers
-    if (EPI != EPI_STORE) lds += (size_t)3 * NWV * TW * sizeof(float);           // + softmax-state exchange
-    int RB = 4;                                                                  // rows per workgroup
-    if (const char *e = getenv("STEREO_VOL_ROWS")) RB = atoi(e) > 0 ? atoi(e) : RB;
-    while (RB > 1 && (long long)((H + RB - 1) / RB) * ((W + TWG - 1) / TWG) * B * ((D + NST * DC - 1) / (NST * DC)) < 2048)
-        RB >>= 1;                                                                // keep >= 8 workgroups per CU
-    const int nparts = (D + NST * DC - 1) / (NST * DC);
+    const int CC = CPG < CCMAX ? CPG : CCMAX;
+    size_t lds = (size_t)2 * CC * (size_t)(TW + Dpad + TW) * sizeof(float);  // two staging buffers
+    if (EPI != EPI_STORE) lds += (size_t)3 * NWV * TW * sizeof(float);         // + softmax-state exchange
+    int RB = 4;                                                                // rows per workgroup
+    while (RB > 1 && (long long)((H + RB - 1) / RB) * ((W + TW - 1) / TW) * B * ((D + NWV * DC - 1) / (NWV * DC)) < 2048)
+        RB >>= 1;                                                              // keep >= 8 workgroups per CU
+    const int nparts = (D + NWV * DC - 1) / (NWV * DC);
     if (Dpad > 256 || lds > 160 * 1024 || !fits_grid_yz((long long)B * nparts) || (EPI != EPI_STORE && nparts != 1))
         return STEREO_ERR_UNSUPPORTED;
     if ((long long)CCMAX * H * W + W >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;  // 32-bit per-slot offsets
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(gwc_volume_pipe_kernel<DC, NWV, EPI, WX, CCM>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return STEREO_ERR_UNSUPPORTED;
+    static std::atomic<unsigned long long> lds_done{0};
+    if (!lds_opt_in(gwc_volume_pipe_kernel<DC, NWV, EPI>, lds, lds_done)) return STEREO_ERR_UNSUPPORTED;
     const bool pow2 = (CPG & (CPG - 1)) == 0;
-    int nt = 0;
-    if (const char *e = getenv("STEREO_VOL_NT")) nt = atoi(e);
-    dim3 pgrid((W + TWG - 1) / TWG, (H + RB - 1) / RB, (unsigned)(B * nparts));
-    hipLaunchKernelGGL((gwc_volume_pipe_kernel<DC, NWV, EPI, WX, CCM>), pgrid, dim3(NWV * 64), lds, st, L, R, vol, aux, C, H, W, D,
-                       G, CPG, Dpad, CC, 1.0f / (float)CPG, pow2 ? 0 : 1, sgn, nparts, RB, nt);
+    dim3 pgrid((W + TW - 1) / TW, (H + RB - 1) / RB, (unsigned)(B * nparts));
+    hipLaunchKernelGGL((gwc_volume_pipe_kernel<DC, NWV, EPI>), pgrid, dim3(NWV * 64), lds, st, L, R, vol, aux, C, H, W, D,
+                       G, CPG, Dpad, CC, 1.0f / (float)CPG, pow2 ? 0 : 1, sgn, nparts, RB);
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }
 
-// Pipelined-path configuration (DC disparities per wave, NWV waves per workgroup).
+// Pipelined-path configuration (DC disparities per wave, NWV waves per workgroup), measured on MI355X at cfg-2:
+// (16, 12) is the fastest for both epilogues; (8, 8) for short disparity ranges.
 template <int EPI>
 int pipe_dispatch(const float *L, const float *R, float *vol, int B, int C, int H, int W, int D, int G, float sgn,
                   hipStream_t st)
 {
-    int dc = 0, nw = 0;
-    if (const char *e = getenv("STEREO_VOL_CFG")) sscanf(e, "%d,%d", &dc, &nw);  // tuning knob (dev only)
-    if constexpr (EPI == EPI_STORE) {
-        // whole-row workgroups (4 waves side by side): opt-in.  As a pure store stream whole rows reach 6.1 TB/s
-        // against 5.6 for 1-KiB pieces, but the real kernel got SLOWER with it at cfg-2 (5.97 vs 5.42 ms in one
-        // A/B run): four disparity parts re-stage the features four times and the 48-plane workgroups overlap less.
-        // Two waves side by side (2-KiB pieces, STEREO_VOL_WX=2) measured equal to the default.
-        int wide = 0;
-        if (const char *e = getenv("STEREO_VOL_WX")) wide = atoi(e);
-        if (wide == 4 || wide == 2) {
-            const int rc = wide == 4 ? launch_pipe<16, 12, EPI, 4, 4>(L, R, vol, B, C, H, W, D, G, sgn, st)
-                                     : launch_pipe<16, 12, EPI, 2, 4>(L, R, vol, B, C, H, W, D, G, sgn, st);
-            if (rc != STEREO_ERR_UNSUPPORTED) return rc;
-        }
-    }
-    if (dc == 0) {  // measured on MI355X at cfg-2 (tools/vol_sweep.sh): (16,12) is the fastest for both epilogues
-        if (D <= 64) dc = 8, nw = 8;
-        else dc = 16, nw = 12;
-    }
-#define PK_CASE(DCV, NWVV) \
-    if (dc == -DCV && nw == NWVV) return launch_pk<DCV, NWVV, EPI>(L, R, vol, B, C, H, W, D, G, sgn, st)
-    PK_CASE(8, 12);   // negative dc selects the channel-pair packed kernel
-    PK_CASE(8, 8);
-    PK_CASE(12, 8);
-    PK_CASE(12, 16);
-    PK_CASE(16, 12);
-    PK_CASE(16, 8);
-#undef PK_CASE
-#define PIPE_CASE(DCV, NWVV) \
-    if (dc == DCV && nw == NWVV) return launch_pipe<DCV, NWVV, EPI>(L, R, vol, B, C, H, W, D, G, sgn, st)
-    PIPE_CASE(8, 8);
-    PIPE_CASE(12, 8);
-    PIPE_CASE(16, 6);
-    PIPE_CASE(16, 8);
-    PIPE_CASE(16, 12);
-    PIPE_CASE(24, 8);
-#undef PIPE_CASE
-    return STEREO_ERR_UNSUPPORTED;
+    if (D <= 64) return launch_pipe<8, 8, EPI>(L, R, vol, B, C, H, W, D, G, sgn, st);
+    return launch_pipe<16, 12, EPI>(L, R, vol, B, C, H, W, D, G, sgn, st);
 }
 
 template <int DC, int EPI>
@@ -801,11 +502,8 @@ int launch_gwc(const float *L, const float *R, float *vol, int B, int C, int H, 
     const bool vec = (W % 4 == 0) && aligned16(L) && aligned16(R) && aligned16(vol);
     dim3 grid((W + TW - 1) / TW, H, (unsigned)(B * G));
     auto kern = vec ? gwc_volume_kernel<DC, true, EPI> : gwc_volume_kernel<DC, false, EPI>;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return STEREO_ERR_UNSUPPORTED;
-    }
+    static std::atomic<unsigned long long> lds_done[2] = {{0}, {0}};
+    if (!lds_opt_in(kern, lds, lds_done[vec ? 1 : 0])) return STEREO_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, L, R, vol, C, H, W, D, G, CPG, Dpad, CC, 1.0f / (float)CPG,
                        pow2 ? 0 : 1, sgn);
     STEREO_LAUNCH_CHECK();
@@ -956,11 +654,7 @@ int shift_dispatch(const float *L, const float *R, float *vol, int B, int C, int
 
 }  // namespace
 
-static bool corr_mfma_enabled()
-{
-    const char *e = getenv("STEREO_CORR_MFMA");  // dev/test knob: "0" forces the VALU kernels
-    return !(e && e[0] == '0');
-}
+static bool corr_mfma_enabled() { return stereo_opt(OPT_CORR_MFMA) != 0; }
 
 extern "C" int stereo_corr_volume_f32(const float *left, const float *right, float *vol, int B, int C, int H, int W,
                                       int D, void *stream)
@@ -1035,7 +729,7 @@ extern "C" int stereo_gwc_volume_soft_argmin_f32(const float *left, const float 
 {
     if (D == 0 && B > 0 && H > 0 && W > 0) return STEREO_ERR_BAD_SHAPE;
     if (B > 0 && C > 0 && H > 0 && W > 0 && G > 0 && left && right && vol && mean && disp && corr_mfma_enabled() &&
-        !getenv("STEREO_GWC_UNFUSED")) {  // one kernel for the whole volume stage where its envelope allows
+        stereo_opt(OPT_GWC_FUSED) != 0) {  // one kernel for the whole volume stage where its envelope allows
         const int rcf = stereo_gwc_mean_argmin_mfma(left, right, vol, mean, disp, B, C, H, W, D, G,
                                                     match_similarity ? 1.0f : -1.0f, as_stream(stream));
         if (rcf != STEREO_ERR_UNSUPPORTED) return rcf;

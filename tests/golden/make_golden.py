@@ -11,7 +11,8 @@ never copied.  Usage:
 Fixture groups follow SURVEY.md section 8(c): G1 volumes (A1/A2/A3), G2 soft-argmin
 (A4), G3 local lookups (A5/A6), G4 RAFT correlation (A8/A9/A10), G5 GRU local
 updater (A11), G6 disp_warp (A12), G7 convex upsample (A13), G8 RAFT update
-block (A14), G9 the RAFT_Stereo hot loop end to end (A8+A9+A13+A14+A15).
+block (A14), G9 the RAFT_Stereo hot loop end to end (A8+A9+A13+A14+A15), G13 the same loop started from `flow_init`
+plus InputPadder values.
 """
 import contextlib
 import io
@@ -507,6 +508,63 @@ def g12_raft_backward():
 
 
 # ------------------------------------------------------------------ cfg-1 check
+# ------------------------------------------------------------------ G13
+def g13_flow_init_padder():
+    """(a) RAFT_Stereo started from a given disparity field (`flow_init`, raft_stereo.py:163-164), 3 iterations, test_mode;
+    the tensors the extractors hand to the hot loop are captured as in G9.  (b) InputPadder.pad / .unpad VALUES
+    (utils/utils.py:7-26), both modes, divis_by 8 and 32."""
+    import types
+    t = types.ModuleType("turtle"); t.left = t.right = None; sys.modules["turtle"] = t
+    sys.argv = ["x"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        from models.IterativeLocalCostVolume import raft_stereo as RS
+    from models.IterativeLocalCostVolume.utils.utils import InputPadder
+    torch.manual_seed(1301)
+    model = RS.RAFT_Stereo(hidden_dim=[32, 32, 32]).eval()
+    fill_state_dict_(model, seed=0.125)
+    cap = {}
+    orig_init = RS.CorrBlock1D.__init__
+
+    def rec_init(self, fmap1, fmap2, num_levels=4, radius=4):
+        cap["fmap1"], cap["fmap2"] = fmap1.clone(), fmap2.clone()
+        orig_init(self, fmap1, fmap2, num_levels=num_levels, radius=radius)
+
+    RS.CorrBlock1D.__init__ = rec_init
+
+    def pre_hook(mod, args, kwargs):
+        if "net" not in cap:
+            cap["net"] = [n.clone() for n in args[0]]
+            cap["inp"] = [[c.clone() for c in lvl] for lvl in args[1]]
+
+    hk = model.update_block.register_forward_pre_hook(pre_hook, with_kwargs=True)
+    left = torch.rand(1, 3, 64, 96) * 255
+    right = torch.rand(1, 3, 64, 96) * 255
+    flow_init = torch.zeros(1, 2, 16, 24)
+    flow_init[:, 0] = -6.0 * torch.rand(1, 16, 24)        # negative x-flow = positive disparity (SURVEY 9.1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        flow_lo, flow_up = model(left, right, iters=3, flow_init=flow_init, test_mode=True)
+    hk.remove()
+    RS.CorrBlock1D.__init__ = orig_init
+    out = {"fmap1": npy(cap["fmap1"]), "fmap2": npy(cap["fmap2"]), "flow_init": npy(flow_init), "flow_lo": npy(flow_lo),
+           "flow_up": npy(flow_up)}
+    for i in range(3):
+        out[f"net{i}"] = npy(cap["net"][i])
+        for j in range(3):
+            out[f"inp{i}{j}"] = npy(cap["inp"][i][j])
+    x = torch.randn(2, 3, 37, 50)
+    out["pad_x"] = npy(x)
+    for mode in ("sintel", "kitti"):
+        for div in (8, 32):
+            p = InputPadder(x.shape, mode=mode, divis_by=div)
+            (xp,) = p.pad(x)
+            out[f"pad_{mode}_{div}"] = npy(xp)
+            out[f"unpad_{mode}_{div}"] = npy(p.unpad(xp))
+    p = InputPadder((1, 3, 540, 960), divis_by=32)          # cfg-4: 540 -> 544
+    (xp,) = p.pad(x[:1, :, :4, :8].repeat(1, 1, 135, 120))
+    out["pad_540x960_rows"] = npy(xp[0, 0, [0, 1, 2, 541, 542, 543], :16])
+    save("g13_flow_init_padder", **out)
+
+
 def check_oracle_cfg1():
     """Not a fixture: proves the C oracle == the reference at BASELINE
     configs[0] (1 pair 384x768 D=64: corr -> soft-argmin -> local lookup)."""
@@ -543,5 +601,6 @@ if __name__ == "__main__":
     g10_metrics_io()
     g11_backward()
     g12_raft_backward()
+    g13_flow_init_padder()
     if CHECK:
         check_oracle_cfg1()

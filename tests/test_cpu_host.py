@@ -78,6 +78,24 @@ def test_host_helpers_cpu():
     assert yp.shape[-2:] == (384, 1248)
 
 
+def test_input_padder_values_golden(golden):
+    """InputPadder.pad / .unpad VALUES against the reference's (utils/utils.py:7-26): both modes, divis_by 8 and 32."""
+    import stereoformer_amd as S
+    g = golden("g13_flow_init_padder")
+    x = torch.from_numpy(g["pad_x"])
+    for mode in ("sintel", "kitti"):
+        for div in (8, 32):
+            p = S.InputPadder(x.shape, mode=mode, divis_by=div)
+            (xp,) = p.pad(x)
+            assert np.array_equal(xp.numpy(), g[f"pad_{mode}_{div}"])
+            assert np.array_equal(p.unpad(xp).numpy(), g[f"unpad_{mode}_{div}"])
+            assert xp.shape[-2] % div == 0 and xp.shape[-1] % div == 0
+    p = S.InputPadder((1, 3, 540, 960), divis_by=32)
+    (xp,) = p.pad(x[:1, :, :4, :8].repeat(1, 1, 135, 120))
+    assert xp.shape[-2:] == (544, 960)
+    assert np.array_equal(xp[0, 0, [0, 1, 2, 541, 542, 543], :16].numpy(), g["pad_540x960_rows"])
+
+
 def test_pair_slices_cover_everything():
     from stereoformer_amd.shard import pair_slice, shard_sizes
     for total in (0, 1, 7, 8, 64):
@@ -151,3 +169,18 @@ def test_bench_launches_its_own_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-cpu"], env=env2,
                         capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert r2.returncode != 0
+
+
+def test_library_reads_no_environment_and_keeps_no_mutable_globals():
+    """The header's contract: no environment knobs in launch paths, process-wide data limited to atomics (test hooks and
+    the once-per-device LDS opt-in)."""
+    csrc = os.path.join(ROOT, "stereoformer_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        txt = open(os.path.join(csrc, f)).read()
+        assert "getenv" not in txt, f
+        for m in re.finditer(r"^\s*static\s+(?!inline|const|constexpr|__device__|std::atomic)(\w[\w:<> ]*)\s+\w+.*[;=]", txt, flags=re.M):
+            assert "(" in m.group(0).split("=")[0], f"{f}: mutable static: {m.group(0).strip()}"
+    from stereoformer_amd import _native
+    lib = _native.load()
+    assert lib.stereo_test_option(b"corr_mfma", 0) == 0 and lib.stereo_test_option(b"corr_mfma", -1) == 0
+    assert lib.stereo_test_option(b"no_such_option", 1) == -2

@@ -297,7 +297,7 @@ def test_fused_volume_stage_backward_matches_composition(S):
 
 @pytest.mark.parametrize("shape", [(1, 32, 3, 960, 192), (2, 12, 4, 520, 150), (1, 6, 5, 260, 97), (2, 32, 2, 300, 64),
                                    (1, 5, 2, 36, 7), (1, 8, 2, 16, 16), (1, 3, 2, 8, 1), (1, 8, 2, 64, 100)])
-def test_corr_volume_backward_mfma_vs_valu_vs_torch(S, shape, monkeypatch):
+def test_corr_volume_backward_mfma_vs_valu_vs_torch(S, shape):
     """A1 backward on the matrix cores (gradient rows read along the sheet's diagonals; dR in mirrored / sheared
     coordinates) against the VALU backward and against torch autograd of the shifted-product formula."""
     B, C, H, W, D = shape
@@ -306,10 +306,10 @@ def test_corr_volume_backward_mfma_vs_valu_vs_torch(S, shape, monkeypatch):
     cot = torch.randn(B, D, H, W, device="cuda")
     got = {}
     for mfma in ("1", "0"):
-        monkeypatch.setenv("STEREO_CORR_MFMA", mfma)
-        L, R = L0.clone().requires_grad_(True), R0.clone().requires_grad_(True)
-        vol = S.CostVolume(D)(L, R)
-        got[mfma] = torch.autograd.grad((vol * cot).sum(), [L, R])
+        with S._native.test_options(corr_mfma=int(mfma)):
+            L, R = L0.clone().requires_grad_(True), R0.clone().requires_grad_(True)
+            vol = S.CostVolume(D)(L, R)
+            got[mfma] = torch.autograd.grad((vol * cot).sum(), [L, R])
     Lr, Rr = L0.clone().requires_grad_(True), R0.clone().requires_grad_(True)
     ref = torch.zeros(B, D, H, W, device="cuda")
     planes = []

@@ -210,3 +210,94 @@ def test_lowcnn_gru_loop_graph_matches_eager(S):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in loop.parameters())
     assert len(eager) == 6 and len(graphed) == 1
     assert (eager[-1] - graphed[0]).abs().max().item() < 1e-4
+
+
+def test_raft_loop_flow_init_g13(S, golden):
+    """The loop started from a given disparity field (`flow_init`, raft_stereo.py:163-164) against the reference
+    RAFT_Stereo run the same way (golden G13), eager and as a HIP-graph replay."""
+    g = golden("g13_flow_init_padder")
+    loop = S.RAFTStereoLoop(hidden_dims=[32, 32, 32]).eval()
+    fill_state_dict_(loop.update_block, seed=0.125, keys=list(golden("g9_raft_loop")["keys"]), prefix="update_block.")
+    loop = loop.cuda()
+    with torch.no_grad():
+        f1, f2, net, inp = _raft_inputs(g)
+        flow_lo, flow_up = loop(f1, f2, net, inp, iters=3, flow_init=dev(g["flow_init"]), test_mode=True)
+        close(flow_lo, g["flow_lo"], rtol=1e-4, atol=1e-3)
+        close(flow_up, g["flow_up"], rtol=1e-4, atol=2e-3)
+        assert float(np.abs(flow_up.cpu().numpy() - g["flow_up"]).mean()) < 2e-4
+        f1, f2, net, inp = _raft_inputs(g)
+        lo_g, up_g = loop(f1, f2, net, inp, iters=3, flow_init=dev(g["flow_init"]), test_mode=True, use_graph=True)
+    assert (lo_g - flow_lo).abs().max().item() < 5e-5 and (up_g - flow_up).abs().max().item() < 1e-4
+    # and without flow_init the result differs (the argument is not ignored)
+    with torch.no_grad():
+        f1, f2, net, inp = _raft_inputs(g)
+        lo0, _ = loop(f1, f2, net, inp, iters=3, test_mode=True)
+    assert (lo0 - flow_lo).abs().max().item() > 1e-2
+
+
+def _loop_inputs(B, Hq, Wq, seed):
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=gen)
+    f1 = rn(B, 256, Hq, Wq)
+    f2 = torch.roll(f1, 5, 3) + 0.1 * rn(B, 256, Hq, Wq)
+    nets = [torch.tanh(rn(B, 128, Hq >> i, Wq >> i)) for i in range(3)]
+    inps = [[rn(B, 128, Hq >> i, Wq >> i) for _ in range(3)] for i in range(3)]
+    return f1, f2, nets, inps
+
+
+def _check_final_iterate(S, oracle, loop, f1, f2, nets, inps, iters, flow_init=None):
+    """Runs the loop eagerly and as a graph replay; checks graph == eager, and the custom ops of the LAST iteration against
+    the oracle fed the loop's own tensors: the pyramid lookup at the final coordinates and the convex upsampling of the
+    final flow with the final mask."""
+    cap = {}
+
+    def hook(mod, args, kwargs, out):
+        cap["corr"], cap["flow"], cap["mask"] = args[2], args[3], out[1]
+
+    hk = loop.update_block.register_forward_hook(hook, with_kwargs=True)
+    with torch.no_grad():
+        flow_lo, flow_up = loop(f1, f2, [n.clone() for n in nets], inps, iters=iters, flow_init=flow_init, test_mode=True)
+    hk.remove()
+    assert torch.isfinite(flow_lo).all() and torch.isfinite(flow_up).all()
+    assert float(flow_lo[:, 1].abs().max()) == 0.0               # raft_stereo.py:180: the y component never moves
+    with torch.no_grad():
+        lo_g, up_g = loop(f1, f2, [n.clone() for n in nets], inps, iters=iters, flow_init=flow_init, test_mode=True,
+                          use_graph=True)
+    # 16 iterations amplify the ulp-level differences of MIOpen's algorithm choice in the graph's warm-up
+    assert (lo_g - flow_lo).abs().max().item() < 2e-3 and (up_g - flow_up).abs().max().item() < 8e-3
+    B, _, Hq, Wq = f1.shape
+    # A8 + A9 at the coordinates the last update block saw: coords0 + flow fed to it
+    coords0 = S.coords_grid(B, Hq, Wq, device="cuda")
+    coords_last = (coords0 + cap["flow"].float()).cpu().numpy()
+    pyr = oracle.corr_pyramid(oracle.allpairs_corr(f1.cpu().numpy(), f2.cpu().numpy()), 4)
+    ref_corr = oracle.corr_lookup(pyr, coords_last, 4, 4)
+    close(cap["corr"].float(), ref_corr, rtol=1e-4, atol=2e-4)
+    # A13 on the final iterate
+    ref_up = oracle.upsample_convex(flow_lo.cpu().numpy(), cap["mask"].float().cpu().numpy(), 4)[:, :1]
+    close(flow_up, ref_up, rtol=1e-5, atol=1e-4)
+    return flow_lo, flow_up
+
+
+def test_raft_loop_16_iterations_full_size(S, oracle):
+    """cfg-4 per-GPU geometry, two pairs: 16 iterations at [2,256,136,240] (544x960 / 4): graph == eager, final lookup and
+    final convex upsampling against the oracle."""
+    torch.manual_seed(4)
+    loop = S.RAFTStereoLoop([128, 128, 128], channels_last=True).eval().cuda()
+    f1, f2, nets, inps = _loop_inputs(2, 136, 240, 41)
+    _check_final_iterate(S, oracle, loop, f1, f2, nets, inps, 16)
+
+
+def test_cfg5_attention_flow_init_loop_chain(S, oracle):
+    """cfg-5 chain at one full-height pair: cross-attention at 1/4 resolution [1,256,96,312] (band 64, mask 'neginf') against
+    the oracle -> initial flow (-disp, 0) -> 16-iteration loop: graph == eager, final lookup / upsampling against the oracle."""
+    torch.manual_seed(5)
+    loop = S.RAFTStereoLoop([128, 128, 128], channels_last=True).eval().cuda()
+    f1, f2, nets, inps = _loop_inputs(1, 96, 312, 51)
+    f1, f2 = f1 * 0.25, f2 * 0.25                                # logits O(1) at C = 256 / sqrt(C) scaling
+    _, d = S.CrossAttentionCostVolume(64, "neginf", "sqrt_c")(f1, f2, need_out=False)
+    _, od = oracle.cross_attention(f1.cpu().numpy(), f2.cpu().numpy(), None, 64, "neginf", "sqrt_c")
+    close(d, od, rtol=0, atol=1e-3)
+    assert float(np.abs(d.cpu().numpy() - od).mean()) < 2.5e-4
+    init = torch.cat([-d.unsqueeze(1), torch.zeros_like(d.unsqueeze(1))], 1)
+    lo, _ = _check_final_iterate(S, oracle, loop, f1, f2, nets, inps, 16, flow_init=init)
+    assert (lo[:, :1] + d.unsqueeze(1)).abs().mean().item() < 50   # the loop moved from, not ignored, its start
