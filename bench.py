@@ -49,6 +49,9 @@ def parse_args(argv=None):
                          "NOT a valid measurement -- the ranks share one GPU; N <= 6)")
     ap.add_argument("--rehearse-on-cpu", action="store_true",
                     help="launcher / sharding / reduction plumbing only, over gloo, no GPU work at all (CPU tests)")
+    ap.add_argument("--fp16-features", action="store_true",
+                    help="hand the features over in fp16 (SURVEY 8(f) N2: widened on the way into LDS, fp32 arithmetic and "
+                         "outputs); NOT the headline configuration -- the reference's features are fp32")
     ap.add_argument("--reread", action="store_true",
                     help="group-mean + soft-argmin by re-reading the 25.5 GB volume (the pre-fusion chain)")
     return ap.parse_args(argv)
@@ -239,6 +242,9 @@ def main():
     S._native.load()
     lookup = S.LocalCostVolume(radius=2, sample_points=20)
     L, R = synth_pairs(B_PER_GPU, 1234 + rank, device)
+    if args.fp16_features:
+        L, R = L.half(), R.half()
+    feat_bytes = L.element_size()
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     ev_read = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -326,6 +332,11 @@ def main():
                     float((volg[b_, :, :, r_].mean(0) - mean_f[b_, :, r_]).abs().max().item())
                     for b_ in (0, B_PER_GPU - 1) for r_ in (0, H // 2, H - 1))
                 del volg, mean_f
+            if not args.fp16_features:   # N2: the same launch fed fp16 features (half the read side)
+                Lh, Rh = L.half(), R.half()
+                other["volume_stage_fused_fp16_features"] = t5(lambda: S.build_gwc_volume_with_disparity(Lh, Rh, D, G, return_mean=True))
+                other["fused_corr_soft_argmin_no_volume_fp16_features"] = t5(lambda: S.corr_soft_argmin(Lh, Rh, D))
+                del Lh, Rh
             other["gwc_volume_alone"] = t5(lambda: S.build_gwc_volume(L, R, D, G))
             other["mean_volume_soft_argmin_from_features"] = t5(lambda: S.corr_volume_with_disparity(L, R, D))
             if not args.reread:
@@ -336,7 +347,7 @@ def main():
     res = None
     if rank == 0:
         n_pix = B_PER_GPU * H * W
-        gwc_bytes = 2 * n_pix * C * 4 + n_pix * G * D * 4  # A3 = 26.54 GB
+        gwc_bytes = 2 * n_pix * C * feat_bytes + n_pix * G * D * 4  # A3 = 26.54 GB
         if not args.reread:
             gwc_bytes += n_pix * D * 4 + n_pix * 4         # + mean volume (8(d): A1's N*D*4) + disparity = 29.74 GB
         traffic, traffic_source = None, None  # HBM bytes per launch: NOT observed in this run -- read from the committed PMC passes
@@ -367,7 +378,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if not args.fp16_features else "f32 arithmetic and outputs, fp16 feature operands (N2; not the headline)",
             "data": "synthetic" if not args.rehearse_on_one_gpu else "synthetic (REHEARSAL: all ranks share cuda:0 over gloo; not a measurement)",
             "config": {"workload": "cfg-2: SceneFlow 960x540 D=192 group-wise (G=8,C=32) LocalCostVolume + soft-argmin, "
                                    "batch=8 per GPU, all reference-API intermediates materialised"

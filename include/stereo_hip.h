@@ -8,7 +8,8 @@
  * would add on the reference side is in INTEGRATION.md.
  *
  * Conventions
- *   - all tensors fp32, contiguous NCHW, DEVICE pointers owned by the caller;
+ *   - all tensors fp32, contiguous NCHW, DEVICE pointers owned by the caller (the `_f16` entry points at the end take
+ *     their FEATURE operands in fp16; outputs are fp32 everywhere);
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*;
  *     NULL = the default stream); no internal sync, no allocation, no state
  *     carried between calls (the only process-wide data are the test hooks of
@@ -43,8 +44,8 @@ int stereo_abi_version(void);
 const char *stereo_strerror(int code);
 
 /* TEST HOOK, not part of the product contract: steers which kernel serves the following calls so that the test-suite
- * can run a fallback kernel on a shape the fast path would take ("corr_mfma" 0/1, "gwc_fused" 0/1, "att_kernel" 0/2/4,
- * "att_waves" 0/4/8, "prob_single_pass" 0/1) or make small inputs walk the persistent multi-tile loops
+ * can run a fallback kernel on a shape the fast path would take ("corr_mfma" 0/1, "gwc_fused" 0/1, "att_kernel" 0/2/4/6,
+ * "att_waves" 0/4/5/8, "prob_single_pass" 0/1) or make small inputs walk the persistent multi-tile loops
  * ("tiles_per_wg" n).  Process-wide atomics; value < 0 restores the default.  The library reads no environment
  * variable.  Returns STEREO_ERR_BAD_SHAPE for an unknown name. */
 int stereo_test_option(const char *name, int value);
@@ -246,6 +247,42 @@ int stereo_allpairs_pyramid_bwd_f32(const float *fmap1, const float *fmap2, floa
 /* backward of the bilinear resize; grad_in must be zero-filled */
 int stereo_resize_bilinear_bwd_f32(const float *grad_out, float *grad_in_zeroed, int NC, int Hi, int Wi, int Ho, int Wo,
                                    int align_corners, float scale, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * N2: feature hand-over in fp16 + the extractor's fused norm epilogue.
+ * Reference sites: the fnet output under autocast is fp16 and is widened by `.float()` before the correlation
+ * block (models/IterativeLocalCostVolume/raft_stereo.py:155-156); InstanceNorm2d + ReLU close the extractor stages
+ * (models/IterativeLocalCostVolume/extractor/extractor.py:135,160-162,187-188); LowCNN hands [B,C,H/8,W/8]
+ * features to CostVolume (models/LocalCostVolume/baseline.py:89-114).
+ *
+ * `_f16` entry points: feature operands are fp16 [B,C,H,W] (const void *), every output is fp32.  The matrix-core
+ * kernels widen the features on the way into LDS: same fp32 arithmetic on the fp16-rounded values, half the read
+ * bytes.  They cover the matrix-core envelope only (W % 4 == 0, 8-byte aligned bases; volumes: C <= 32, D <= 256
+ * (192 for the group-wise forms), channels per group in {2,4,8,16}; attention: D <= 192 for C > 32) and return
+ * STEREO_ERR_UNSUPPORTED outside it -- there is no slow fp16 path; the caller widens and uses the fp32 entry point. */
+int stereo_corr_volume_f16(const void *left, const void *right, float *vol,
+                           int B, int C, int H, int W, int D, void *stream);
+int stereo_gwc_volume_f16(const void *left, const void *right, float *vol,
+                          int B, int C, int H, int W, int D, int G, void *stream);
+int stereo_corr_soft_argmin_f16(const void *left, const void *right, float *disp,
+                                int B, int C, int H, int W, int D, int match_similarity, void *stream);
+int stereo_corr_volume_soft_argmin_f16(const void *left, const void *right, float *vol, float *disp,
+                                       int B, int C, int H, int W, int D, int match_similarity, void *stream);
+int stereo_gwc_volume_soft_argmin_f16(const void *left, const void *right, float *vol, float *mean, float *disp,
+                                      int B, int C, int H, int W, int D, int G, int match_similarity, void *stream);
+int stereo_cross_attention_f16(const void *left, const void *right, const void *value, float *out, float *disp,
+                               int B, int C, int Cv, int H, int W, int D, int mask_mode, int scale_mode, void *stream);
+int stereo_allpairs_pyramid_f16(const void *fmap1, const void *fmap2, float *const *levels,
+                                int B, int C, int H, int W1, int W2, int num_levels, void *stream);
+
+/* nn.InstanceNorm2d(C, eps, affine) [+ ReLU] in one call (extractor.py:135 + :187-188): x [B,C,H,W] fp32 ->
+ * out [B,C,H,W] fp32 (out_is_f16 = 0) or fp16 (1), the layout the `_f16` loaders above take.  gamma / beta [C] or NULL
+ * (affine=False, the nn.InstanceNorm2d default).  Biased variance over H*W, eps inside the square root.
+ * workspace: stereo_instance_norm_workspace_bytes(B, C) bytes of device memory, 8-byte aligned, caller-owned (it is
+ * zeroed on the stream by the call).  H*W % 4 == 0 and aligned bases, else STEREO_ERR_UNSUPPORTED. */
+long long stereo_instance_norm_workspace_bytes(int B, int C);
+int stereo_instance_norm_relu_f32(const float *x, const float *gamma, const float *beta, void *out, void *workspace,
+                                  int out_is_f16, int B, int C, int H, int W, float eps, int relu, void *stream);
 
 #ifdef __cplusplus
 }

@@ -279,3 +279,15 @@ def gru_reset(h, rc, cr=None):
     out = np.empty_like(h)
     load().oracle_gru_reset(_p(h), _p(rc), _p(cr) if cr is not None else None, _p(out), _ll(h.size))
     return out
+
+
+# --------------------------------------------------------------- extractor epilogue (N2)
+def instance_norm_relu(x, gamma=None, beta=None, eps=1e-5, relu=True):
+    x = _c(x)
+    B, C, H, W = x.shape
+    g = None if gamma is None else _c(gamma)
+    b = None if beta is None else _c(beta)
+    out = np.empty_like(x)
+    load().oracle_instance_norm_relu(_p(x), _p(g) if g is not None else None, _p(b) if b is not None else None, _p(out),
+                                     _i(B), _i(C), _i(H), _i(W), ctypes.c_float(eps), _i(int(relu)))
+    return out

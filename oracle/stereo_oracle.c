@@ -730,3 +730,36 @@ void oracle_gru_reset(const float *h, const float *rc, const float *cr, float *o
         out[i] = r * h[i];
     }
 }
+
+/* ------------------------------------------------------------------ N2 --
+ * nn.InstanceNorm2d(C, eps, affine) followed by ReLU, as the reference's extractors apply them
+ * (models/IterativeLocalCostVolume/extractor/extractor.py:135 norm1 = nn.InstanceNorm2d(64), :187-188
+ * x = self.norm1(x); x = self.relu1(x); ResidualBlock :38-41,63-64).  Per (b, c) plane: biased variance over
+ * H*W, y = (x - mean) / sqrt(var + eps) * gamma + beta, then max(y, 0) when relu.  gamma / beta may be NULL.
+ * Statistics in double (torch accumulates its float plane sums in a cascade; both agree to ~1e-6). */
+void oracle_instance_norm_relu(const float *x, const float *gamma, const float *beta, float *out,
+                               int B, int C, int H, int W, float eps, int relu)
+{
+    const size_t HW = (size_t)H * W;
+#pragma omp parallel for schedule(static)
+    for (long long p = 0; p < (long long)B * C; ++p) {
+        const float *xp = x + (size_t)p * HW;
+        float *op = out + (size_t)p * HW;
+        double s = 0.0, ss = 0.0;
+        for (size_t i = 0; i < HW; ++i) s += xp[i];
+        const double mean = s / (double)HW;
+        for (size_t i = 0; i < HW; ++i) {
+            const double d = (double)xp[i] - mean;
+            ss += d * d;
+        }
+        const double var = ss / (double)HW;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const int c = (int)(p % C);
+        const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+        for (size_t i = 0; i < HW; ++i) {
+            float y = ((xp[i] - (float)mean) * rstd) * g + b;
+            if (relu && y < 0.0f) y = 0.0f;
+            op[i] = y;
+        }
+    }
+}

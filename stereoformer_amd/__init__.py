@@ -18,6 +18,7 @@ from .corr import (AlternateCorrBlock, CorrBlock1D, InputPadder, PytorchAlternat
                    coords_grid)
 from .cross_attention import CrossAttentionCostVolume
 from .disparity_warper import disp_warp
+from .extractor_epilogue import InstanceNormReLU, instance_norm_relu
 from .metrics import D1_metric, EPE_Loss, P1_metric, scale_disp, sequence_loss, thres_metric
 from .pfm import read_disp, read_pfm, write_pfm
 from .pipelines import LowCNNGRULoop, RAFTStereoLoop
@@ -28,6 +29,7 @@ from .upsample import (ConvAffinityUpsample, interp, resize_bilinear, upflow8, u
                        upsample_flow, upsample_simple8)
 
 __all__ = [
+    "InstanceNormReLU", "instance_norm_relu",
     "D1_metric", "EPE_Loss", "P1_metric", "scale_disp", "sequence_loss", "thres_metric", "read_disp", "read_pfm",
     "write_pfm",
     "LowCNNGRULoop", "RAFTStereoLoop",

@@ -50,6 +50,15 @@ SIGNATURES = {
     "stereo_upsample_convex_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_resize_bilinear_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "stereo_cross_attention_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_cross_attention_f16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_corr_volume_f16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "stereo_gwc_volume_f16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_corr_soft_argmin_f16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_corr_volume_soft_argmin_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_gwc_volume_soft_argmin_f16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_allpairs_pyramid_f16": [_vp, _vp, ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_instance_norm_workspace_bytes": [_i, _i],
+    "stereo_instance_norm_relu_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "stereo_soft_argmin_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_gwc_volume_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_local_lookup_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
@@ -67,13 +76,21 @@ SIGNATURES = {
     "stereo_gru_reset_f16": [_vp, _vp, _vp, _vp, _ll, _vp],
     "stereo_gru_blend_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp],
 }
-_RESTYPE = {"stereo_strerror": ctypes.c_char_p, "stereo_alt_corr_workspace_floats": _ll}
+_RESTYPE = {"stereo_strerror": ctypes.c_char_p, "stereo_alt_corr_workspace_floats": _ll,
+            "stereo_instance_norm_workspace_bytes": _ll}
 
 _lib = None
 
 
 class StereoHipError(RuntimeError):
-    """Raised when a libstereo_hip.so entry point returns a STEREO_ERR_* code."""
+    """Raised when a libstereo_hip.so entry point returns a STEREO_ERR_* code (``.code``)."""
+
+    def __init__(self, msg, code=0):
+        super().__init__(msg)
+        self.code = code
+
+
+ERR_UNSUPPORTED = -3
 
 
 def load() -> ctypes.CDLL:
@@ -100,7 +117,7 @@ def load() -> ctypes.CDLL:
 def check(rc: int, name: str) -> None:
     if rc != 0:
         msg = load().stereo_strerror(rc).decode()
-        raise StereoHipError(f"{name} failed: {msg} (code {rc})")
+        raise StereoHipError(f"{name} failed: {msg} (code {rc})", rc)
 
 
 def call(name: str, *args) -> None:
@@ -148,6 +165,30 @@ def dev_f32(t: torch.Tensor, name: str, dense_ok: bool = False) -> torch.Tensor:
     if dense_ok and t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
         return t
     return t.contiguous()
+
+
+def dev_feat(t: torch.Tensor, name: str) -> torch.Tensor:
+    """Validate a FEATURE operand of a matrix-core op: HIP device, fp32 or fp16 (an fp16 extractor hands
+    its features over as they are; the kernels widen them on the way into LDS), contiguous NCHW."""
+    if isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float16 and not (torch.is_grad_enabled() and t.requires_grad):
+        return t.contiguous()
+    if isinstance(t, torch.Tensor) and t.dtype == torch.float16:
+        t = t.float()          # grad mode: the differentiable ops are fp32 (autograd carries the cast)
+    return dev_f32(t, name)
+
+
+def feat_call(base: str, feats, args_of):
+    """Call ``<base>_f16`` when every feature operand is fp16, else ``<base>_f32``.  The fp16 entry points cover the
+    matrix-core envelope only: on STEREO_ERR_UNSUPPORTED the features are widened HERE (a device cast, not a fallback off
+    the HIP path) and the fp32 entry point runs.  ``args_of(feats)`` builds the C argument tuple."""
+    if all(f is None or f.dtype == torch.float16 for f in feats):
+        try:
+            return call(base + "_f16", *args_of(feats))
+        except StereoHipError as e:
+            if e.code != ERR_UNSUPPORTED:
+                raise
+    feats = [None if f is None else (f if f.dtype == torch.float32 else f.float()) for f in feats]
+    return call(base + "_f32", *args_of(feats))
 
 
 def one_layout(*ts):

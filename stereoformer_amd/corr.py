@@ -22,8 +22,9 @@ def _pyramid_forward(fmap1, fmap2, num_levels):
     rows = B * H * W1
     levels = [torch.empty((rows, 1, 1, W2 >> i), device=fmap1.device, dtype=torch.float32) for i in range(num_levels + 1)]
     with torch.cuda.device(fmap1.device):
-        N.call("stereo_allpairs_pyramid_f32", N.ptr(fmap1), N.ptr(fmap2), _level_array(levels), B, C, H, W1, W2,
-               num_levels, N.stream_ptr(fmap1.device))
+        N.feat_call("stereo_allpairs_pyramid", [fmap1, fmap2],
+                    lambda f: (N.ptr(f[0]), N.ptr(f[1]), _level_array(levels), B, C, H, W1, W2, num_levels,
+                               N.stream_ptr(fmap1.device)))
     return levels
 
 
@@ -105,8 +106,12 @@ class CorrBlock1D:
         if torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad):
             self.corr_pyramid = list(_AllPairsPyramidFn.apply(fmap1.contiguous(), fmap2.contiguous(), num_levels))
             return
-        fmap1 = N.dev_f32(fmap1, "CorrBlock1D: fmap1")
-        fmap2 = N.dev_f32(fmap2, "CorrBlock1D: fmap2")
+        # fp16 feature maps (the fnet's output under autocast, widened by `.float()` in raft_stereo.py:155-156) are taken as
+        # they are: the kernel widens them on the way into LDS -- same numbers, half the read bytes
+        fmap1 = N.dev_feat(fmap1, "CorrBlock1D: fmap1")
+        fmap2 = N.dev_feat(fmap2, "CorrBlock1D: fmap2")
+        if fmap1.dtype != fmap2.dtype:
+            fmap1, fmap2 = fmap1.float(), fmap2.float()
         N.same_device(fmap1, fmap2)
         self.corr_pyramid = _pyramid_forward(fmap1, fmap2, num_levels)
 
@@ -130,14 +135,17 @@ class CorrBlock1D:
     @staticmethod
     def corr(fmap1, fmap2):
         """All-pairs ``einsum('aijk,aijh->ajkh')/sqrt(C)`` -> [B,H,W1,1,W2] (corr.py:103-111)."""
-        fmap1 = N.dev_f32(fmap1, "CorrBlock1D.corr: fmap1")
-        fmap2 = N.dev_f32(fmap2, "CorrBlock1D.corr: fmap2")
+        fmap1 = N.dev_feat(fmap1, "CorrBlock1D.corr: fmap1")
+        fmap2 = N.dev_feat(fmap2, "CorrBlock1D.corr: fmap2")
+        if fmap1.dtype != fmap2.dtype:
+            fmap1, fmap2 = fmap1.float(), fmap2.float()
         B, C, H, W1 = fmap1.shape
         W2 = fmap2.shape[3]
         out = torch.empty((B, H, W1, 1, W2), device=fmap1.device, dtype=torch.float32)
         with torch.cuda.device(fmap1.device):
-            N.call("stereo_allpairs_pyramid_f32", N.ptr(fmap1), N.ptr(fmap2), _level_array([out]), B, C, H, W1, W2, 0,
-                   N.stream_ptr(fmap1.device))
+            N.feat_call("stereo_allpairs_pyramid", [fmap1, fmap2],
+                        lambda f: (N.ptr(f[0]), N.ptr(f[1]), _level_array([out]), B, C, H, W1, W2, 0,
+                                   N.stream_ptr(fmap1.device)))
         return out
 
 

@@ -97,8 +97,8 @@ def _gwc_forward(L, R, maxdisp, num_groups):
     B, C, H, W = L.shape
     vol = torch.empty((B, num_groups, maxdisp, H, W), device=L.device, dtype=torch.float32)
     with torch.cuda.device(L.device):
-        N.call("stereo_gwc_volume_f32", N.ptr(L), N.ptr(R), N.ptr(vol), B, C, H, W, int(maxdisp), int(num_groups),
-               N.stream_ptr(L.device))
+        N.feat_call("stereo_gwc_volume", [L, R], lambda f: (N.ptr(f[0]), N.ptr(f[1]), N.ptr(vol), B, C, H, W, int(maxdisp),
+                                                            int(num_groups), N.stream_ptr(L.device)))
     return vol
 
 
@@ -106,9 +106,13 @@ def _wants_grad(*ts):
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts)
 
 
-def _pair(left, right, who):
-    left = N.dev_f32(left, f"{who}: left_feature")
-    right = N.dev_f32(right, f"{who}: right_feature")
+def _pair(left, right, who, feat=False):
+    """``feat``: the op has an fp16-feature form -- fp16 tensors pass through as they are."""
+    check = N.dev_feat if feat else N.dev_f32
+    left = check(left, f"{who}: left_feature")
+    right = check(right, f"{who}: right_feature")
+    if left.dtype != right.dtype:   # mixed precisions: the fp32 path
+        left, right = left.float(), right.float()
     if left.dim() != 4 or left.shape != right.shape:
         raise ValueError(f"{who}: expected two [B,C,H,W] tensors of one shape, got {tuple(left.shape)} "
                          f"and {tuple(right.shape)}")
@@ -134,14 +138,14 @@ class CostVolume(nn.Module):
             with torch.no_grad():
                 _pair(left_feature, right_feature, "CostVolume")  # validation only
             return _GwcVolumeFn.apply(left_feature.contiguous(), right_feature.contiguous(), int(self.max_disp), 1, True)
-        L, R = _pair(left_feature, right_feature, "CostVolume")
+        L, R = _pair(left_feature, right_feature, "CostVolume", feat=self.feature_similarity == "correlation")
         b, c, h, w = L.shape
         D = int(self.max_disp)
         st = N.stream_ptr(L.device)
         with torch.cuda.device(L.device):
             if self.feature_similarity == "correlation":
                 vol = torch.empty((b, D, h, w), device=L.device, dtype=torch.float32)
-                N.call("stereo_corr_volume_f32", N.ptr(L), N.ptr(R), N.ptr(vol), b, c, h, w, D, st)
+                N.feat_call("stereo_corr_volume", [L, R], lambda f: (N.ptr(f[0]), N.ptr(f[1]), N.ptr(vol), b, c, h, w, D, st))
             elif self.feature_similarity == "difference":
                 vol = torch.empty((b, c, D, h, w), device=L.device, dtype=torch.float32)
                 N.call("stereo_diff_volume_f32", N.ptr(L), N.ptr(R), N.ptr(vol), b, c, h, w, D, st)
@@ -174,7 +178,7 @@ def build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups):
             L, R = _pair(refimg_fea, targetimg_fea, "build_gwc_volume")
         assert L.shape[1] % num_groups == 0  # GWC_Cost_Volume.py:7
         return _GwcVolumeFn.apply(refimg_fea.contiguous(), targetimg_fea.contiguous(), int(maxdisp), int(num_groups), False)
-    L, R = _pair(refimg_fea, targetimg_fea, "build_gwc_volume")
+    L, R = _pair(refimg_fea, targetimg_fea, "build_gwc_volume", feat=True)
     assert L.shape[1] % num_groups == 0  # GWC_Cost_Volume.py:7
     return _gwc_forward(L, R, maxdisp, num_groups)
 
@@ -187,14 +191,15 @@ def corr_volume_with_disparity(left_feature, right_feature, max_disp, match_simi
     if _wants_grad(left_feature, right_feature):
         vol = CostVolume(int(max_disp), "correlation")(left_feature, right_feature)
         return vol, DisparityEstimation(int(max_disp), match_similarity)(vol)
-    L, R = _pair(left_feature, right_feature, "corr_volume_with_disparity")
+    L, R = _pair(left_feature, right_feature, "corr_volume_with_disparity", feat=True)
     B, C, H, W = L.shape
     D = int(max_disp)
     vol = torch.empty((B, D, H, W), device=L.device, dtype=torch.float32)
     disp = torch.empty((B, H, W), device=L.device, dtype=torch.float32)
     with torch.cuda.device(L.device):
-        N.call("stereo_corr_volume_soft_argmin_f32", N.ptr(L), N.ptr(R), N.ptr(vol), N.ptr(disp), B, C, H, W, D,
-               1 if match_similarity else 0, N.stream_ptr(L.device))
+        N.feat_call("stereo_corr_volume_soft_argmin", [L, R],
+                    lambda f: (N.ptr(f[0]), N.ptr(f[1]), N.ptr(vol), N.ptr(disp), B, C, H, W, D,
+                               1 if match_similarity else 0, N.stream_ptr(L.device)))
     return vol, disp
 
 
@@ -214,22 +219,24 @@ def build_gwc_volume_with_disparity(refimg_fea, targetimg_fea, maxdisp, num_grou
         vol, disp, mean = _GwcWithDisparityFn.apply(refimg_fea.contiguous(), targetimg_fea.contiguous(), int(maxdisp),
                                                     int(num_groups), bool(match_similarity))
         return (vol, disp, mean) if return_mean else (vol, disp)
-    L, R = _pair(refimg_fea, targetimg_fea, "build_gwc_volume_with_disparity")
+    L, R = _pair(refimg_fea, targetimg_fea, "build_gwc_volume_with_disparity", feat=True)
     assert L.shape[1] % num_groups == 0  # GWC_Cost_Volume.py:7
     B, C, H, W = L.shape
     D, G = int(maxdisp), int(num_groups)
     vol = torch.empty((B, G, D, H, W), device=L.device, dtype=torch.float32)
     disp = torch.empty((B, H, W), device=L.device, dtype=torch.float32)
-    mean = torch.empty((B, D, H, W), device=L.device, dtype=torch.float32) if return_mean else None
+    # the fp16 form always produces the mean volume (the fused kernel's only shape); fp32 keeps it optional
+    mean = torch.empty((B, D, H, W), device=L.device, dtype=torch.float32) if (return_mean or L.dtype == torch.float16) else None
     with torch.cuda.device(L.device):
-        N.call("stereo_gwc_volume_soft_argmin_f32", N.ptr(L), N.ptr(R), N.ptr(vol), N.ptr(mean), N.ptr(disp), B, C, H, W,
-               D, G, 1 if match_similarity else 0, N.stream_ptr(L.device))
+        N.feat_call("stereo_gwc_volume_soft_argmin", [L, R],
+                    lambda f: (N.ptr(f[0]), N.ptr(f[1]), N.ptr(vol), N.ptr(mean), N.ptr(disp), B, C, H, W, D, G,
+                               1 if match_similarity else 0, N.stream_ptr(L.device)))
     return (vol, disp, mean) if return_mean else (vol, disp)
 
 
 def groupwise_correlation(fea1, fea2, num_groups):
     """``groupwise_correlation`` (GWC_Cost_Volume.py:5-11) -> [B,G,H,W] (= the D=1 slice)."""
-    L, R = _pair(fea1, fea2, "groupwise_correlation")
+    L, R = _pair(fea1, fea2, "groupwise_correlation", feat=True)
     B, C, H, W = L.shape
     assert C % num_groups == 0
     cost = build_gwc_volume(L, R, 1, num_groups).view(B, num_groups, H, W)

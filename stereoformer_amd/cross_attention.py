@@ -31,18 +31,25 @@ class CrossAttentionCostVolume(nn.Module):
         self.scale = scale
 
     def forward(self, left_feature, right_feature, value=None, need_out=True):
-        L = N.dev_f32(left_feature, "CrossAttentionCostVolume: left_feature")
-        R = N.dev_f32(right_feature, "CrossAttentionCostVolume: right_feature")
+        # features fp32 or fp16 (widened on the way into LDS, f32 accumulate, fp32 outputs)
+        L = N.dev_feat(left_feature, "CrossAttentionCostVolume: left_feature")
+        R = N.dev_feat(right_feature, "CrossAttentionCostVolume: right_feature")
         if L.dim() != 4 or L.shape != R.shape:
             raise ValueError("CrossAttentionCostVolume: expected two [B,C,H,W] tensors of one shape")
-        V = R if value is None else N.dev_f32(value, "CrossAttentionCostVolume: value")
+        V = R if value is None else N.dev_feat(value, "CrossAttentionCostVolume: value")
+        if not (L.dtype == R.dtype == V.dtype):     # mixed precisions: the fp32 path
+            same = V is R
+            L, R = L.float(), R.float()
+            V = R if same else V.float()
         B, C, H, W = L.shape
         if V.dim() != 4 or V.shape[0] != B or tuple(V.shape[2:]) != (H, W):
             raise ValueError("CrossAttentionCostVolume: value must be [B,Cv,H,W]")
         Cv = V.shape[1]
         out = torch.empty((B, Cv, H, W), device=L.device, dtype=torch.float32) if need_out else None
         disp = torch.empty((B, H, W), device=L.device, dtype=torch.float32)
+        same = V is R
         with torch.cuda.device(L.device):
-            N.call("stereo_cross_attention_f32", N.ptr(L), N.ptr(R), N.ptr(V), N.ptr(out), N.ptr(disp), B, C, Cv, H,
-                   W, int(self.max_disp), _MASK[self.mask], _SCALE[self.scale], N.stream_ptr(L.device))
+            N.feat_call("stereo_cross_attention", [L, R, None if same else V],
+                        lambda f: (N.ptr(f[0]), N.ptr(f[1]), N.ptr(f[1] if same else f[2]), N.ptr(out), N.ptr(disp), B, C, Cv,
+                                   H, W, int(self.max_disp), _MASK[self.mask], _SCALE[self.scale], N.stream_ptr(L.device)))
         return out, disp

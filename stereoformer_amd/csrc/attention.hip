@@ -10,6 +10,7 @@
 //   v2  f32 MFMA for both contractions, probabilities through an LDS score sheet (ragged W, D > 256).
 //   v4  scores stay in the MFMA accumulators, two-pass softmax (any C / Cv / value tensor).
 //   v5  v4 + online softmax + persistent prefetching workgroups (C <= 32, value = right features).
+//   v6  (attention_chunked.hip) v4's arithmetic as a persistent item pipeline over channel chunks (any C / Cv / value).
 // The [B,H,W,D] score tensor is never materialised in HBM by any of them.
 #include "common.h"
 
@@ -452,9 +453,9 @@ __global__ __launch_bounds__(A4_NW * 64, MINW) void cross_attention_reg_kernel(c
 // image (row-major, so the 192-key halo it re-reads was fetched by itself a moment ago and sits in L2) and the K
 // quads and Q values of the NEXT tile are loaded into registers before the current tile's MFMAs start; they are
 // committed to LDS between two barriers once every wave is done with the current tile.
-template <int NT, int NWV>
-__global__ __launch_bounds__(NWV * 64) void cross_attention_online_kernel(const float *__restrict__ L,
-                                                                          const float *__restrict__ R,
+template <int NT, int NWV, typename TIN>
+__global__ __launch_bounds__(NWV * 64) void cross_attention_online_kernel(const TIN *__restrict__ L,
+                                                                          const TIN *__restrict__ R,
                                                                           float *__restrict__ out,
                                                                           float *__restrict__ disp, int C, int H, int W,
                                                                           int D, int mask_mode, float scale,
@@ -483,15 +484,15 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_online_kernel(const 
     const int tile_end = (tile + tiles_per_wg < ntiles) ? tile + tiles_per_wg : ntiles;
     if (tile >= tile_end) return;
 
-    f32x4 rk[RMAX][NPASS];
-    float qn[16];
+    typename Quad<TIN>::raw rk[RMAX][NPASS];  // raw quads (16 B fp32 / 8 B fp16), widened at commit
+    TIN qn[16];                               // raw as well: a conversion right behind each load would serialise the 16 loads
     unsigned okbits = 0;  // validity of the prefetched quads, applied at commit time (keeps the loads in flight)
     auto issue = [&](int tl) {  // K quads and Q values of tile tl -> registers
         const int x = tl % nx, bh = tl / nx;  // bh = b * H + h
         const int hh = bh % H, bb = bh / H;
         const int w0 = x * TQW, kbase = w0 - Dk;
-        const float *Rb = R + ((size_t)bb * C * HWu + (size_t)hh * W);  // workgroup-uniform bases
-        const float *Lb = L + ((size_t)bb * C * HWu + (size_t)hh * W);
+        const TIN *Rb = R + ((size_t)bb * C * HWu + (size_t)hh * W);  // workgroup-uniform bases
+        const TIN *Lb = L + ((size_t)bb * C * HWu + (size_t)hh * W);
         okbits = 0;
 #pragma unroll
         for (int pp = 0; pp < NPASS; ++pp) {
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_online_kernel(const 
 #pragma unroll
             for (int pp = 0; pp < NPASS; ++pp) {
                 const bool ok = ((okbits >> pp) & 1u) && row < C && row < 32;
-                rk[rr][pp] = ld4(Rb + (ok ? (unsigned)row * HWu + (unsigned)(kbase + 4 * (lane + 64 * pp)) : 0u));
+                rk[rr][pp] = Quad<TIN>::ld(Rb + (ok ? (unsigned)row * HWu + (unsigned)(kbase + 4 * (lane + 64 * pp)) : 0u));
             }
         }
         const int q = w0 + 32 * wave + l31;
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_online_kernel(const 
                 for (int pp = 0; pp < NPASS; ++pp) {
                     if (lane + 64 * pp < NK / 4)
                         Ks4[(row * KS) / 4 + lane + 64 * pp] =
-                            (((okbits >> pp) & 1u) && row < C) ? rk[rr][pp] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                            (((okbits >> pp) & 1u) && row < C) ? Quad<TIN>::widen(rk[rr][pp]) : (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
             }
         }
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_online_kernel(const 
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int c = 2 * s + half;
-            qv[s] = (c < C && q < W) ? qn[s] * sc2 : 0.0f;
+            qv[s] = (c < C && q < W) ? (float)qn[s] * sc2 : 0.0f;
         }
         __syncthreads();  // the tile is visible
         const bool more = tile + 1 < tile_end;
@@ -644,10 +645,12 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_online_kernel(const 
 
 // v5 launcher (also behind corr_soft_argmin: A1 + A4 without any volume is this kernel with mask 'zero', scale
 // +-1/C and no output tensor -- SURVEY 8(c) identity I3).  Envelope: C <= 32, D <= 256, W % 4 == 0, 16-B aligned.
-int launch_online(const float *left, const float *right, float *out, float *disp, int B, int C, int H, int W, int D,
+template <typename TIN>
+int launch_online(const TIN *left, const TIN *right, float *out, float *disp, int B, int C, int H, int W, int D,
                   int mask_mode, float sc, hipStream_t st)
 {
-    if (C > 32 || D > 256 || D < 1 || W % 4 != 0 || !aligned16(left) || !aligned16(right) || (long long)32 * H * W >= (1LL << 31))
+    if (C > 32 || D > 256 || D < 1 || W % 4 != 0 || !aligned_quad<TIN>(left) || !aligned_quad<TIN>(right) ||
+        (long long)32 * H * W >= (1LL << 31))
         return STEREO_ERR_UNSUPPORTED;
     const int nt = (D + 31) / 32 + 1;
     // waves (32 queries each) per workgroup: 8 (256 queries, the halo is re-fetched 1.75x) unless the row
@@ -661,7 +664,7 @@ int launch_online(const float *left, const float *right, float *out, float *disp
     if (stereo_opt(OPT_TILES_PER_WG) > 0) tpw = stereo_opt(OPT_TILES_PER_WG);  // test hook: short persistent runs
     const int nwg = (ntl + tpw - 1) / tpw;
 #define ATT5N(NTV, NWVV)                                                                                        \
-    hipLaunchKernelGGL((cross_attention_online_kernel<NTV, NWVV>), dim3(nwg), dim3(NWVV * 64), 0, st, left, right, out, \
+    hipLaunchKernelGGL((cross_attention_online_kernel<NTV, NWVV, TIN>), dim3(nwg), dim3(NWVV * 64), 0, st, left, right, out, \
                        disp, C, H, W, D, mask_mode, sc, tpw, ntl)
 #define ATT5(NTV)                    \
     do {                             \
@@ -702,8 +705,16 @@ extern "C" int stereo_cross_attention_f32(const float *left, const float *right,
             const int same_kv = (out != nullptr && value == right && Cv == C) ? 1 : 0;
             dim3 grid4((W + A4_TQ - 1) / A4_TQ, H, B);
             if (C <= 32 && (out == nullptr || same_kv) && forced != 4) {  // v5: online softmax
-                const int rc5 = launch_online(left, right, out, disp, B, C, H, W, D, mask_mode, sc, as_stream(stream));
+                const int rc5 = launch_online<float>(left, right, out, disp, B, C, H, W, D, mask_mode, sc, as_stream(stream));
                 if (rc5 != STEREO_ERR_UNSUPPORTED) return rc5;
+            }
+            // v6 (channel-chunked item pipeline) serves the fp16-feature entry points; on fp32 features at C = 256 it
+            // measured 5-10 % behind v4 (0.36 vs 0.335 ms at [8,256,136,240] D=48: both sit on the executed f32-MFMA work
+            // of the 32-key band tiles), so fp32 calls take it only through the test hook
+            if (forced == 6) {
+                const int rc6 = stereo_cross_attention_chunked<float>(left, right, value, out, disp, B, C, Cv, H, W, D,
+                                                                      mask_mode, sc, as_stream(stream));
+                if (rc6 != STEREO_ERR_UNSUPPORTED) return rc6;
             }
 #define ATT4(NTV)                                                                                                      \
     hipLaunchKernelGGL((cross_attention_reg_kernel<NTV, (NTV <= 7 ? 2 : 1)>), grid4, dim3(A4_NW * 64), 0, as_stream(stream), left, right, value, \
@@ -744,8 +755,37 @@ extern "C" int stereo_cross_attention_f32(const float *left, const float *right,
 }
 
 // A1 + A4 with no volume at all, on the matrix cores (library-internal; STEREO_ERR_UNSUPPORTED outside the envelope).
-int stereo_corr_soft_argmin_mfma(const float *L, const float *R, float *disp, int B, int C, int H, int W, int D, float sgn,
+template <typename TIN>
+int stereo_corr_soft_argmin_mfma(const TIN *L, const TIN *R, float *disp, int B, int C, int H, int W, int D, float sgn,
                                  hipStream_t st)
 {
-    return launch_online(L, R, nullptr, disp, B, C, H, W, D, STEREO_MASK_ZERO, sgn / (float)C, st);
+    return launch_online<TIN>(L, R, nullptr, disp, B, C, H, W, D, STEREO_MASK_ZERO, sgn / (float)C, st);
+}
+template int stereo_corr_soft_argmin_mfma<float>(const float *, const float *, float *, int, int, int, int, int, float,
+                                                 hipStream_t);
+template int stereo_corr_soft_argmin_mfma<f16>(const f16 *, const f16 *, float *, int, int, int, int, int, float, hipStream_t);
+
+// A7 with fp16 features: left / right / value [B,C,H,W] fp16, out / disp fp32.  C <= 32 with value = right
+// features -> the online-softmax kernel; anything else -> the channel-chunked kernel.  No slow path: outside both envelopes
+// the call returns STEREO_ERR_UNSUPPORTED and the host layer widens the features itself.
+extern "C" int stereo_cross_attention_f16(const void *left, const void *right, const void *value, float *out, float *disp,
+                                          int B, int C, int Cv, int H, int W, int D, int mask_mode, int scale_mode,
+                                          void *stream)
+{
+    if (B < 0 || C < 0 || Cv < 0 || H < 0 || W < 0 || D < 0) return STEREO_ERR_BAD_SHAPE;
+    if (mask_mode != STEREO_MASK_ZERO && mask_mode != STEREO_MASK_NEGINF) return STEREO_ERR_BAD_SHAPE;
+    if (scale_mode != STEREO_SCALE_SQRT_C && scale_mode != STEREO_SCALE_MEAN) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(left);
+    STEREO_REQUIRE_PTR(right);
+    if (out) STEREO_REQUIRE_PTR(value);
+    if (D == 0 || C == 0) return STEREO_ERR_BAD_SHAPE;
+    const f16 *L = static_cast<const f16 *>(left), *R = static_cast<const f16 *>(right), *V = static_cast<const f16 *>(value);
+    const float sc = scale_mode == STEREO_SCALE_MEAN ? 1.0f / (float)C : 1.0f / sqrtf((float)C);
+    const bool same_kv = out != nullptr && value == right && Cv == C;
+    if (C <= 32 && (out == nullptr || same_kv) && stereo_opt(OPT_ATT_KERNEL) != 6) {
+        const int rc = launch_online<f16>(L, R, out, disp, B, C, H, W, D, mask_mode, sc, as_stream(stream));
+        if (rc != STEREO_ERR_UNSUPPORTED) return rc;
+    }
+    return stereo_cross_attention_chunked<f16>(L, R, V, out, disp, B, C, Cv, H, W, D, mask_mode, sc, as_stream(stream));
 }

@@ -17,8 +17,8 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 enum StereoOpt {
     OPT_CORR_MFMA = 0,   // 1 (default): matrix-core volume kernels where their envelope allows; 0: VALU kernels
     OPT_GWC_FUSED,       // 1 (default): A3 + group mean + A4 in one launch; 0: separate launches
-    OPT_ATT_KERNEL,      // 0 (default): newest applicable; 2: LDS-score-sheet kernel; 4: two-pass register kernel
-    OPT_ATT_WAVES,       // 0 (default): by row length; 4 / 8: waves per workgroup of the online-softmax kernel
+    OPT_ATT_KERNEL,      // 0 (default): by shape; 2: LDS-score-sheet kernel; 4: two-pass register kernel; 6: chunked pipeline
+    OPT_ATT_WAVES,       // 0 (default): by row length; 4 / 5 / 8: waves per workgroup of the persistent attention kernels
     OPT_TILES_PER_WG,    // 0 (default): sized to the resident workgroups; n > 0: tiles per persistent workgroup
     OPT_PROB_SINGLE_PASS,  // 1 (default): softmax column in registers (D <= 192); 0: two-pass kernel
     OPT_COUNT
@@ -62,6 +62,29 @@ __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<
 __device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 __device__ __forceinline__ void st4_nt(float *p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p)); }
 
+// ---- feature operand types: the matrix-core kernels take their FEATURE inputs as fp32 or fp16 and
+// convert on the way into LDS; all arithmetic and every output stays fp32.  `Quad<T>`: 4 consecutive elements as they sit
+// in memory (16 B / 8 B), kept raw in the prefetch registers and widened at commit time.
+typedef _Float16 f16;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+struct Quad;
+template <>
+struct Quad<float> {
+    typedef f32x4 raw;
+    static __device__ __forceinline__ raw ld(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+    static __device__ __forceinline__ f32x4 widen(raw r) { return r; }
+};
+template <>
+struct Quad<f16> {
+    typedef f16x4 raw;
+    static __device__ __forceinline__ raw ld(const f16 *p) { return *reinterpret_cast<const f16x4 *>(p); }
+    static __device__ __forceinline__ f32x4 widen(raw r) { return __builtin_convertvector(r, f32x4); }
+};
+// base pointers of quad loads: 16 B for fp32, 8 B for fp16
+template <typename T>
+static inline bool aligned_quad(const void *p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(T) - 1)) == 0; }
+
 // v_exp_f32 based exp: |rel err| ~1e-6 on the softmax range; far inside the 1e-3 disparity bar
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
@@ -85,15 +108,23 @@ __device__ __forceinline__ float sample_tap(const float *__restrict__ v, size_t 
 }
 
 // corr_mfma.hip: A1 (+ A4 when disp != nullptr) on the f32 matrix cores.  Library-internal (not part of the C ABI);
-// returns STEREO_ERR_UNSUPPORTED outside its envelope (C <= 32, D <= 256, W % 4 == 0, 16-B aligned).
-int stereo_corr_volume_mfma(const float *L, const float *R, float *vol, float *disp, int B, int C, int H, int W, int D,
+// returns STEREO_ERR_UNSUPPORTED outside its envelope (C <= 32, D <= 256, W % 4 == 0, quad-aligned).  TIN = float | f16:
+// the feature operands' storage type (widened on the way into LDS; arithmetic and outputs are fp32 either way).
+template <typename TIN>
+int stereo_corr_volume_mfma(const TIN *L, const TIN *R, float *vol, float *disp, int B, int C, int H, int W, int D,
                             float sgn, hipStream_t st);
 // A3 + group mean + A4 in one kernel (even channels per group <= 16); same envelope, same return convention.
-int stereo_gwc_mean_argmin_mfma(const float *L, const float *R, float *volg, float *mean, float *disp, int B, int C, int H,
+template <typename TIN>
+int stereo_gwc_mean_argmin_mfma(const TIN *L, const TIN *R, float *volg, float *mean, float *disp, int B, int C, int H,
                                 int W, int D, int G, float sgn, hipStream_t st);
 // attention.hip: A1 + A4 without any volume (= cross-attention, mask 'zero', scale +-1/C, no output tensor).
-int stereo_corr_soft_argmin_mfma(const float *L, const float *R, float *disp, int B, int C, int H, int W, int D, float sgn,
+template <typename TIN>
+int stereo_corr_soft_argmin_mfma(const TIN *L, const TIN *R, float *disp, int B, int C, int H, int W, int D, float sgn,
                                  hipStream_t st);
 // corr_mfma_bwd.hip: backward of A1 (G = 1) on the f32 matrix cores; either output may be null.
 int stereo_corr_volume_bwd_mfma(const float *left, const float *right, const float *grad_vol, float *grad_left,
                                 float *grad_right, int B, int C, int H, int W, int D, hipStream_t st);
+// attention_chunked.hip: A7 for any C / Cv / value tensor, channel-chunked and software-pipelined; features fp32 or fp16.
+template <typename TIN>
+int stereo_cross_attention_chunked(const TIN *L, const TIN *R, const TIN *V, float *out, float *disp, int B, int C, int Cv,
+                                   int H, int W, int D, int mask_mode, float sc, hipStream_t st);

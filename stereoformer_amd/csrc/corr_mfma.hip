@@ -34,9 +34,9 @@ namespace {
 // flushes into volg[b, g]; then the all-channel pass produces the mean volume and the disparity as before.  The key
 // tile and the Q registers are fetched once for both; the 25.5 GB group-wise volume leaves through the same
 // row-contiguous flush path (which sustains > 6 TB/s on its own) and is never read back.
-template <int NT, bool ARGMIN, int CM_NWV, int RINGB, int CPG2 = 0, bool MEANPASS = true>
-__global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const float *__restrict__ L,
-                                                                       const float *__restrict__ R,
+template <int NT, bool ARGMIN, int CM_NWV, int RINGB, int CPG2 = 0, bool MEANPASS = true, typename TIN = float>
+__global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const TIN *__restrict__ L,
+                                                                       const TIN *__restrict__ R,
                                                                        float *__restrict__ vol, float *__restrict__ disp,
                                                                        int C, int H, int W, int D, float inv_c, float sgn,
                                                                        int tiles_per_wg, int ntiles,
@@ -70,15 +70,15 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
     const int tile_end = (tile + tiles_per_wg < ntiles) ? tile + tiles_per_wg : ntiles;
     if (tile >= tile_end) return;
 
-    f32x4 rk[RMAX][NPASS];
-    float qn[16];
+    typename Quad<TIN>::raw rk[RMAX][NPASS];  // raw quads (16 B fp32 / 8 B fp16), widened at commit
+    TIN qn[16];                               // raw as well: a conversion right behind each load would serialise the 16 loads
     unsigned okbits = 0;
     auto issue = [&](int tl) {  // K quads and Q values of tile tl -> registers
         const int x = tl % nx, bh = tl / nx;
         const int hh = bh % H, bb = bh / H;
         const int w0 = x * CM_TQW, kbase = w0 - Dk;
-        const float *Rb = R + ((size_t)bb * C * HWu + (size_t)hh * W);
-        const float *Lb = L + ((size_t)bb * C * HWu + (size_t)hh * W);
+        const TIN *Rb = R + ((size_t)bb * C * HWu + (size_t)hh * W);
+        const TIN *Lb = L + ((size_t)bb * C * HWu + (size_t)hh * W);
         okbits = 0;
 #pragma unroll
         for (int pp = 0; pp < NPASS; ++pp) {
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
 #pragma unroll
             for (int pp = 0; pp < NPASS; ++pp) {
                 const bool ok = ((okbits >> pp) & 1u) && row < C && row < 32;
-                rk[rr][pp] = ld4(Rb + (ok ? (unsigned)row * HWu + (unsigned)(kbase + 4 * (lane + 64 * pp)) : 0u));
+                rk[rr][pp] = Quad<TIN>::ld(Rb + (ok ? (unsigned)row * HWu + (unsigned)(kbase + 4 * (lane + 64 * pp)) : 0u));
             }
         }
         const int q = w0 + 32 * wave + l31;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
             for (int pp = 0; pp < NPASS; ++pp) {
                 if (row < 32 && lane + 64 * pp < NK / 4)
                     Ks4[(row * KS) / 4 + lane + 64 * pp] =
-                        (((okbits >> pp) & 1u) && row < C) ? rk[rr][pp] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        (((okbits >> pp) & 1u) && row < C) ? Quad<TIN>::widen(rk[rr][pp]) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
     };
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int c = 2 * s + half;
-            qv[s] = (c < C && q < W) ? qn[s] * inv_c : 0.0f;
+            qv[s] = (c < C && q < W) ? (float)qn[s] * inv_c : 0.0f;
         }
         __syncthreads();  // the key tile is visible; the previous tile's last sheet reads are done
         const bool more = tile + 1 < tile_end;
@@ -259,13 +259,13 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const flo
     }
 }
 
-template <int NT, bool ARGMIN, int NWV, int RINGB, int CPG2 = 0, bool MEANPASS = true>
-int launch_cm(const float *L, const float *R, float *vol, float *disp, int B, int C, int H, int W, int D, float sgn,
+template <int NT, bool ARGMIN, int NWV, int RINGB, int CPG2 = 0, bool MEANPASS = true, typename TIN = float>
+int launch_cm(const TIN *L, const TIN *R, float *vol, float *disp, int B, int C, int H, int W, int D, float sgn,
               hipStream_t st, float *volg = nullptr, int G = 0)
 {
     constexpr int Dk = 32 * (NT - 1), TQW = 32 * NWV;
     const size_t lds = ((size_t)32 * (TQW + Dk + 4) + (size_t)32 * RINGB * (TQW + 4)) * sizeof(float);
-    auto kern = corr_volume_mfma_kernel<NT, ARGMIN, NWV, RINGB, CPG2, MEANPASS>;
+    auto kern = corr_volume_mfma_kernel<NT, ARGMIN, NWV, RINGB, CPG2, MEANPASS, TIN>;
     if (lds > 160 * 1024) return STEREO_ERR_UNSUPPORTED;
     static std::atomic<unsigned long long> lds_done{0};  // per instantiation: a bit per device
     if (!lds_opt_in(kern, lds, lds_done)) return STEREO_ERR_UNSUPPORTED;
@@ -285,18 +285,20 @@ int launch_cm(const float *L, const float *R, float *vol, float *disp, int B, in
 
 // Returns STEREO_ERR_UNSUPPORTED when the shape is outside the kernel's envelope (the caller then takes the VALU path).
 // disp == nullptr: store-only (A1).
-int stereo_corr_volume_mfma(const float *L, const float *R, float *vol, float *disp, int B, int C, int H, int W, int D,
+template <typename TIN>
+int stereo_corr_volume_mfma(const TIN *L, const TIN *R, float *vol, float *disp, int B, int C, int H, int W, int D,
                             float sgn, hipStream_t st)
 {
-    if (C > 32 || D > 256 || D < 1 || W % 4 != 0 || !aligned16(L) || !aligned16(R) || !aligned16(vol)) return STEREO_ERR_UNSUPPORTED;
+    if (C > 32 || D > 256 || D < 1 || W % 4 != 0 || !aligned_quad<TIN>(L) || !aligned_quad<TIN>(R) || !aligned16(vol))
+        return STEREO_ERR_UNSUPPORTED;
     if ((long long)32 * H * W >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
     const int nt = (D + 31) / 32 + 1;
     if (nt > 7)  // 192 < D <= 256: six waves (192 queries) keep key tile + sheet inside the 160 KB of LDS
-        return disp ? launch_cm<9, true, 6, 3>(L, R, vol, disp, B, C, H, W, D, sgn, st)
-                    : launch_cm<9, false, 6, 3>(L, R, vol, disp, B, C, H, W, D, sgn, st);
+        return disp ? launch_cm<9, true, 6, 3, 0, true, TIN>(L, R, vol, disp, B, C, H, W, D, sgn, st)
+                    : launch_cm<9, false, 6, 3, 0, true, TIN>(L, R, vol, disp, B, C, H, W, D, sgn, st);
 #define CM_CASE(NTV)                                                                     \
-    return disp ? launch_cm<NTV, true, 8, 3>(L, R, vol, disp, B, C, H, W, D, sgn, st) \
-                : launch_cm<NTV, false, 8, 3>(L, R, vol, disp, B, C, H, W, D, sgn, st)
+    return disp ? launch_cm<NTV, true, 8, 3, 0, true, TIN>(L, R, vol, disp, B, C, H, W, D, sgn, st) \
+                : launch_cm<NTV, false, 8, 3, 0, true, TIN>(L, R, vol, disp, B, C, H, W, D, sgn, st)
     if (nt <= 3) CM_CASE(3);
     if (nt <= 5) CM_CASE(5);
     CM_CASE(7);
@@ -305,11 +307,12 @@ int stereo_corr_volume_mfma(const float *L, const float *R, float *vol, float *d
 
 // A3 + group mean + A4 fused (see the kernel's group pass).  volg [B,G,D,H,W], mean [B,D,H,W], disp [B,H,W].
 // mean == nullptr && disp == nullptr: A3 alone (group pass only).
-int stereo_gwc_mean_argmin_mfma(const float *L, const float *R, float *volg, float *mean, float *disp, int B, int C, int H,
+template <typename TIN>
+int stereo_gwc_mean_argmin_mfma(const TIN *L, const TIN *R, float *volg, float *mean, float *disp, int B, int C, int H,
                                 int W, int D, int G, float sgn, hipStream_t st)
 {
     const bool only_groups = mean == nullptr && disp == nullptr;
-    if (C > 32 || D > 192 || D < 1 || W % 4 != 0 || G < 1 || C % G != 0 || !aligned16(L) || !aligned16(R) ||
+    if (C > 32 || D > 192 || D < 1 || W % 4 != 0 || G < 1 || C % G != 0 || !aligned_quad<TIN>(L) || !aligned_quad<TIN>(R) ||
         !aligned16(volg) || (!only_groups && (!aligned16(mean) || mean == nullptr || disp == nullptr)))
         return STEREO_ERR_UNSUPPORTED;
     if ((long long)32 * H * W >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
@@ -317,8 +320,8 @@ int stereo_gwc_mean_argmin_mfma(const float *L, const float *R, float *volg, flo
     if (cpg != 2 && cpg != 4 && cpg != 8 && cpg != 16) return STEREO_ERR_UNSUPPORTED;
     const int nt = (D + 31) / 32 + 1;  // (D <= 192 here: the fused launch is instantiated for the 8-wave shape only)
 #define CMG(NTV, P2)                                                                                          \
-    return only_groups ? launch_cm<NTV, false, 8, 3, P2, false>(L, R, mean, disp, B, C, H, W, D, sgn, st, volg, G) \
-                       : launch_cm<NTV, true, 8, 3, P2, true>(L, R, mean, disp, B, C, H, W, D, sgn, st, volg, G)
+    return only_groups ? launch_cm<NTV, false, 8, 3, P2, false, TIN>(L, R, mean, disp, B, C, H, W, D, sgn, st, volg, G) \
+                       : launch_cm<NTV, true, 8, 3, P2, true, TIN>(L, R, mean, disp, B, C, H, W, D, sgn, st, volg, G)
 #define CMG_NT(NTV)                \
     do {                           \
         if (cpg == 2) CMG(NTV, 1); \
@@ -332,3 +335,12 @@ int stereo_gwc_mean_argmin_mfma(const float *L, const float *R, float *volg, flo
 #undef CMG_NT
 #undef CMG
 }
+
+template int stereo_corr_volume_mfma<float>(const float *, const float *, float *, float *, int, int, int, int, int, float,
+                                            hipStream_t);
+template int stereo_corr_volume_mfma<f16>(const f16 *, const f16 *, float *, float *, int, int, int, int, int, float,
+                                          hipStream_t);
+template int stereo_gwc_mean_argmin_mfma<float>(const float *, const float *, float *, float *, float *, int, int, int, int,
+                                                int, int, float, hipStream_t);
+template int stereo_gwc_mean_argmin_mfma<f16>(const f16 *, const f16 *, float *, float *, float *, int, int, int, int, int,
+                                              int, float, hipStream_t);

@@ -1,0 +1,147 @@
+// Extractor epilogue for the feature hand-over: InstanceNorm2d (affine optional, eps inside the sqrt,
+// biased variance over H x W -- what nn.InstanceNorm2d computes in eval and in training, extractor.py:135,160-162) fused
+// with the ReLU that follows it (extractor.py:187-188), written in the layout / precision the cost-volume loaders take:
+// fp32 or fp16, NCHW.  HBM-bound: the plane statistics need one read of x, the normalisation a second one (a 540 x 960
+// plane is 2 MB, far beyond LDS): 8 B read + 2 or 4 B written per element.
+//
+//   pass 1  stats_kernel: grid (chunks, B*C); a workgroup sums its chunk of one plane with 16-B loads (fp32 partials of
+//           <= 32 quads per lane, combined in fp64) and adds (sum, sum of squares) to the plane's two fp64 accumulators
+//           with global_atomic_add_f64 -- the workspace is caller-owned and zeroed on the stream by the launcher.
+//   pass 2  apply_kernel: y = max((x - mean) * rstd * gamma + beta, 0) with mean / rstd derived in fp64 per workgroup.
+#include "common.h"
+
+namespace {
+
+constexpr int IN_THREADS = 256;
+constexpr int IN_QUADS = 32;  // 16-B quads per lane and workgroup chunk (32 KiB of x per wave)
+
+__global__ __launch_bounds__(IN_THREADS) void instance_norm_stats_kernel(const float *__restrict__ x,
+                                                                          double *__restrict__ stats, long long HW)
+{
+    const long long plane = blockIdx.y;
+    const float *xp = x + plane * HW;
+    const long long q0 = (long long)blockIdx.x * IN_THREADS * IN_QUADS;  // first quad of this chunk
+    const long long nq = HW / 4;
+    float s = 0.0f, ss = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < IN_QUADS; ++k) {
+        const long long q = q0 + (long long)k * IN_THREADS + threadIdx.x;
+        if (q < nq) {
+            const f32x4 v = ld4(xp + 4 * q);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+            ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1) {  // ragged tail of the plane (HW % 4 elements)
+        const long long t = 4 * nq + threadIdx.x;
+        if (t < HW) {
+            const float v = xp[t];
+            s += v;
+            ss += v * v;
+        }
+    }
+    double ds = (double)s, dss = (double)ss;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        ds += __shfl_xor(ds, off);
+        dss += __shfl_xor(dss, off);
+    }
+    __shared__ double red[2][IN_THREADS / 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) red[0][wave] = ds, red[1][wave] = dss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int w = 0; w < IN_THREADS / 64; ++w) a += red[0][w], b += red[1][w];
+        atomicAdd(stats + 2 * plane, a);
+        atomicAdd(stats + 2 * plane + 1, b);
+    }
+}
+
+template <typename TOUT>
+__device__ __forceinline__ void store_quad(TOUT *p, f32x4 v);
+template <>
+__device__ __forceinline__ void store_quad<float>(float *p, f32x4 v) { st4(p, v); }
+template <>
+__device__ __forceinline__ void store_quad<f16>(f16 *p, f32x4 v)
+{
+    *reinterpret_cast<f16x4 *>(p) = __builtin_convertvector(v, f16x4);  // round to nearest even
+}
+
+template <typename TOUT>
+__global__ __launch_bounds__(IN_THREADS) void instance_norm_apply_kernel(const float *__restrict__ x,
+                                                                          const double *__restrict__ stats,
+                                                                          const float *__restrict__ gamma,
+                                                                          const float *__restrict__ beta,
+                                                                          TOUT *__restrict__ out, int C, long long HW,
+                                                                          float eps, int relu)
+{
+    const long long plane = blockIdx.y;
+    const int c = (int)(plane % C);
+    const double mean = stats[2 * plane] / (double)HW;
+    double var = stats[2 * plane + 1] / (double)HW - mean * mean;  // biased, like F.instance_norm
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] * rstd : rstd;
+    const float sh = (beta ? beta[c] : 0.0f) - (float)mean * g;  // y = x * g + sh
+    const float *xp = x + plane * HW;
+    TOUT *op = out + plane * HW;
+    const long long q0 = (long long)blockIdx.x * IN_THREADS * IN_QUADS;
+    const long long nq = HW / 4;
+    const float lo = relu ? 0.0f : -INFINITY;
+#pragma unroll 8
+    for (int k = 0; k < IN_QUADS; ++k) {
+        const long long q = q0 + (long long)k * IN_THREADS + threadIdx.x;
+        if (q < nq) {
+            const f32x4 v = ld4(xp + 4 * q);
+            f32x4 y;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = fmaxf(fmaf(v[i], g, sh), lo);
+            store_quad<TOUT>(op + 4 * q, y);
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1) {
+        const long long t = 4 * nq + threadIdx.x;
+        if (t < HW) op[t] = (TOUT)fmaxf(fmaf(xp[t], g, sh), lo);
+    }
+}
+
+}  // namespace
+
+extern "C" long long stereo_instance_norm_workspace_bytes(int B, int C)
+{
+    return B > 0 && C > 0 ? (long long)B * C * 2 * (long long)sizeof(double) : 0;
+}
+
+extern "C" int stereo_instance_norm_relu_f32(const float *x, const float *gamma, const float *beta, void *out,
+                                             void *workspace, int out_is_f16, int B, int C, int H, int W, float eps,
+                                             int relu, void *stream)
+{
+    if (B < 0 || C < 0 || H < 0 || W < 0 || !(eps >= 0.0f)) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || C == 0 || H == 0 || W == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(x);
+    STEREO_REQUIRE_PTR(out);
+    STEREO_REQUIRE_PTR(workspace);
+    const long long HW = (long long)H * W, planes = (long long)B * C;
+    // 16-B loads per plane need HW % 4 == 0 for every plane base to stay aligned; 8-B fp16 stores likewise
+    if (!aligned16(x) || HW % 4 != 0 || !fits_grid_yz(planes) || (reinterpret_cast<uintptr_t>(workspace) & 7u) != 0 ||
+        (out_is_f16 ? (reinterpret_cast<uintptr_t>(out) & 7u) != 0 : !aligned16(out)))
+        return STEREO_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    double *stats = static_cast<double *>(workspace);
+    if (hipMemsetAsync(stats, 0, (size_t)planes * 2 * sizeof(double), st) != hipSuccess) return STEREO_ERR_LAUNCH;
+    const long long per_wg = (long long)IN_THREADS * IN_QUADS * 4;
+    const unsigned chunks = (unsigned)((HW + per_wg - 1) / per_wg);
+    dim3 grid(chunks, (unsigned)planes);
+    hipLaunchKernelGGL(instance_norm_stats_kernel, grid, dim3(IN_THREADS), 0, st, x, stats, HW);
+    STEREO_LAUNCH_CHECK();
+    if (out_is_f16)
+        hipLaunchKernelGGL(instance_norm_apply_kernel<f16>, grid, dim3(IN_THREADS), 0, st, x, stats, gamma, beta,
+                           static_cast<f16 *>(out), C, HW, eps, relu);
+    else
+        hipLaunchKernelGGL(instance_norm_apply_kernel<float>, grid, dim3(IN_THREADS), 0, st, x, stats, gamma, beta,
+                           static_cast<float *>(out), C, HW, eps, relu);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}

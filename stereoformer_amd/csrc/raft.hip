@@ -86,7 +86,8 @@ struct PyrOut {
 // per output, 32-bit offsets from a workgroup-uniform base, no bounds tests on interior tiles.  (Pooling the pyramid
 // levels in this epilogue with cross-lane adds was bit-identical but slower than one streaming pass over level 0:
 // 0.631 vs 0.583 ms at [8,256,136,240].)
-__global__ __launch_bounds__(256) void allpairs_lds_kernel(const float *__restrict__ f1, const float *__restrict__ f2,
+template <typename TIN>
+__global__ __launch_bounds__(256) void allpairs_lds_kernel(const TIN *__restrict__ f1, const TIN *__restrict__ f2,
                                                            float *__restrict__ out, int C, int H, int W1, int W2,
                                                            float sqrt_c, float inv_sqrt_c, int mul_exact)
 {
@@ -100,8 +101,8 @@ __global__ __launch_bounds__(256) void allpairs_lds_kernel(const float *__restri
     const int mw = (wave >> 1) * 64, nw = (wave & 1) * 64;  // wave origin inside the tile
 
     const size_t HW1 = (size_t)H * W1, HW2 = (size_t)H * W2;
-    const float *a_base = f1 + (size_t)b * C * HW1 + (size_t)h * W1;
-    const float *b_base = f2 + (size_t)b * C * HW2 + (size_t)h * W2;
+    const TIN *a_base = f1 + (size_t)b * C * HW1 + (size_t)h * W1;
+    const TIN *b_base = f2 + (size_t)b * C * HW2 + (size_t)h * W2;
 
     // staging slots: quad q = tid + k*256 of a [16][32 quads] slice
     int sc[2], sx[2];
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void allpairs_lds_kernel(const float *__restri
         sc[k] = q >> 5;
         sx[k] = (q & 31) * 4;
     }
-    f32x4 pa[2], pb[2];
+    typename Quad<TIN>::raw pa[2], pb[2];  // raw quads (16 B fp32 / 8 B fp16), widened at commit
     unsigned okmask = 0;  // applied at commit time so that the loads stay in flight during the MFMA block
     auto issue = [&](int c0) {
         okmask = 0;
@@ -120,8 +121,8 @@ __global__ __launch_bounds__(256) void allpairs_lds_kernel(const float *__restri
             const int c = c0 + sc[k];
             const bool oka = c < C && M0 + sx[k] + 3 < W1;  // W % 4 == 0: a quad is all-in or all-out
             const bool okb = c < C && N0 + sx[k] + 3 < W2;
-            pa[k] = ld4(a_base + (oka ? (size_t)c * HW1 + M0 + sx[k] : 0));
-            pb[k] = ld4(b_base + (okb ? (size_t)c * HW2 + N0 + sx[k] : 0));
+            pa[k] = Quad<TIN>::ld(a_base + (oka ? (size_t)c * HW1 + M0 + sx[k] : 0));
+            pb[k] = Quad<TIN>::ld(b_base + (okb ? (size_t)c * HW2 + N0 + sx[k] : 0));
             okmask |= (oka ? (1u << k) : 0u) | (okb ? (4u << k) : 0u);
         }
     };
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(256) void allpairs_lds_kernel(const float *__restri
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            *reinterpret_cast<f32x4 *>(&As[buf][sc[k]][sx[k]]) = (okmask >> k) & 1u ? pa[k] : zero;
-            *reinterpret_cast<f32x4 *>(&Bs[buf][sc[k]][sx[k]]) = (okmask >> (2 + k)) & 1u ? pb[k] : zero;
+            *reinterpret_cast<f32x4 *>(&As[buf][sc[k]][sx[k]]) = (okmask >> k) & 1u ? Quad<TIN>::widen(pa[k]) : zero;
+            *reinterpret_cast<f32x4 *>(&Bs[buf][sc[k]][sx[k]]) = (okmask >> (2 + k)) & 1u ? Quad<TIN>::widen(pb[k]) : zero;
         }
     };
 
@@ -347,34 +348,12 @@ __global__ __launch_bounds__(256) void alt_corr_lookup_kernel(const float *__res
 
 }  // namespace
 
-extern "C" int stereo_allpairs_pyramid_f32(const float *fmap1, const float *fmap2, float *const *levels, int B, int C,
-                                           int H, int W1, int W2, int num_levels, void *stream)
+// levels 1..num_levels from level 0 (shared by the fp32 and fp16 entry points)
+static int pool_pyramid(float *const *levels, int B, int H, int W1, int W2, int num_levels, hipStream_t st)
 {
-    if (B < 0 || C < 0 || H < 0 || W1 < 0 || W2 < 0 || num_levels < 0) return STEREO_ERR_BAD_SHAPE;
-    if (num_levels + 1 > STEREO_MAX_LEVELS) return STEREO_ERR_UNSUPPORTED;
-    if (B == 0 || H == 0 || W1 == 0 || W2 == 0) return STEREO_OK;
-    STEREO_REQUIRE_PTR(fmap1);
-    STEREO_REQUIRE_PTR(fmap2);
-    STEREO_REQUIRE_PTR(levels);
-    for (int i = 0, w = W2; i <= num_levels; ++i, w /= 2)
-        if (w > 0) STEREO_REQUIRE_PTR(levels[i]);
-    if (!fits_grid_yz((long long)B * H) || !fits_grid_yz((W1 + 127) / 128)) return STEREO_ERR_UNSUPPORTED;
-    hipStream_t st = as_stream(stream);
-    dim3 grid((W2 + 127) / 128, (W1 + 127) / 128, (unsigned)(B * H));
-    int first_unpooled = 1;  // first level still to be produced by the pooling kernels
-    if (W1 % 4 == 0 && W2 % 4 == 0 && aligned16(fmap1) && aligned16(fmap2) && (long long)W1 * W2 < (1LL << 31)) {
-        const float sq = sqrtf((float)C);
-        int e2 = 0;
-        const int mul_exact = frexpf(sq, &e2) == 0.5f ? 1 : 0;  // sqrt(C) a power of two: x * (1/sqrt) == x / sqrt
-        hipLaunchKernelGGL(allpairs_lds_kernel, grid, dim3(256), 0, st, fmap1, fmap2, levels[0], C, H, W1, W2, sq,
-                           1.0f / sq, mul_exact);
-    } else {
-        hipLaunchKernelGGL(allpairs_kernel, grid, dim3(256), 0, st, fmap1, fmap2, levels[0], C, H, W1, W2,
-                           sqrtf((float)C));
-    }
-    STEREO_LAUNCH_CHECK();
+    int first_unpooled = 1;  // first level still to be produced by the single-level pooling kernel
     const long long rows = (long long)B * H * W1;
-    if (first_unpooled == 1 && num_levels >= 2) {  // levels 1..NL in one pass over level 0
+    if (num_levels >= 2) {  // levels 1..NL in one pass over level 0
         const int NL = num_levels >= 4 ? 4 : num_levels >= 3 ? 3 : 2;
         bool ok = W2 % (1 << NL) == 0 && aligned16(levels[0]);
         for (int i = 1; i <= NL; ++i) ok = ok && aligned16(levels[i]);
@@ -405,6 +384,70 @@ extern "C" int stereo_allpairs_pyramid_f32(const float *fmap1, const float *fmap
         w = wo;
     }
     return STEREO_OK;
+}
+
+static int allpairs_args_check(const void *fmap1, const void *fmap2, float *const *levels, int B, int C, int H, int W1,
+                               int W2, int num_levels)
+{
+    if (B < 0 || C < 0 || H < 0 || W1 < 0 || W2 < 0 || num_levels < 0) return STEREO_ERR_BAD_SHAPE;
+    if (num_levels + 1 > STEREO_MAX_LEVELS) return STEREO_ERR_UNSUPPORTED;
+    if (B == 0 || H == 0 || W1 == 0 || W2 == 0) return 1;  // nothing to do
+    STEREO_REQUIRE_PTR(fmap1);
+    STEREO_REQUIRE_PTR(fmap2);
+    STEREO_REQUIRE_PTR(levels);
+    for (int i = 0, w = W2; i <= num_levels; ++i, w /= 2)
+        if (w > 0) STEREO_REQUIRE_PTR(levels[i]);
+    if (!fits_grid_yz((long long)B * H) || !fits_grid_yz((W1 + 127) / 128)) return STEREO_ERR_UNSUPPORTED;
+    return STEREO_OK;
+}
+
+template <typename TIN>
+static int allpairs_fast(const TIN *fmap1, const TIN *fmap2, float *level0, int B, int C, int H, int W1, int W2,
+                         hipStream_t st)
+{
+    if (!(W1 % 4 == 0 && W2 % 4 == 0 && aligned_quad<TIN>(fmap1) && aligned_quad<TIN>(fmap2) &&
+          (long long)W1 * W2 < (1LL << 31)))
+        return STEREO_ERR_UNSUPPORTED;
+    const float sq = sqrtf((float)C);
+    int e2 = 0;
+    const int mul_exact = frexpf(sq, &e2) == 0.5f ? 1 : 0;  // sqrt(C) a power of two: x * (1/sqrt) == x / sqrt
+    dim3 grid((W2 + 127) / 128, (W1 + 127) / 128, (unsigned)(B * H));
+    hipLaunchKernelGGL(allpairs_lds_kernel<TIN>, grid, dim3(256), 0, st, fmap1, fmap2, level0, C, H, W1, W2, sq, 1.0f / sq,
+                       mul_exact);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+extern "C" int stereo_allpairs_pyramid_f32(const float *fmap1, const float *fmap2, float *const *levels, int B, int C,
+                                           int H, int W1, int W2, int num_levels, void *stream)
+{
+    const int chk = allpairs_args_check(fmap1, fmap2, levels, B, C, H, W1, W2, num_levels);
+    if (chk != STEREO_OK) return chk > 0 ? STEREO_OK : chk;
+    hipStream_t st = as_stream(stream);
+    int rc = allpairs_fast<float>(fmap1, fmap2, levels[0], B, C, H, W1, W2, st);
+    if (rc == STEREO_ERR_UNSUPPORTED) {
+        dim3 grid((W2 + 127) / 128, (W1 + 127) / 128, (unsigned)(B * H));
+        hipLaunchKernelGGL(allpairs_kernel, grid, dim3(256), 0, st, fmap1, fmap2, levels[0], C, H, W1, W2,
+                           sqrtf((float)C));
+        STEREO_LAUNCH_CHECK();
+        rc = STEREO_OK;
+    }
+    if (rc != STEREO_OK) return rc;
+    return pool_pyramid(levels, B, H, W1, W2, num_levels, st);
+}
+
+// A8 with fp16 features: fmap1 / fmap2 [B,C,H,W] fp16, pyramid fp32.  W1 % 4 == 0 && W2 % 4 == 0 and
+// 8-B aligned bases, else STEREO_ERR_UNSUPPORTED (the host layer then widens the features itself).
+extern "C" int stereo_allpairs_pyramid_f16(const void *fmap1, const void *fmap2, float *const *levels, int B, int C,
+                                           int H, int W1, int W2, int num_levels, void *stream)
+{
+    const int chk = allpairs_args_check(fmap1, fmap2, levels, B, C, H, W1, W2, num_levels);
+    if (chk != STEREO_OK) return chk > 0 ? STEREO_OK : chk;
+    hipStream_t st = as_stream(stream);
+    const int rc = allpairs_fast<f16>(static_cast<const f16 *>(fmap1), static_cast<const f16 *>(fmap2), levels[0], B, C, H,
+                                      W1, W2, st);
+    if (rc != STEREO_OK) return rc;
+    return pool_pyramid(levels, B, H, W1, W2, num_levels, st);
 }
 
 extern "C" int stereo_corr_lookup_f32(const float *const *levels, const float *coords, float *out, int B, int H, int W1,

@@ -754,3 +754,78 @@ extern "C" int stereo_corr_soft_argmin_f32(const float *left, const float *right
     }
     return gwc_dispatch<EPI_ARGMIN>(left, right, disp, B, C, H, W, D, 1, match_similarity ? 1.0f : -1.0f, stream);
 }
+
+// ---------------------------------------------------------------- fp16 feature operands
+// left / right [B,C,H,W] fp16 (what an fp16 extractor hands over), every output fp32: the matrix-core kernels widen the
+// features on the way into LDS, so the arithmetic is the fp32 path's on the fp16-rounded values and the read side of the
+// launch is half the bytes.  These entry points have NO slow path: outside the matrix-core envelope (C <= 32, W % 4 == 0,
+// D <= 192 / 256, 8-B aligned bases, channels per group in {2,4,8,16}) they return STEREO_ERR_UNSUPPORTED and the host
+// layer widens the features itself before calling the fp32 entry point.
+namespace {
+int f16_args(const void *left, const void *right, int B, int C, int H, int W, int D, bool softmax)
+{
+    if (B < 0 || C < 0 || H < 0 || W < 0 || D < 0) return STEREO_ERR_BAD_SHAPE;
+    if (softmax && D == 0 && B > 0 && H > 0 && W > 0) return STEREO_ERR_BAD_SHAPE;  // softmax over an empty axis
+    if (B == 0 || H == 0 || W == 0 || D == 0) return 1;                           // nothing to do
+    if (C == 0) return STEREO_ERR_BAD_SHAPE;
+    if (left == nullptr || right == nullptr) return STEREO_ERR_NULL_POINTER;
+    return STEREO_OK;
+}
+}  // namespace
+
+extern "C" int stereo_corr_volume_f16(const void *left, const void *right, float *vol, int B, int C, int H, int W, int D,
+                                      void *stream)
+{
+    const int chk = f16_args(left, right, B, C, H, W, D, false);
+    if (chk != STEREO_OK) return chk > 0 ? STEREO_OK : chk;
+    STEREO_REQUIRE_PTR(vol);
+    return stereo_corr_volume_mfma<f16>(static_cast<const f16 *>(left), static_cast<const f16 *>(right), vol, nullptr, B, C, H,
+                                        W, D, 1.0f, as_stream(stream));
+}
+
+extern "C" int stereo_gwc_volume_f16(const void *left, const void *right, float *vol, int B, int C, int H, int W, int D,
+                                     int G, void *stream)
+{
+    if (G <= 0 || (C >= 0 && C % G != 0)) return STEREO_ERR_BAD_SHAPE;
+    const int chk = f16_args(left, right, B, C, H, W, D, false);
+    if (chk != STEREO_OK) return chk > 0 ? STEREO_OK : chk;
+    STEREO_REQUIRE_PTR(vol);
+    const f16 *L = static_cast<const f16 *>(left), *R = static_cast<const f16 *>(right);
+    if (G == 1) return stereo_corr_volume_mfma<f16>(L, R, vol, nullptr, B, C, H, W, D, 1.0f, as_stream(stream));
+    return stereo_gwc_mean_argmin_mfma<f16>(L, R, vol, nullptr, nullptr, B, C, H, W, D, G, 1.0f, as_stream(stream));
+}
+
+extern "C" int stereo_corr_volume_soft_argmin_f16(const void *left, const void *right, float *vol, float *disp, int B,
+                                                  int C, int H, int W, int D, int match_similarity, void *stream)
+{
+    const int chk = f16_args(left, right, B, C, H, W, D, true);
+    if (chk != STEREO_OK) return chk > 0 ? STEREO_OK : chk;
+    STEREO_REQUIRE_PTR(vol);
+    STEREO_REQUIRE_PTR(disp);
+    return stereo_corr_volume_mfma<f16>(static_cast<const f16 *>(left), static_cast<const f16 *>(right), vol, disp, B, C, H, W,
+                                        D, match_similarity ? 1.0f : -1.0f, as_stream(stream));
+}
+
+extern "C" int stereo_gwc_volume_soft_argmin_f16(const void *left, const void *right, float *vol, float *mean, float *disp,
+                                                 int B, int C, int H, int W, int D, int G, int match_similarity,
+                                                 void *stream)
+{
+    if (G <= 0 || (C >= 0 && C % G != 0)) return STEREO_ERR_BAD_SHAPE;
+    const int chk = f16_args(left, right, B, C, H, W, D, true);
+    if (chk != STEREO_OK) return chk > 0 ? STEREO_OK : chk;
+    STEREO_REQUIRE_PTR(vol);
+    STEREO_REQUIRE_PTR(mean);
+    STEREO_REQUIRE_PTR(disp);
+    return stereo_gwc_mean_argmin_mfma<f16>(static_cast<const f16 *>(left), static_cast<const f16 *>(right), vol, mean, disp,
+                                            B, C, H, W, D, G, match_similarity ? 1.0f : -1.0f, as_stream(stream));
+}
+
+extern "C" int stereo_corr_soft_argmin_f16(const void *left, const void *right, float *disp, int B, int C, int H, int W,
+                                           int D, int match_similarity, void *stream)
+{
+    const int chk = f16_args(left, right, B, C, H, W, D, true);
+    if (chk != STEREO_OK) return chk > 0 ? STEREO_OK : chk;
+    STEREO_REQUIRE_PTR(disp);
+    return stereo_corr_soft_argmin_mfma<f16>(static_cast<const f16 *>(left), static_cast<const f16 *>(right), disp, B, C, H,
+                                             W, D, match_similarity ? 1.0f : -1.0f, as_stream(stream));
+}

@@ -151,13 +151,16 @@ def group_mean_soft_argmin(volume_g, match_similarity=True, return_mean=False):
 def corr_soft_argmin(left_feature, right_feature, max_disp, match_similarity=True):
     """Fused ``DisparityEstimation(D)(CostVolume(D,'correlation')(L,R))`` without
     materialising the volume (opt-in fast path; same numbers as the two-step chain)."""
-    L = N.dev_f32(left_feature, "corr_soft_argmin: left_feature")
-    R = N.dev_f32(right_feature, "corr_soft_argmin: right_feature")
+    L = N.dev_feat(left_feature, "corr_soft_argmin: left_feature")   # fp32 or fp16 features (SURVEY 8(f) N2)
+    R = N.dev_feat(right_feature, "corr_soft_argmin: right_feature")
+    if L.dtype != R.dtype:
+        L, R = L.float(), R.float()
     if L.dim() != 4 or L.shape != R.shape:
         raise ValueError("corr_soft_argmin: expected two [B,C,H,W] tensors of one shape")
     B, C, H, W = L.shape
     disp = torch.empty((B, H, W), device=L.device, dtype=torch.float32)
     with torch.cuda.device(L.device):
-        N.call("stereo_corr_soft_argmin_f32", N.ptr(L), N.ptr(R), N.ptr(disp), B, C, H, W, int(max_disp),
-               1 if match_similarity else 0, N.stream_ptr(L.device))
+        N.feat_call("stereo_corr_soft_argmin", [L, R],
+                    lambda f: (N.ptr(f[0]), N.ptr(f[1]), N.ptr(disp), B, C, H, W, int(max_disp),
+                               1 if match_similarity else 0, N.stream_ptr(L.device)))
     return disp

@@ -116,7 +116,11 @@ class RAFTStereoLoop(nn.Module):
         return tuple(out) if test_mode else out
 
     def _forward_eager(self, fmap1, fmap2, net_list, inp_list, iters, flow_init, test_mode):
-        corr_fn = CorrBlock1D(fmap1.float(), fmap2.float(), radius=self.corr_radius, num_levels=self.corr_levels)
+        # raft_stereo.py:155-156 widens the feature maps with `.float()`; fp16 maps are handed over as they are -- the
+        # all-pairs kernel widens them on the way into LDS (same numbers, half the read bytes)
+        keep = (torch.float16, torch.float32)
+        corr_fn = CorrBlock1D(fmap1 if fmap1.dtype in keep else fmap1.float(), fmap2 if fmap2.dtype in keep else fmap2.float(),
+                              radius=self.corr_radius, num_levels=self.corr_levels)
         N, _, H, W = net_list[0].shape
         coords0 = coords_grid(N, H, W, device=fmap1.device)
         coords1 = coords0.clone()

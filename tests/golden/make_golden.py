@@ -565,6 +565,31 @@ def g13_flow_init_padder():
     save("g13_flow_init_padder", **out)
 
 
+# ------------------------------------------------------------------ G14
+def g14_extractor_epilogue():
+    """InstanceNorm2d + ReLU as the reference's extractor applies them (extractor.py:135,187-188 and the residual blocks'
+    norm1/relu :38-41,63): the tensors entering norm1 / leaving relu1 of BasicEncoder(norm_fn='instance') and of its first
+    ResidualBlock are captured with hooks; plus an affine InstanceNorm2d (weight / bias) without ReLU."""
+    from models.IterativeLocalCostVolume.extractor.extractor import BasicEncoder
+    torch.manual_seed(1401)
+    enc = BasicEncoder(output_dim=32, norm_fn="instance", downsample=2).eval()
+    cap = {}
+    enc.norm1.register_forward_hook(lambda m, a, o: cap.__setitem__("x1", a[0].clone()))
+    enc.relu1.register_forward_hook(lambda m, a, o: cap.__setitem__("y1", o.clone()))
+    blk = enc.layer1[0]
+    blk.norm1.register_forward_hook(lambda m, a, o: cap.__setitem__("x2", a[0].clone()))
+    img = torch.rand(2, 3, 20, 36) * 2 - 1
+    enc(img)
+    out = {"x1": npy(cap["x1"]), "y1": npy(cap["y1"]), "x2": npy(cap["x2"]),
+           "y2": npy(torch.relu(blk.norm1(cap["x2"])))}
+    aff = torch.nn.InstanceNorm2d(6, eps=1e-3, affine=True).eval()
+    aff.weight.data = torch.linspace(0.5, 2.0, 6)
+    aff.bias.data = torch.linspace(-1.0, 1.0, 6)
+    xa = torch.randn(1, 6, 9, 12) * 3 + 5           # large mean relative to the spread
+    out.update(xa=npy(xa), ya=npy(aff(xa)), wa=npy(aff.weight.data), ba=npy(aff.bias.data))
+    save("g14_extractor_epilogue", **out)
+
+
 def check_oracle_cfg1():
     """Not a fixture: proves the C oracle == the reference at BASELINE
     configs[0] (1 pair 384x768 D=64: corr -> soft-argmin -> local lookup)."""
@@ -602,5 +627,6 @@ if __name__ == "__main__":
     g11_backward()
     g12_raft_backward()
     g13_flow_init_padder()
+    g14_extractor_epilogue()
     if CHECK:
         check_oracle_cfg1()

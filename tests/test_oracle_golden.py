@@ -143,3 +143,13 @@ def test_cross_attention_identity_i3(oracle, golden):
     # neginf mask: probability mass only on in-image taps -> disp[w] <= w
     _, dn = oracle.cross_attention(L, R, None, D, mask="neginf", scale="sqrt_c")
     assert (dn <= np.arange(W)[None, None, :] + 1e-4).all()
+
+
+def test_instance_norm_relu_golden(oracle, golden):
+    """N2 extractor epilogue: the oracle against tensors captured inside the reference's BasicEncoder(norm_fn='instance')
+    (norm1 -> relu1, a residual block's norm + relu) and an affine InstanceNorm2d without ReLU."""
+    g = golden("g14_extractor_epilogue")
+    np.testing.assert_allclose(oracle.instance_norm_relu(g["x1"]), g["y1"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(oracle.instance_norm_relu(g["x2"]), g["y2"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(oracle.instance_norm_relu(g["xa"], g["wa"], g["ba"], eps=1e-3, relu=False), g["ya"],
+                               rtol=1e-5, atol=5e-6)

@@ -119,9 +119,43 @@ def main():
                 q2 = torch.randn(bb, cc, hh, ww, device=dev)
                 a2 = S.CrossAttentionCostVolume(dd, "neginf", "sqrt_c")
                 bnd = dd * ww - dd * (dd - 1) / 2
-                add(f"A7_cross_attention {nm}", timeit(lambda: a2(q1, q2), 3, 1),
-                    (4 * bb * cc * hh * ww * 4 + bb * hh * ww * 4) / 1e9, 2 * 2 * bb * hh * cc * bnd / 1e9, bound="mfma")
+                gb, gf = (4 * bb * cc * hh * ww * 4 + bb * hh * ww * 4) / 1e9, 2 * 2 * bb * hh * cc * bnd / 1e9
+                ms = timeit(lambda: a2(q1, q2), 20, 3)
+                # 11 flop/B: left of the f32 ridge (~20 flop/B) -> the HBM roofline is the relevant one; both are reported
+                add(f"A7_cross_attention {nm}", ms, gb, gf, bound="hbm",
+                    note=f"channel-chunked pipelined kernel; {gf / ms / MFMA_F32:.3f} of the f32 MFMA peak on algorithmic flops")
+                add(f"A7_cross_attention(disp only) {nm}", timeit(lambda: a2(q1, q2, need_out=False), 20, 3),
+                    (2 * bb * cc * hh * ww * 4 + bb * hh * ww * 4) / 1e9, gf / 2, bound="hbm")
+                with S._native.test_options(att_kernel=4):
+                    add(f"A7_cross_attention {nm} [two-pass kernel v4, for comparison]", timeit(lambda: a2(q1, q2), 20, 3),
+                        gb, gf, bound="hbm")
                 del q1, q2
+        if want("N2_fp16"):   # fp16 feature operands (fp32 arithmetic / outputs) + the extractor epilogue
+            Lh, Rh = L.half(), R.half()
+            add("N2 A1_corr_volume cfg-2, fp16 features", timeit(lambda: S.CostVolume(D)(Lh, Rh), args.reps),
+                (2 * N * C * 2 + N * D * 4) / 1e9)
+            add("N2 A3+mean+A4 fused cfg-2, fp16 features", timeit(lambda: S.build_gwc_volume_with_disparity(Lh, Rh, D, G, return_mean=True), 5),
+                (2 * N * C * 2 + N * G * D * 4 + N * D * 4 + N * 4) / 1e9)
+            add("N2 A1+A4 corr_soft_argmin cfg-2, fp16 features", timeit(lambda: S.corr_soft_argmin(Lh, Rh, D), args.reps),
+                (2 * N * C * 2 + N * 4) / 1e9, 2 * B * H * C * (D * W - D * (D - 1) / 2) / 1e9, bound="mfma")
+            att16 = S.CrossAttentionCostVolume(D, "zero", "sqrt_c")
+            add("N2 A7_cross_attention cfg-3, fp16 features", timeit(lambda: att16(Lh, Rh), 5, 1),
+                (2 * N * C * 2 + N * C * 4 + N * 4) / 1e9, 2 * 2 * B * H * C * (D * W - D * (D - 1) / 2) / 1e9, bound="mfma")
+            raw = torch.randn(B, C, H, W, device=dev)
+            add("N2 instance_norm_relu [8,32,540,960] -> fp16", timeit(lambda: S.instance_norm_relu(raw), args.reps),
+                (N * C * (4 + 4 + 2)) / 1e9, note="two reads of x (statistics, apply) + one fp16 write")
+            add("N2 instance_norm_relu [8,32,540,960] -> fp32", timeit(lambda: S.instance_norm_relu(raw, out_dtype=torch.float32), args.reps),
+                (N * C * (4 + 4 + 4)) / 1e9)
+            del Lh, Rh, raw
+            f1h, f2h = f1.half(), f2.half()
+            pyr_b = Br * Hr * Wr * (Wr + Wr // 2 + Wr // 4 + Wr // 8 + Wr // 16) * 4
+            add("N2 A8_allpairs+pyramid cfg-4, fp16 features", timeit(lambda: S.CorrBlock1D(f1h, f2h, 4, 4), args.reps),
+                (2 * Br * Cr * Hr * Wr * 2 + pyr_b) / 1e9, 2 * Br * Hr * Wr * Wr * Cr / 1e9, bound="mfma")
+            a16 = S.CrossAttentionCostVolume(48, "neginf", "sqrt_c")
+            bnd = 48 * Wr - 48 * 47 / 2
+            add("N2 A7_cross_attention cfg-3b [8,256,136,240] D=48, fp16 features", timeit(lambda: a16(f1h, f2h), 20, 3),
+                (3 * Br * Cr * Hr * Wr * 2 + Br * Cr * Hr * Wr * 4 + Br * Hr * Wr * 4) / 1e9, 2 * 2 * Br * Hr * Cr * bnd / 1e9)
+            del f1h, f2h
         if want("A8_allpairs"):
             pyr_bytes = Br * Hr * Wr * (Wr + Wr // 2 + Wr // 4 + Wr // 8 + Wr // 16) * 4
             add("A8_allpairs+pyramid cfg-4 [8,256,136,240]", timeit(lambda: S.CorrBlock1D(f1, f2, 4, 4), args.reps),
