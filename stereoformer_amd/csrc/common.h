@@ -128,3 +128,7 @@ int stereo_corr_volume_bwd_mfma(const float *left, const float *right, const flo
 template <typename TIN>
 int stereo_cross_attention_chunked(const TIN *L, const TIN *R, const TIN *V, float *out, float *disp, int B, int C, int Cv,
                                    int H, int W, int D, int mask_mode, float sc, hipStream_t st);
+// corr_chunked.hip: A1 (+ A4) for C > 32, channels in 32-channel chunks (D <= 128); same conventions as above.
+template <typename TIN>
+int stereo_corr_volume_chunked(const TIN *L, const TIN *R, float *vol, float *disp, int B, int C, int H, int W, int D,
+                               float sgn, hipStream_t st);

@@ -289,7 +289,8 @@ template <typename TIN>
 int stereo_corr_volume_mfma(const TIN *L, const TIN *R, float *vol, float *disp, int B, int C, int H, int W, int D,
                             float sgn, hipStream_t st)
 {
-    if (C > 32 || D > 256 || D < 1 || W % 4 != 0 || !aligned_quad<TIN>(L) || !aligned_quad<TIN>(R) || !aligned16(vol))
+    if (C > 32) return stereo_corr_volume_chunked<TIN>(L, R, vol, disp, B, C, H, W, D, sgn, st);  // 32-channel chunks
+    if (D > 256 || D < 1 || W % 4 != 0 || !aligned_quad<TIN>(L) || !aligned_quad<TIN>(R) || !aligned16(vol))
         return STEREO_ERR_UNSUPPORTED;
     if ((long long)32 * H * W >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
     const int nt = (D + 31) / 32 + 1;

@@ -206,3 +206,31 @@ def test_cfg2_chain_fp16_handover_full_size_rows(S, oracle):
     L32, R32 = S.instance_norm_relu(dev(raw), out_dtype=torch.float32), S.instance_norm_relu(dev(rawR), out_dtype=torch.float32)
     _, disp32 = S.build_gwc_volume_with_disparity(L32, R32, D, G)
     assert (disp32 - disp).abs().max().item() < 5e-2     # informational bound: fp16 features, not a parity claim
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 5, 120, 24), (1, 64, 3, 300, 64), (1, 40, 2, 516, 100), (1, 33, 2, 128, 128), (2, 96, 1, 36, 7),
+                                   (1, 256, 2, 960, 24), (1, 48, 3, 8, 5)])
+@pytest.mark.parametrize("half", [False, True])
+def test_corr_volume_channel_chunked(S, oracle, shape, half):
+    """A1 and A1+A4 for C > 32 on the matrix cores (32-channel chunks through two LDS buffers, band tiles accumulated in
+    registers, skew sheet, row-contiguous flush) -- incl. the reference-native shape class (256 channels, D = 24,
+    baseline.py:63,114) -- against the oracle and against the VALU fallback; fp32 and fp16 features."""
+    B, C, H, W, D = shape
+    rng = np.random.default_rng(81)
+    L0 = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    R0 = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    if half:
+        Ld, L = h16(L0)
+        Rd, R = h16(R0)
+    else:
+        Ld, Rd, L, R = torch.from_numpy(L0).cuda(), torch.from_numpy(R0).cuda(), L0, R0
+    ref = oracle.corr_volume(L, R, D)
+    close(S.CostVolume(D)(Ld, Rd), ref, **VOL_TOL)
+    for sim in (True, False):
+        for tpw in (0, 1, 3):
+            with S._native.test_options(tiles_per_wg=tpw):
+                v, d = S.corr_volume_with_disparity(Ld, Rd, D, match_similarity=sim)
+            close(v, ref, **VOL_TOL)
+            disp_close(d, oracle.soft_argmin(ref, sim), D)
+    with S._native.test_options(corr_mfma=0):        # the VALU kernel it replaces at these shapes
+        close(S.CostVolume(D)(Ld.float(), Rd.float()), ref, **VOL_TOL)

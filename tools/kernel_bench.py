@@ -65,6 +65,21 @@ def main():
         if want("A1_corr_volume"):
             add("A1_corr_volume cfg-2", timeit(lambda: S.CostVolume(D)(L, R), args.reps),
                 (2 * N * C * 4 + N * D * 4) / 1e9, 2 * B * H * C * (D * W - D * (D - 1) / 2) / 1e9)
+        if want("A1_corr_volume"):   # the reference's own use: 256 channels at 1/8 scale, D = 192 // 8 (baseline.py:63,114)
+            Bn, Cn, Hn, Wn, Dn = 8, 256, 68, 120, 24
+            Ln, Rn = torch.randn(Bn, Cn, Hn, Wn, device=dev), torch.randn(Bn, Cn, Hn, Wn, device=dev)
+            nb = (2 * Bn * Cn * Hn * Wn * 4 + Bn * Dn * Hn * Wn * 4) / 1e9
+            nf = 2 * Bn * Hn * Cn * (Dn * Wn - Dn * (Dn - 1) / 2) / 1e9
+            add("A1_corr_volume reference-native [8,256,68,120] D=24", timeit(lambda: S.CostVolume(Dn)(Ln, Rn), 50, 5), nb, nf,
+                note="channel-chunked matrix-core kernel")
+            add("A1+A4 corr_volume_with_disparity reference-native", timeit(lambda: S.corr_volume_with_disparity(Ln, Rn, Dn), 50, 5),
+                nb + Bn * Hn * Wn * 4 / 1e9, nf)
+            with S._native.test_options(corr_mfma=0):
+                add("A1_corr_volume reference-native [VALU kernel, for comparison]", timeit(lambda: S.CostVolume(Dn)(Ln, Rn), 50, 5), nb, nf)
+            Lh, Rh = Ln.half(), Rn.half()
+            add("A1_corr_volume reference-native, fp16 features", timeit(lambda: S.CostVolume(Dn)(Lh, Rh), 50, 5),
+                (2 * Bn * Cn * Hn * Wn * 2 + Bn * Dn * Hn * Wn * 4) / 1e9, nf)
+            del Ln, Rn, Lh, Rh
         if want("A3_gwc_volume"):
             add("A3_gwc_volume cfg-2 G=8", timeit(lambda: S.build_gwc_volume(L, R, D, G), 5),
                 (2 * N * C * 4 + N * G * D * 4) / 1e9)
