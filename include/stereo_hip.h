@@ -248,6 +248,16 @@ int stereo_allpairs_pyramid_bwd_f32(const float *fmap1, const float *fmap2, floa
 int stereo_resize_bilinear_bwd_f32(const float *grad_out, float *grad_in_zeroed, int NC, int Hi, int Wi, int Ho, int Wo,
                                    int align_corners, float scale, void *stream);
 
+/* N3 completed: backward of A6 (variance_local_cost_volume.py:34-78 as autograd differentiates it; grad_vol must be
+ * zero-filled by the caller) and of A2 ('difference' / 'concat', build_cost_volume.py:21-37; either output may be NULL). */
+int stereo_variance_lookup_bwd_f32(const float *vol, const float *disp, const float *grad_out, float *grad_vol_zeroed,
+                                   float *grad_disp, int B, int D, int H, int W, float gamma, int S, int consider_valid,
+                                   void *stream);
+int stereo_diff_volume_bwd_f32(const float *grad_vol, float *grad_left, float *grad_right,
+                               int B, int C, int H, int W, int D, void *stream);
+int stereo_concat_volume_bwd_f32(const float *grad_vol, float *grad_left, float *grad_right,
+                                 int B, int C, int H, int W, int D, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * N2: feature hand-over in fp16 + the extractor's fused norm epilogue.
  * Reference sites: the fnet output under autocast is fp16 and is widened by `.float()` before the correlation

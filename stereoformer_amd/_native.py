@@ -62,6 +62,9 @@ SIGNATURES = {
     "stereo_soft_argmin_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_gwc_volume_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_local_lookup_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "stereo_variance_lookup_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "stereo_diff_volume_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "stereo_concat_volume_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_upsample_convex_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_gru_reset_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp],
     "stereo_gru_blend_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp],
@@ -160,8 +163,8 @@ def dev_f32(t: torch.Tensor, name: str, dense_ok: bool = False) -> torch.Tensor:
         raise TypeError(f"{name}: expected float32, got {t.dtype} (the path computes in f32)")
     if torch.is_grad_enabled() and t.requires_grad:
         raise RuntimeError(
-            f"{name}: this op is forward-only (backward exists for CostVolume('correlation'), build_gwc_volume, "
-            "DisparityEstimation(WithProb) and LocalCostVolume - SURVEY 8(f) N3); call under torch.no_grad()")
+            f"{name}: this op is forward-only (PytorchAlternateCorrBlock1D, build_cost_volume_from_volume, the fused "
+            "inference entry points); every module surface of the path has a backward - call this one under torch.no_grad()")
     if dense_ok and t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
         return t
     return t.contiguous()

@@ -93,6 +93,32 @@ class _GwcWithDisparityFn(torch.autograd.Function):
         return gl, gr, None, None, None
 
 
+class _ShiftVolumeFn(torch.autograd.Function):
+    """Differentiable 'difference' / 'concat' volume (A2): HIP forward + HIP backward (shifted plane sums)."""
+
+    @staticmethod
+    def forward(ctx, left, right, max_disp, concat):
+        B, C, H, W = left.shape
+        D = int(max_disp)
+        vol = torch.empty((B, 2 * C if concat else C, D, H, W), device=left.device, dtype=torch.float32)
+        with torch.cuda.device(left.device):
+            N.call("stereo_concat_volume_f32" if concat else "stereo_diff_volume_f32", N.ptr(left), N.ptr(right), N.ptr(vol),
+                   B, C, H, W, D, N.stream_ptr(left.device))
+        ctx.cfg = (B, C, H, W, D, bool(concat))
+        return vol
+
+    @staticmethod
+    def backward(ctx, grad_vol):
+        B, C, H, W, D, concat = ctx.cfg
+        gv = N.dev_f32(grad_vol, "shift volume backward: grad")
+        gl = torch.empty((B, C, H, W), device=gv.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        gr = torch.empty((B, C, H, W), device=gv.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(gv.device):
+            N.call("stereo_concat_volume_bwd_f32" if concat else "stereo_diff_volume_bwd_f32", N.ptr(gv), N.ptr(gl),
+                   N.ptr(gr), B, C, H, W, D, N.stream_ptr(gv.device))
+        return gl, gr, None, None
+
+
 def _gwc_forward(L, R, maxdisp, num_groups):
     B, C, H, W = L.shape
     vol = torch.empty((B, num_groups, maxdisp, H, W), device=L.device, dtype=torch.float32)
@@ -138,6 +164,11 @@ class CostVolume(nn.Module):
             with torch.no_grad():
                 _pair(left_feature, right_feature, "CostVolume")  # validation only
             return _GwcVolumeFn.apply(left_feature.contiguous(), right_feature.contiguous(), int(self.max_disp), 1, True)
+        if _wants_grad(left_feature, right_feature):   # 'difference' / 'concat' under grad
+            with torch.no_grad():
+                _pair(left_feature, right_feature, "CostVolume")  # validation only
+            return _ShiftVolumeFn.apply(left_feature.contiguous(), right_feature.contiguous(), int(self.max_disp),
+                                        self.feature_similarity == "concat")
         L, R = _pair(left_feature, right_feature, "CostVolume", feat=self.feature_similarity == "correlation")
         b, c, h, w = L.shape
         D = int(self.max_disp)

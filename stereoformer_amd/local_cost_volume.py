@@ -72,6 +72,41 @@ class LocalCostVolume(nn.Module):
         return _local_lookup_fwd(vol, disp, self.radius, self.sample_points, consider_valid)
 
 
+def _variance_lookup_fwd(vol, disp, gamma, sample_points, consider_valid):
+    B, D, H, W = vol.shape
+    out = torch.empty((B, 1, H, W), device=vol.device, dtype=torch.float32)
+    with torch.cuda.device(vol.device):
+        N.call("stereo_variance_lookup_f32", N.ptr(vol), N.ptr(disp), N.ptr(out), B, D, H, W, float(gamma),
+               int(sample_points), 1 if consider_valid else 0, N.stream_ptr(vol.device))
+    return out
+
+
+class _VarianceLookupFn(torch.autograd.Function):
+    """Differentiable variance-based lookup (A6): HIP forward + HIP backward that follows the reference's autograd graph
+    (softmax variance -> bounds -> candidates -> gathered taps -> softmax expectation; ``.long()`` indices carry no
+    gradient, the interpolation rates do)."""
+
+    @staticmethod
+    def forward(ctx, vol, disp, gamma, sample_points, consider_valid):
+        out = _variance_lookup_fwd(vol, disp, gamma, sample_points, consider_valid)
+        ctx.save_for_backward(vol, disp)
+        ctx.cfg = (float(gamma), int(sample_points), bool(consider_valid))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        vol, disp = ctx.saved_tensors
+        gamma, S, cv = ctx.cfg
+        B, D, H, W = vol.shape
+        go = N.dev_f32(grad_out, "Variance_Based_Local_Cost_Volume backward: grad")
+        gvol = torch.zeros_like(vol)      # taps and the variance path are accumulated into it
+        gdisp = torch.empty_like(disp)
+        with torch.cuda.device(vol.device):
+            N.call("stereo_variance_lookup_bwd_f32", N.ptr(vol), N.ptr(disp), N.ptr(go), N.ptr(gvol), N.ptr(gdisp), B, D,
+                   H, W, gamma, S, 1 if cv else 0, N.stream_ptr(vol.device))
+        return gvol, gdisp, None, None, None
+
+
 class Variance_Based_Local_Cost_Volume(nn.Module):
     """``Variance_Based_Local_Cost_Volume(garma=1, sample_points=10)``
     (variance_local_cost_volume.py:28-78)."""
@@ -82,13 +117,13 @@ class Variance_Based_Local_Cost_Volume(nn.Module):
         self.garma = garma
 
     def forward(self, old_cost_volume, cur_disparity, consider_valid=False):
+        if torch.is_grad_enabled() and (old_cost_volume.requires_grad or cur_disparity.requires_grad):
+            with torch.no_grad():
+                _vol_disp(old_cost_volume, cur_disparity, "Variance_Based_Local_Cost_Volume")  # validation only
+            return _VarianceLookupFn.apply(old_cost_volume.contiguous(), cur_disparity.contiguous(), float(self.garma),
+                                           int(self.sample_points), bool(consider_valid))
         vol, disp = _vol_disp(old_cost_volume, cur_disparity, "Variance_Based_Local_Cost_Volume")
-        B, D, H, W = vol.shape
-        out = torch.empty((B, 1, H, W), device=vol.device, dtype=torch.float32)
-        with torch.cuda.device(vol.device):
-            N.call("stereo_variance_lookup_f32", N.ptr(vol), N.ptr(disp), N.ptr(out), B, D, H, W, float(self.garma),
-                   int(self.sample_points), 1 if consider_valid else 0, N.stream_ptr(vol.device))
-        return out
+        return _variance_lookup_fwd(vol, disp, self.garma, self.sample_points, consider_valid)
 
 
 def build_cost_volume_from_volume(old_volume, sampling_candidates):

@@ -590,6 +590,45 @@ def g14_extractor_epilogue():
     save("g14_extractor_epilogue", **out)
 
 
+# ------------------------------------------------------------------ G15
+def g15_backward2():
+    """Gradients from the reference's own autograd for the ops that became differentiable in round 2: A6
+    (Variance_Based_Local_Cost_Volume, both validity modes) and A2 ('difference' / 'concat' volumes)."""
+    from models.utils.build_cost_volume import CostVolume
+    from models.LocalCostVolume.Attempts.variance_local_cost_volume import Variance_Based_Local_Cost_Volume
+
+    out = {}
+    with torch.enable_grad():
+        torch.manual_seed(1501)
+        vol = (2.0 * torch.randn(2, 24, 6, 28)).requires_grad_(True)
+        disp = (torch.rand(2, 1, 6, 28) * 23).requires_grad_(True)
+        with torch.no_grad():
+            disp[0, 0, 0, 0] = 0.5
+            disp[0, 0, 0, 1] = 22.5
+            disp[0, 0, 0, 2] = 7.0
+            vol[0, :, 1, 5] = 0.0
+            vol[0, 9, 1, 5] = 12.0          # a sharply peaked column: small sigma
+            disp[0, 0, 1, 5] = 9.25
+        co = torch.randn(2, 1, 6, 28)
+        out["vl_vol"], out["vl_disp"], out["vl_cot"] = npy(vol), npy(disp), npy(co)
+        for (gm, S) in ((1.0, 10), (2.0, 20), (0.5, 7)):
+            for cv in (False, True):
+                o = Variance_Based_Local_Cost_Volume(gm, S)(vol, disp, cv)
+                gvv, gdd = torch.autograd.grad(o, (vol, disp), co)
+                out[f"vl_out_g{gm}_S{S}_cv{int(cv)}"] = npy(o)
+                out[f"vl_gvol_g{gm}_S{S}_cv{int(cv)}"], out[f"vl_gdisp_g{gm}_S{S}_cv{int(cv)}"] = npy(gvv), npy(gdd)
+        L = torch.randn(2, 3, 4, 20, requires_grad=True)
+        R = torch.randn(2, 3, 4, 20, requires_grad=True)
+        out["sv_L"], out["sv_R"] = npy(L), npy(R)
+        for kind in ("difference", "concat"):
+            for D in (1, 7, 20, 26):          # D == W and D > W included
+                v = CostVolume(D, kind)(L, R)
+                cot = torch.randn_like(v)
+                gl, gr = torch.autograd.grad(v, (L, R), cot)
+                out[f"sv_cot_{kind}_D{D}"], out[f"sv_gl_{kind}_D{D}"], out[f"sv_gr_{kind}_D{D}"] = npy(cot), npy(gl), npy(gr)
+    save("g15_backward2", **out)
+
+
 def check_oracle_cfg1():
     """Not a fixture: proves the C oracle == the reference at BASELINE
     configs[0] (1 pair 384x768 D=64: corr -> soft-argmin -> local lookup)."""
@@ -628,5 +667,6 @@ if __name__ == "__main__":
     g12_raft_backward()
     g13_flow_init_padder()
     g14_extractor_epilogue()
+    g15_backward2()
     if CHECK:
         check_oracle_cfg1()

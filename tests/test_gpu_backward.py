@@ -325,3 +325,94 @@ def test_corr_volume_backward_mfma_vs_valu_vs_torch(S, shape):
     for k in ("1", "0"):
         for a, b in zip(got[k], gref):
             close(a, b.cpu().numpy(), rtol=1e-4, atol=5e-5)
+
+
+# ------------------------------------------------------------------ round 2: A6, A2, A7
+def test_variance_lookup_backward_g15(S, golden):
+    """A6 (Variance_Based_Local_Cost_Volume) gradients w.r.t. the volume and the disparity against the reference's own
+    autograd (golden G15): three (gamma, S) settings x both validity modes, incl. edge pixels and a sharply peaked column."""
+    g = golden("g15_backward2")
+    for (gm, Sp) in ((1.0, 10), (2.0, 20), (0.5, 7)):
+        for cv in (False, True):
+            vol = dev(g["vl_vol"]).requires_grad_(True)
+            disp = dev(g["vl_disp"]).requires_grad_(True)
+            out = S.Variance_Based_Local_Cost_Volume(gm, Sp)(vol, disp, cv)
+            close(out, g[f"vl_out_g{gm}_S{Sp}_cv{int(cv)}"], rtol=1e-4, atol=2e-4)
+            gv, gd = torch.autograd.grad(out, (vol, disp), dev(g["vl_cot"]))
+            close(gv, g[f"vl_gvol_g{gm}_S{Sp}_cv{int(cv)}"], rtol=2e-3, atol=2e-4)
+            close(gd, g[f"vl_gdisp_g{gm}_S{Sp}_cv{int(cv)}"], rtol=2e-3, atol=5e-4)
+
+
+def test_shift_volume_backward_g15(S, golden):
+    """A2 'difference' / 'concat' volume gradients against the reference's autograd (G15), D in {1, 7, W, > W}; exact sums of
+    the same terms in another order."""
+    g = golden("g15_backward2")
+    for kind in ("difference", "concat"):
+        for D in (1, 7, 20, 26):
+            L = dev(g["sv_L"]).requires_grad_(True)
+            R = dev(g["sv_R"]).requires_grad_(True)
+            v = S.CostVolume(D, kind)(L, R)
+            gl, gr = torch.autograd.grad(v, (L, R), dev(g[f"sv_cot_{kind}_D{D}"]))
+            close(gl, g[f"sv_gl_{kind}_D{D}"], rtol=1e-5, atol=1e-5)
+            close(gr, g[f"sv_gr_{kind}_D{D}"], rtol=1e-5, atol=1e-5)
+    L = dev(g["sv_L"]).requires_grad_(True)       # one-sided: only the left features need a gradient
+    v = S.build_concat_volume(L, dev(g["sv_R"]), 7)
+    (gl,) = torch.autograd.grad(v, (L,), dev(g["sv_cot_concat_D7"]))
+    close(gl, g["sv_gl_concat_D7"], rtol=1e-5, atol=1e-5)
+
+
+def _attention_reference(L, R, V, D, mask, scale):
+    """Plain-torch fp64 statement of the build-defined cross-attention (A7 has no reference body: identity-pinned)."""
+    B, C, H, W = L.shape
+    sc = 1.0 / C if scale == "mean" else 1.0 / C ** 0.5
+    logits, vals = [], []
+    for d in range(D):
+        Rs = torch.zeros_like(R)
+        Vs = torch.zeros_like(V)
+        if d < W:
+            Rs[..., d:] = R[..., :W - d]
+            Vs[..., d:] = V[..., :W - d]
+        lg = (L * Rs).sum(1) * sc
+        if mask == "neginf":
+            w = torch.arange(W, device=L.device).view(1, 1, W)
+            lg = lg.masked_fill(w < d, float("-inf"))
+        logits.append(lg)
+        vals.append(Vs)
+    P = torch.softmax(torch.stack(logits, 1), 1)                  # [B,D,H,W]
+    disp = (P * torch.arange(D, device=L.device, dtype=L.dtype).view(1, D, 1, 1)).sum(1)
+    out = sum(P[:, d:d + 1] * vals[d] for d in range(D))
+    return out, disp
+
+
+@pytest.mark.parametrize("cfg", [(2, 8, 3, 40, 12, 8), (1, 32, 2, 64, 20, 5), (1, 48, 2, 36, 9, 48)])
+@pytest.mark.parametrize("mask", ["zero", "neginf"])
+@pytest.mark.parametrize("scale", ["sqrt_c", "mean"])
+def test_cross_attention_backward(S, cfg, mask, scale):
+    """A7 under grad: the differentiable composition (A1 forward / backward kernels for Q K^T and P V) reproduces the fused
+    inference kernel's outputs and the gradients of a plain fp64 torch statement of the same function w.r.t. left, right
+    and value features."""
+    B, C, H, W, D, Cv = cfg
+    torch.manual_seed(33)
+    L0, R0 = torch.randn(B, C, H, W, device="cuda"), torch.randn(B, C, H, W, device="cuda")
+    V0 = torch.randn(B, Cv, H, W, device="cuda")
+    att = S.CrossAttentionCostVolume(D, mask, scale)
+    with torch.no_grad():
+        o_inf, d_inf = att(L0, R0, V0)
+    L, R, V = (t.clone().requires_grad_(True) for t in (L0, R0, V0))
+    o, d = att(L, R, V)
+    assert (o - o_inf).abs().max().item() < 5e-5 and (d - d_inf).abs().max().item() < 1e-3
+    co, cd = torch.randn_like(o), torch.randn_like(d)
+    gl, gr, gv = torch.autograd.grad((o * co).sum() + (d * cd).sum(), (L, R, V))
+    Lr, Rr, Vr = (t.double().clone().requires_grad_(True) for t in (L0, R0, V0))
+    orf, drf = _attention_reference(Lr, Rr, Vr, D, mask, scale)
+    rl, rr, rv = torch.autograd.grad((orf * co.double()).sum() + (drf * cd.double()).sum(), (Lr, Rr, Vr))
+    for a, b in ((gl, rl), (gr, rr), (gv, rv)):
+        close(a, b.float().cpu().numpy(), rtol=2e-3, atol=3e-4)
+    # value defaults to the right features: its gradient is the sum of both roles
+    R2 = R0.clone().requires_grad_(True)
+    o2, d2 = att(L0, R2)
+    (g2,) = torch.autograd.grad(o2.sum() + (d2 * cd).sum(), (R2,))
+    Rr2 = R0.double().clone().requires_grad_(True)
+    or2, dr2 = _attention_reference(L0.double(), Rr2, Rr2, D, mask, scale)
+    (r2,) = torch.autograd.grad(or2.sum() + (dr2 * cd.double()).sum(), (Rr2,))
+    close(g2, r2.float().cpu().numpy(), rtol=2e-3, atol=3e-4)
