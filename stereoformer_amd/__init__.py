@@ -17,6 +17,8 @@ from .local_cost_volume import (LocalCostVolume, Variance_Based_Local_Cost_Volum
 from .corr import (AlternateCorrBlock, CorrBlock1D, InputPadder, PytorchAlternateCorrBlock1D, bilinear_sampler,
                    coords_grid)
 from .cross_attention import CrossAttentionCostVolume
+from . import data
+from .data import StereoDataset
 from .disparity_warper import disp_warp
 from .extractor_epilogue import InstanceNormReLU, instance_norm_relu
 from .metrics import D1_metric, EPE_Loss, P1_metric, scale_disp, sequence_loss, thres_metric
@@ -29,7 +31,7 @@ from .upsample import (ConvAffinityUpsample, interp, resize_bilinear, upflow8, u
                        upsample_flow, upsample_simple8)
 
 __all__ = [
-    "InstanceNormReLU", "instance_norm_relu",
+    "InstanceNormReLU", "instance_norm_relu", "StereoDataset", "data",
     "D1_metric", "EPE_Loss", "P1_metric", "scale_disp", "sequence_loss", "thres_metric", "read_disp", "read_pfm",
     "write_pfm",
     "LowCNNGRULoop", "RAFTStereoLoop",

@@ -157,12 +157,29 @@ class PytorchAlternateCorrBlock1D:
         self.num_levels = num_levels
         self.radius = radius
         self.corr_pyramid = []
+        self._grad_block = None
+        if torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad):
+            # Training: sampling pooled fmap2 and then contracting the channels equals contracting first and sampling the
+            # pooled volume (both are linear; SURVEY 8(c) identity I7, 3.7e-5), and that order has HIP backward kernels
+            # (A8 + A9).  The memory saving of the alternate block is an inference property.
+            if fmap1.shape != fmap2.shape:
+                raise ValueError("PytorchAlternateCorrBlock1D: fmap shapes differ")
+            self._grad_block = CorrBlock1D(fmap1, fmap2, num_levels=num_levels, radius=radius)
+            self.fmap1, self.fmap2 = fmap1, fmap2
+            return
         self.fmap1 = N.dev_f32(fmap1, "PytorchAlternateCorrBlock1D: fmap1")
         self.fmap2 = N.dev_f32(fmap2, "PytorchAlternateCorrBlock1D: fmap2")
         if self.fmap1.shape != self.fmap2.shape:
             raise ValueError("PytorchAlternateCorrBlock1D: fmap shapes differ")
 
     def __call__(self, coords):
+        if self._grad_block is not None:
+            B, C, H, W = self.fmap1.shape
+            rows = torch.arange(H, device=coords.device, dtype=coords.dtype).view(1, H, 1)
+            if tuple(coords.shape) != (B, 2, H, W) or not torch.equal(coords[:, 1].detach(), rows.expand(B, H, W)):
+                raise RuntimeError("PytorchAlternateCorrBlock1D under grad: coords[:, 1] must be the pixel's own row (what the "
+                                   "RAFT loop feeds: delta_flow[:, 1] = 0, raft_stereo.py:180)")
+            return self._grad_block(coords)
         coords = N.dev_f32(coords, "PytorchAlternateCorrBlock1D: coords")
         B, C, H, W = self.fmap1.shape
         if tuple(coords.shape) != (B, 2, H, W):

@@ -629,6 +629,56 @@ def g15_backward2():
     save("g15_backward2", **out)
 
 
+# ------------------------------------------------------------------ G16
+def g16_dataset():
+    """StereoDataset + the geometric transforms (dataloader/SceneflowLoader.py, dataloader/transforms.py, utils/file_io.py) on a
+    tiny synthetic tree written to a temp dir: two SceneFlow-style samples (PNG + PFM) in 'train' mode through
+    Compose([RandomCrop(validate=True), ToTensor(), Normalize(...)]), and a KITTI-style 16-bit PNG disparity.  scikit-image and torchvision are absent here: they are only imported (never executed) by the
+    code paths used, so import-only stand-ins are installed first (SURVEY 9.3 recipe).  The fixture keeps the source arrays,
+    so the test can re-create the files."""
+    import tempfile
+    import types
+    from PIL import Image
+    sk = types.ModuleType("skimage"); sk.io = types.ModuleType("skimage.io"); sk.transform = types.ModuleType("skimage.transform")
+    sys.modules.update({"skimage": sk, "skimage.io": sk.io, "skimage.transform": sk.transform})
+    tv = types.ModuleType("torchvision"); tvt = types.ModuleType("torchvision.transforms")
+    tvf = types.ModuleType("torchvision.transforms.functional"); tv.transforms = tvt; tvt.functional = tvf
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt, "torchvision.transforms.functional": tvf})
+    from dataloader.SceneflowLoader import StereoDataset
+    from dataloader import transforms as T
+    from utils.file_io import write_pfm, read_disp
+
+    rng = np.random.default_rng(1601)
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        lines = []
+        for i in range(2):
+            os.makedirs(os.path.join(td, "frames", f"{i}"), exist_ok=True)
+            l = rng.integers(0, 256, (20, 36, 3), dtype=np.uint8)
+            r = rng.integers(0, 256, (20, 36, 3), dtype=np.uint8)
+            d = (rng.random((20, 36)) * 30).astype(np.float32)
+            Image.fromarray(l).save(os.path.join(td, "frames", f"{i}", "left.png"))
+            Image.fromarray(r).save(os.path.join(td, "frames", f"{i}", "right.png"))
+            write_pfm(os.path.join(td, "frames", f"{i}", "disp.pfm"), d)
+            lines.append(f"frames/{i}/left.png frames/{i}/right.png frames/{i}/disp.pfm")
+            out[f"src_left{i}"], out[f"src_right{i}"], out[f"src_disp{i}"] = l, r, d
+        lst = os.path.join(td, "train.list")
+        open(lst, "w").write("\n".join(lines) + "\n")
+        mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+        ds = StereoDataset(td, lst, lst, mode="train", save_filename=True,
+                           transform=T.Compose([T.RandomCrop(16, 32, validate=True), T.ToTensor(), T.Normalize(mean, std)]))
+        for i in range(2):
+            smp = ds[i]
+            out[f"crop_left{i}"], out[f"crop_right{i}"], out[f"crop_disp{i}"] = npy(smp["img_left"]), npy(smp["img_right"]), npy(smp["gt_disp"])
+            out[f"name{i}"] = np.array([smp["left_name"]])
+        # (RandomCrop's zero-padding branch calls np.lib.pad, which numpy 2 removed: the reference raises there on this
+        # interpreter, so that branch is restated from the source text and checked against np.pad in the test, unpinned.)
+        k = (rng.random((6, 9)) * 200 * 256).astype(np.uint16)
+        Image.fromarray(k).save(os.path.join(td, "kitti_disp.png"))
+        out["kitti_png"], out["kitti_disp"] = k, read_disp(os.path.join(td, "kitti_disp.png")).astype(np.float32)
+    save("g16_dataset", **out)
+
+
 def check_oracle_cfg1():
     """Not a fixture: proves the C oracle == the reference at BASELINE
     configs[0] (1 pair 384x768 D=64: corr -> soft-argmin -> local lookup)."""
@@ -668,5 +718,6 @@ if __name__ == "__main__":
     g13_flow_init_padder()
     g14_extractor_epilogue()
     g15_backward2()
+    g16_dataset()
     if CHECK:
         check_oracle_cfg1()

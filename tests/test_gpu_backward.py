@@ -416,3 +416,28 @@ def test_cross_attention_backward(S, cfg, mask, scale):
     or2, dr2 = _attention_reference(L0.double(), Rr2, Rr2, D, mask, scale)
     (r2,) = torch.autograd.grad(or2.sum() + (dr2 * cd.double()).sum(), (Rr2,))
     close(g2, r2.float().cpu().numpy(), rtol=2e-3, atol=3e-4)
+
+
+def test_alternate_corr_block_under_grad(S):
+    """A10 under grad computes through the all-pairs pyramid (identity I7): same gradients as CorrBlock1D, forward within
+    1e-4 of the on-the-fly kernel; a y coordinate off the pixel's own row is refused."""
+    torch.manual_seed(9)
+    B, C, H, W = 1, 16, 3, 40
+    f1, f2 = torch.randn(B, C, H, W, device="cuda"), torch.randn(B, C, H, W, device="cuda")
+    coords = S.coords_grid(B, H, W, device="cuda")
+    coords[:, 0] -= torch.rand(B, H, W, device="cuda") * 6
+    with torch.no_grad():
+        ref = S.PytorchAlternateCorrBlock1D(f1, f2, 4, 4)(coords)
+    a1, a2 = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+    out = S.PytorchAlternateCorrBlock1D(a1, a2, 4, 4)(coords)
+    assert (out - ref).abs().max().item() < 1e-4
+    cot = torch.randn_like(out)
+    ga = torch.autograd.grad(out, (a1, a2), cot)
+    b1, b2 = f1.clone().requires_grad_(True), f2.clone().requires_grad_(True)
+    gb = torch.autograd.grad(S.CorrBlock1D(b1, b2, 4, 4)(coords), (b1, b2), cot)
+    for x, y in zip(ga, gb):
+        assert torch.equal(x, y)
+    bad = coords.clone()
+    bad[:, 1] += 0.25
+    with pytest.raises(RuntimeError, match="own row"):
+        S.PytorchAlternateCorrBlock1D(a1, a2, 4, 4)(bad)
