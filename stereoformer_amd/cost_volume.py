@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import _native as N
+from . import ops
 
 
 class _GwcVolumeFn(torch.autograd.Function):
@@ -160,6 +161,8 @@ class CostVolume(nn.Module):
     def forward(self, left_feature, right_feature):
         if self.feature_similarity not in ("difference", "concat", "correlation"):
             raise NotImplementedError
+        if self.feature_similarity == "correlation" and ops.tracing():   # torch.compile / export: the registered op
+            return torch.ops.stereo_hip.gwc_volume(left_feature, right_feature, int(self.max_disp), 1)[:, 0]
         if self.feature_similarity == "correlation" and _wants_grad(left_feature, right_feature):
             with torch.no_grad():
                 _pair(left_feature, right_feature, "CostVolume")  # validation only
@@ -204,6 +207,8 @@ class CostVolumePyramid(nn.Module):
 
 def build_gwc_volume(refimg_fea, targetimg_fea, maxdisp, num_groups):
     """``build_gwc_volume`` (GWC_Cost_Volume.py:14-24) -> [B,G,D,H,W]."""
+    if ops.tracing():
+        return torch.ops.stereo_hip.gwc_volume(refimg_fea, targetimg_fea, int(maxdisp), int(num_groups))
     if _wants_grad(refimg_fea, targetimg_fea):
         with torch.no_grad():
             L, R = _pair(refimg_fea, targetimg_fea, "build_gwc_volume")
@@ -243,6 +248,10 @@ def build_gwc_volume_with_disparity(refimg_fea, targetimg_fea, maxdisp, num_grou
     the disparity and the mean come from the LDS-staged feature tiles while the group-wise volume is being
     produced: the [B,G,D,H,W] volume is written once and never read back (cfg-2: 25.5 GB of reads saved).
     Differentiable: the backward follows the fused forward (see ``_GwcWithDisparityFn``)."""
+    if ops.tracing():
+        vol, disp, mean = torch.ops.stereo_hip.gwc_volume_soft_argmin(refimg_fea, targetimg_fea, int(maxdisp), int(num_groups),
+                                                                      bool(match_similarity))
+        return (vol, disp, mean) if return_mean else (vol, disp)
     if _wants_grad(refimg_fea, targetimg_fea):
         with torch.no_grad():
             L, R = _pair(refimg_fea, targetimg_fea, "build_gwc_volume_with_disparity")

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import _native as N
+from . import ops
 
 class _BandApplyFn(torch.autograd.Function):
     """``out[b,c,h,w] = sum_{d <= w} P[b,d,h,w] * V[b,c,h,w-d]`` -- the P V half of the attention as the transpose of the
@@ -86,6 +87,11 @@ class CrossAttentionCostVolume(nn.Module):
         return out, disp
 
     def forward(self, left_feature, right_feature, value=None, need_out=True):
+        if ops.tracing():   # torch.compile / export: the registered (inference) op
+            out, disp = torch.ops.stereo_hip.cross_attention(left_feature, right_feature,
+                                                             right_feature if value is None else value, int(self.max_disp),
+                                                             _MASK[self.mask], _SCALE[self.scale])
+            return (out if need_out else None), disp
         if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad
                                            for t in (left_feature, right_feature, value)):
             if left_feature.dim() != 4 or left_feature.shape != right_feature.shape:

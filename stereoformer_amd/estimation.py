@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 
 from . import _native as N
+from . import ops
 
 
 class _SoftArgminFn(torch.autograd.Function):
@@ -37,6 +38,8 @@ class _SoftArgminFn(torch.autograd.Function):
 
 def _soft_argmin(cost_volume, match_similarity, with_prob, who):
     assert cost_volume.dim() == 4  # estimation.py:15
+    if ops.tracing() and not with_prob:   # torch.compile / export: the registered op
+        return torch.ops.stereo_hip.soft_argmin(cost_volume, bool(match_similarity)), None
     if torch.is_grad_enabled() and cost_volume.requires_grad:
         with torch.no_grad():
             N.dev_f32(cost_volume, f"{who}: cost_volume")  # validation only

@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from . import _native as N
+from . import ops
 
 
 def _vol_disp(old_cost_volume, cur_disparity, who):
@@ -63,6 +64,9 @@ class LocalCostVolume(nn.Module):
         self.sample_points = sample_points
 
     def forward(self, old_cost_volume, cur_disparity, consider_valid=False):
+        if ops.tracing():   # torch.compile / export: the registered op
+            return torch.ops.stereo_hip.local_lookup(old_cost_volume, cur_disparity, float(self.radius),
+                                                     int(self.sample_points), bool(consider_valid))
         if torch.is_grad_enabled() and (old_cost_volume.requires_grad or cur_disparity.requires_grad):
             with torch.no_grad():
                 _vol_disp(old_cost_volume, cur_disparity, "LocalCostVolume")  # validation only

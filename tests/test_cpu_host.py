@@ -184,3 +184,26 @@ def test_library_reads_no_environment_and_keeps_no_mutable_globals():
     lib = _native.load()
     assert lib.stereo_test_option(b"corr_mfma", 0) == 0 and lib.stereo_test_option(b"corr_mfma", -1) == 0
     assert lib.stereo_test_option(b"no_such_option", 1) == -2
+
+
+def test_registered_ops_trace_with_fake_tensors():
+    """`torch.ops.stereo_hip.*`: the schemas exist and the FakeTensor (meta) shape functions propagate through the cfg-2 chain
+    without a GPU -- what torch.compile / torch.export need to trace the module surfaces without a graph break."""
+    import stereoformer_amd as S  # noqa: F401  (registers the ops)
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    for name in ("gwc_volume", "gwc_volume_bwd", "soft_argmin", "soft_argmin_bwd", "gwc_volume_soft_argmin", "local_lookup",
+                 "local_lookup_bwd", "cross_attention", "upsample_convex"):
+        assert hasattr(torch.ops.stereo_hip, name), name
+    with FakeTensorMode():
+        L = torch.empty(2, 32, 16, 64, device="cuda")
+        R = torch.empty(2, 32, 16, 64, device="cuda", dtype=torch.float16)
+        vol, disp, mean = torch.ops.stereo_hip.gwc_volume_soft_argmin(L, R, 24, 8, True)
+        assert vol.shape == (2, 8, 24, 16, 64) and disp.shape == (2, 16, 64) and mean.shape == (2, 24, 16, 64)
+        assert vol.dtype == torch.float32 and vol.device.type == "cuda"
+        out = torch.ops.stereo_hip.local_lookup(mean, disp.unsqueeze(1), 2.0, 20, True)
+        assert out.shape == (2, 1, 16, 64)
+        o, d = torch.ops.stereo_hip.cross_attention(L, L, torch.empty(2, 5, 16, 64, device="cuda"), 24, 0, 0)
+        assert o.shape == (2, 5, 16, 64) and d.shape == (2, 16, 64)
+        up = torch.ops.stereo_hip.upsample_convex(disp.unsqueeze(1), torch.empty(2, 576, 16, 64, device="cuda"), 8)
+        assert up.shape == (2, 1, 128, 512)
+    assert "Tensor left, Tensor right, SymInt max_disp, SymInt num_groups" in str(torch.ops.stereo_hip.gwc_volume.default._schema)
