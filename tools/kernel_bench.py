@@ -175,6 +175,11 @@ def main():
             pyr_bytes = Br * Hr * Wr * (Wr + Wr // 2 + Wr // 4 + Wr // 8 + Wr // 16) * 4
             add("A8_allpairs+pyramid cfg-4 [8,256,136,240]", timeit(lambda: S.CorrBlock1D(f1, f2, 4, 4), args.reps),
                 (2 * Br * Cr * Hr * Wr * 4 + pyr_bytes) / 1e9, 2 * Br * Hr * Wr * Wr * Cr / 1e9, bound="mfma")
+        if want("A8_allpairs"):
+            lv0 = torch.empty(Br * Hr * Wr, 1, 1, Wr, device=dev)
+            add("A8_allpairs level 0 only cfg-4", timeit(lambda: S.CorrBlock1D.corr(f1, f2), args.reps),
+                (2 * Br * Cr * Hr * Wr * 4 + Br * Hr * Wr * Wr * 4) / 1e9, 2 * Br * Hr * Wr * Wr * Cr / 1e9, bound="mfma")
+            del lv0
         blk = S.CorrBlock1D(f1, f2, 4, 4)
         coords = S.coords_grid(Br, Hr, Wr, device=dev) - torch.rand(Br, 2, Hr, Wr, device=dev) * 30
         coords = coords.contiguous()
