@@ -7,6 +7,7 @@ arguments and output layouts; the bodies are hand-written HIP kernels reached th
 the C ABI in ``include/stereo_hip.h`` (``libstereo_hip.so``).  No CPU fallback.
 """
 from . import _native
+from . import hbm
 from . import ops
 from .cost_volume import (CostVolume, CostVolumePyramid, build_concat_volume, build_gwc_volume,
                           build_gwc_volume_with_disparity, corr_volume_with_disparity,

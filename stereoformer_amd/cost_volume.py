@@ -239,20 +239,33 @@ def corr_volume_with_disparity(left_feature, right_feature, max_disp, match_simi
     return vol, disp
 
 
+def _check_out(t, shape, dev, what):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.device == dev and t.dtype == torch.float32
+            and tuple(t.shape) == tuple(shape) and t.is_contiguous()):
+        raise ValueError(f"build_gwc_volume_with_disparity: out {what} must be a contiguous float32 tensor of shape "
+                         f"{tuple(shape)} on {dev}")
+    return t
+
+
 def build_gwc_volume_with_disparity(refimg_fea, targetimg_fea, maxdisp, num_groups, return_mean=False,
-                                    match_similarity=True):
+                                    match_similarity=True, out=None):
     """``vol = build_gwc_volume(L, R, D, G)`` together with ``DisparityEstimation(D)(vol.mean(1))`` (and the mean
     volume itself when ``return_mean``) in one call -> ``(vol, disp[, mean])``.
 
     ``vol.mean(1)`` over equally sized groups is the all-channel correlation volume (SURVEY 8(c) identity I1), so
     the disparity and the mean come from the LDS-staged feature tiles while the group-wise volume is being
     produced: the [B,G,D,H,W] volume is written once and never read back (cfg-2: 25.5 GB of reads saved).
-    Differentiable: the backward follows the fused forward (see ``_GwcWithDisparityFn``)."""
+    Differentiable: the backward follows the fused forward (see ``_GwcWithDisparityFn``).
+
+    ``out=(vol, disp, mean)`` (inference only, like torch's ``out=``): caller-owned output tensors that this call overwrites
+    completely -- for buffers that live across many steps and were placed with ``stereoformer_amd.hbm.place_volume_stage_outputs``."""
     if ops.tracing():
         vol, disp, mean = torch.ops.stereo_hip.gwc_volume_soft_argmin(refimg_fea, targetimg_fea, int(maxdisp), int(num_groups),
                                                                       bool(match_similarity))
         return (vol, disp, mean) if return_mean else (vol, disp)
     if _wants_grad(refimg_fea, targetimg_fea):
+        if out is not None:
+            raise RuntimeError("build_gwc_volume_with_disparity: out= is an inference option (call under torch.no_grad())")
         with torch.no_grad():
             L, R = _pair(refimg_fea, targetimg_fea, "build_gwc_volume_with_disparity")
         assert L.shape[1] % num_groups == 0  # GWC_Cost_Volume.py:7
@@ -263,10 +276,15 @@ def build_gwc_volume_with_disparity(refimg_fea, targetimg_fea, maxdisp, num_grou
     assert L.shape[1] % num_groups == 0  # GWC_Cost_Volume.py:7
     B, C, H, W = L.shape
     D, G = int(maxdisp), int(num_groups)
-    vol = torch.empty((B, G, D, H, W), device=L.device, dtype=torch.float32)
-    disp = torch.empty((B, H, W), device=L.device, dtype=torch.float32)
-    # the fp16 form always produces the mean volume (the fused kernel's only shape); fp32 keeps it optional
-    mean = torch.empty((B, D, H, W), device=L.device, dtype=torch.float32) if (return_mean or L.dtype == torch.float16) else None
+    if out is not None:
+        vol = _check_out(out[0], (B, G, D, H, W), L.device, "[0] (volume)")
+        disp = _check_out(out[1], (B, H, W), L.device, "[1] (disparity)")
+        mean = _check_out(out[2], (B, D, H, W), L.device, "[2] (mean volume)")
+    else:
+        vol = torch.empty((B, G, D, H, W), device=L.device, dtype=torch.float32)
+        disp = torch.empty((B, H, W), device=L.device, dtype=torch.float32)
+        # the fp16 form always produces the mean volume (the fused kernel's only shape); fp32 keeps it optional
+        mean = torch.empty((B, D, H, W), device=L.device, dtype=torch.float32) if (return_mean or L.dtype == torch.float16) else None
     with torch.cuda.device(L.device):
         N.feat_call("stereo_gwc_volume_soft_argmin", [L, R],
                     lambda f: (N.ptr(f[0]), N.ptr(f[1]), N.ptr(vol), N.ptr(mean), N.ptr(disp), B, C, H, W, D, G,

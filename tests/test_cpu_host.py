@@ -207,3 +207,34 @@ def test_registered_ops_trace_with_fake_tensors():
         up = torch.ops.stereo_hip.upsample_convex(disp.unsqueeze(1), torch.empty(2, 576, 16, 64, device="cuda"), 8)
         assert up.shape == (2, 1, 128, 512)
     assert "Tensor left, Tensor right, SymInt max_disp, SymInt num_groups" in str(torch.ops.stereo_hip.gwc_volume.default._schema)
+
+
+def test_hbm_place_keeps_the_fastest_candidate_and_frees_the_rest():
+    """hbm.place: candidates are held while probing (a freed block would come straight back), the fastest wins, early exit at
+    good_enough_ms, and the report shows every probe incl. the first (= what the default allocation would have got)."""
+    from stereoformer_amd import hbm
+    made, alive = [], set()
+
+    class Buf:
+        def __init__(self, i):
+            self.i = i
+            alive.add(i)
+
+        def __del__(self):
+            alive.discard(self.i)
+
+    times = [5.7, 5.4, 4.7, 5.8, 4.6]
+
+    def alloc():
+        assert len(alive) == len(made), "rejected candidates must stay alive while probing"
+        made.append(len(made))
+        return Buf(made[-1])
+
+    best, rep = hbm.place(alloc, lambda b: times[b.i], max_tries=5)
+    assert best.i == 4 and rep["probe_ms"] == times and rep["chosen"] == 4 and rep["first_allocation_ms"] == 5.7
+    import gc
+    gc.collect()
+    assert alive == {4}
+    made.clear(), alive.clear()
+    best, rep = hbm.place(alloc, lambda b: times[b.i], max_tries=5, good_enough_ms=4.8)
+    assert best.i == 2 and len(rep["probe_ms"]) == 3          # stopped at the first good-enough candidate

@@ -703,3 +703,23 @@ def test_module_surfaces_compile_without_graph_breaks(S, oracle):
     torch.autograd.backward(train_chain(lb, rb))
     close(la.grad, host(lb.grad), rtol=1e-5, atol=1e-5)
     close(ra.grad, host(rb.grad), rtol=1e-5, atol=1e-5)
+
+
+def test_out_buffers_and_placement(S, oracle):
+    """`out=` of the fused volume stage: caller-owned buffers are overwritten completely and returned; placed buffers
+    (hbm.place_volume_stage_outputs) give the same numbers as fresh allocations; wrong buffers are refused on the host."""
+    rng = np.random.default_rng(97)
+    B, C, H, W, D, G = 1, 16, 3, 64, 20, 4
+    L, R = dev(rng.standard_normal((B, C, H, W), dtype=np.float32)), dev(rng.standard_normal((B, C, H, W), dtype=np.float32))
+    want = S.build_gwc_volume_with_disparity(L, R, D, G, return_mean=True)
+    bufs, rep = S.hbm.place_volume_stage_outputs(L, R, D, G, max_tries=3, good_enough_tbs=1e9)
+    assert len(rep["probe_ms"]) == 3 and rep["chosen_ms"] == min(rep["probe_ms"])
+    for b_ in bufs:
+        b_.fill_(float("nan"))
+    got = S.build_gwc_volume_with_disparity(L, R, D, G, return_mean=True, out=bufs)
+    for a, b_, w in zip(got, bufs, want):
+        assert a.data_ptr() == b_.data_ptr() and torch.equal(a, w)
+    with pytest.raises(ValueError, match="out"):
+        S.build_gwc_volume_with_disparity(L, R, D, G, out=(bufs[0], bufs[1], bufs[2][:, :-1]))
+    with pytest.raises(RuntimeError, match="inference option"):
+        S.build_gwc_volume_with_disparity(L.clone().requires_grad_(True), R, D, G, out=bufs)
