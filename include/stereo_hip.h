@@ -44,7 +44,7 @@ int stereo_abi_version(void);
 const char *stereo_strerror(int code);
 
 /* TEST HOOK, not part of the product contract: steers which kernel serves the following calls so that the test-suite
- * can run a fallback kernel on a shape the fast path would take ("corr_mfma" 0/1, "gwc_fused" 0/1, "att_kernel" 0/2/4/6,
+ * can run a fallback kernel on a shape the fast path would take ("corr_mfma" 0/1, "gwc_fused" 0/1, "att_kernel" 0/2/4/5/6/7,
  * "att_waves" 0/4/5/8, "prob_single_pass" 0/1) or make small inputs walk the persistent multi-tile loops
  * ("tiles_per_wg" n).  Process-wide atomics; value < 0 restores the default.  The library reads no environment
  * variable.  Returns STEREO_ERR_BAD_SHAPE for an unknown name. */

@@ -11,6 +11,8 @@
 //   v4  scores stay in the MFMA accumulators, two-pass softmax (any C / Cv / value tensor).
 //   v5  v4 + online softmax + persistent prefetching workgroups (C <= 32, value = right features).
 //   v6  (attention_chunked.hip) v4's arithmetic as a persistent item pipeline over channel chunks (any C / Cv / value).
+//   v7  (attention_bf16.hip) v5 on the bf16 matrix cores with split operands (C <= 32, value = right features, D <= 192):
+//       the default where it applies -- 1.0 vs 1.4 ms at cfg-3 at the same parity tolerances.
 // The [B,H,W,D] score tensor is never materialised in HBM by any of them.
 #include "common.h"
 
@@ -704,7 +706,12 @@ extern "C" int stereo_cross_attention_f32(const float *left, const float *right,
             const float sc = scale_mode == STEREO_SCALE_MEAN ? 1.0f / (float)C : 1.0f / sqrtf((float)C);
             const int same_kv = (out != nullptr && value == right && Cv == C) ? 1 : 0;
             dim3 grid4((W + A4_TQ - 1) / A4_TQ, H, B);
-            if (C <= 32 && (out == nullptr || same_kv) && forced != 4) {  // v5: online softmax
+            if (C <= 32 && (out == nullptr || same_kv) && (forced == 7 || forced == 0)) {  // v7: split-bf16 matrix cores (default)
+                const int rc7 = stereo_cross_attention_split<float>(left, right, out, disp, B, C, H, W, D, mask_mode, sc,
+                                                                    as_stream(stream));
+                if (rc7 != STEREO_ERR_UNSUPPORTED) return rc7;
+            }
+            if (C <= 32 && (out == nullptr || same_kv) && forced != 4) {  // v5: fp32 online softmax (192 < D <= 256; test hook 5)
                 const int rc5 = launch_online<float>(left, right, out, disp, B, C, H, W, D, mask_mode, sc, as_stream(stream));
                 if (rc5 != STEREO_ERR_UNSUPPORTED) return rc5;
             }
@@ -759,6 +766,10 @@ template <typename TIN>
 int stereo_corr_soft_argmin_mfma(const TIN *L, const TIN *R, float *disp, int B, int C, int H, int W, int D, float sgn,
                                  hipStream_t st)
 {
+    if (stereo_opt(OPT_ATT_KERNEL) == 0 || stereo_opt(OPT_ATT_KERNEL) == 7) {  // split-bf16 matrix cores where they apply
+        const int rc = stereo_cross_attention_split<TIN>(L, R, nullptr, disp, B, C, H, W, D, STEREO_MASK_ZERO, sgn / (float)C, st);
+        if (rc != STEREO_ERR_UNSUPPORTED) return rc;
+    }
     return launch_online<TIN>(L, R, nullptr, disp, B, C, H, W, D, STEREO_MASK_ZERO, sgn / (float)C, st);
 }
 template int stereo_corr_soft_argmin_mfma<float>(const float *, const float *, float *, int, int, int, int, int, float,
@@ -783,6 +794,10 @@ extern "C" int stereo_cross_attention_f16(const void *left, const void *right, c
     const f16 *L = static_cast<const f16 *>(left), *R = static_cast<const f16 *>(right), *V = static_cast<const f16 *>(value);
     const float sc = scale_mode == STEREO_SCALE_MEAN ? 1.0f / (float)C : 1.0f / sqrtf((float)C);
     const bool same_kv = out != nullptr && value == right && Cv == C;
+    if (C <= 32 && (out == nullptr || same_kv) && (stereo_opt(OPT_ATT_KERNEL) == 7 || stereo_opt(OPT_ATT_KERNEL) == 0)) {
+        const int rc = stereo_cross_attention_split<f16>(L, R, out, disp, B, C, H, W, D, mask_mode, sc, as_stream(stream));
+        if (rc != STEREO_ERR_UNSUPPORTED) return rc;
+    }
     if (C <= 32 && (out == nullptr || same_kv) && stereo_opt(OPT_ATT_KERNEL) != 6) {
         const int rc = launch_online<f16>(L, R, out, disp, B, C, H, W, D, mask_mode, sc, as_stream(stream));
         if (rc != STEREO_ERR_UNSUPPORTED) return rc;

@@ -1,0 +1,331 @@
+// Epipolar cross-attention (A7), C <= 32, value = right features, on the BF16 matrix cores with SPLIT operands (v7).
+//
+// attention.hip's v5 keeps everything in fp32 on v_mfma_f32_32x32x2_f32 -- which runs on the SIMD's FP32 vector lanes, so its
+// 224 MFMAs per 32-query tile (14 300 cycles) and the ~1 600 softmax / staging VALU instructions ADD: the kernel sits at 42-45 %
+// of the f32 matrix peak and no schedule moves it (tools/a7_v5_ab.py).  Here every fp32 operand is split into three bf16 pieces,
+// x = hi + mid + lo EXACTLY (8 + 8 + 8 significand bits), and a product x y becomes six v_mfma_f32_32x32x16_bf16 piece products
+// accumulated in fp32 (the three dropped ones are <= 2^-24 |x y| each -- one fp32 rounding); fp16 features split exactly into
+// two pieces, four products, nothing dropped.  Per 32-key tile: Q K^T = 2 k-steps x 6 = 12 matrix instructions, P V = 2 x 5
+// (probabilities as hi + mid, 16 bits: 8e-6 relative on `out`; the disparity never goes through them) -- 22 x 32 cycles instead
+// of 32 x 64, and a bf16 MFMA holds the vector issue for 8 of its 32 cycles only, so the wave's own VALU work runs underneath.
+//
+// One LDS image serves K and V: [piece][channel][key] bf16, staged straight from the NCHW rows (a quad of 4 keys -> one 8-byte
+// store per piece).  V^T (rows = channels, k = keys) reads it row-wise (two ds_read_b64 per fragment, in the accumulator's key
+// order, so the probabilities feed the B operand from the registers they were computed in); K (rows = keys, k = channels)
+// reads it through the hardware transpose ds_read_b64_tr_b16.  Operand maps pinned on the device by tools/mfma_bf16_maps.hip.
+// Softmax, masks, disparity expectation, persistence and prefetch are v5's.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+template <typename TIN>
+struct Pieces;
+template <>
+struct Pieces<float> {
+    static constexpr int NP = 3;
+};
+template <>
+struct Pieces<f16> {
+    static constexpr int NP = 2;
+};
+
+// x = p[0] + p[1] (+ p[2]) exactly (fp32: three pieces; fp16-valued: the third would be 0 and is not produced)
+template <int NP>
+__device__ __forceinline__ void split(float x, __bf16 *p)
+{
+    const __bf16 h = (__bf16)x;
+    const float r = x - (float)h;
+    p[0] = h;
+    if (NP == 2) {
+        p[1] = (__bf16)r;
+    } else {
+        const __bf16 m = (__bf16)r;
+        p[1] = m;
+        p[2] = (__bf16)(r - (float)m);
+    }
+}
+
+template <int NT, int NWV, typename TIN>
+__global__ __launch_bounds__(NWV * 64) void cross_attention_split_kernel(const TIN *__restrict__ L, const TIN *__restrict__ R,
+                                                                         float *__restrict__ out, float *__restrict__ disp,
+                                                                         int C, int H, int W, int D, int mask_mode,
+                                                                         float scale, int tiles_per_wg, int ntiles)
+{
+    constexpr int NP = Pieces<TIN>::NP;
+    constexpr int Dk = 32 * (NT - 1);
+    constexpr int TQW = 32 * NWV;
+    constexpr int NK = TQW + Dk;
+    constexpr int RSE = NK + 4;                  // image row stride in bf16 elements (8-byte multiple)
+    constexpr int PSE = 32 * RSE;                // piece stride
+    constexpr int RMAX = (32 + NWV - 1) / NWV;
+    constexpr int NPASS = (NK / 4 + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) __bf16 Img[];   // [NP][32][RSE]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const unsigned HWu = (unsigned)H * (unsigned)W;  // launcher: 32 * H * W < 2^31
+    const int nx = (W + TQW - 1) / TQW;
+    const float sc2 = scale * 1.44269504088896340736f;
+    const int dl = l31 - 4 * half;
+    // transposed K reads: lane 4 q + p of its 16-lane group supplies row (channel) R0 + q, keys K0 + 4 p ..
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
+    const int k_off = (8 * half + tq) * RSE + 32 * wave + 16 * tg1 + 4 * tp;     // + 16 s RSE (k-step) + 4 tt RSE + 32 t (key tile)
+    const int v_off = l31 * RSE + 32 * wave + 4 * half;                          // + 32 t + 16 s (+ 8 for elements 4..7)
+
+    int tile = blockIdx.x * tiles_per_wg;
+    const int tile_end = (tile + tiles_per_wg < ntiles) ? tile + tiles_per_wg : ntiles;
+    if (tile >= tile_end) return;
+
+    typename Quad<TIN>::raw rk[RMAX][NPASS];
+    TIN qn[16];
+    unsigned okbits = 0;
+    auto issue = [&](int tl) {
+        const int x = tl % nx, bh = tl / nx;
+        const int hh = bh % H, bb = bh / H;
+        const int w0 = x * TQW, kbase = w0 - Dk;
+        const TIN *Rb = R + ((size_t)bb * C * HWu + (size_t)hh * W);
+        const TIN *Lb = L + ((size_t)bb * C * HWu + (size_t)hh * W);
+        okbits = 0;
+#pragma unroll
+        for (int pp = 0; pp < NPASS; ++pp) {
+            const int w = kbase + 4 * (lane + 64 * pp);
+            if (lane + 64 * pp < NK / 4 && w >= 0 && w + 3 < W) okbits |= 1u << pp;
+        }
+#pragma unroll
+        for (int rr = 0; rr < RMAX; ++rr) {
+            const int row = wave + rr * NWV;
+#pragma unroll
+            for (int pp = 0; pp < NPASS; ++pp) {
+                const bool ok = ((okbits >> pp) & 1u) && row < C && row < 32;
+                rk[rr][pp] = Quad<TIN>::ld(Rb + (ok ? (unsigned)row * HWu + (unsigned)(kbase + 4 * (lane + 64 * pp)) : 0u));
+            }
+        }
+        const int q = w0 + 32 * wave + l31;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {           // B operand order: k-step s = i >> 3, element j = i & 7 -> channel 16 s + 8 half + j
+            const int c = 16 * (i >> 3) + 8 * half + (i & 7);
+            qn[i] = Lb[(c < C && q < W) ? (unsigned)c * HWu + (unsigned)q : 0u];
+        }
+    };
+    auto commit = [&]() {  // registers -> the bf16 piece images: one 8-byte store per quad and piece
+#pragma unroll
+        for (int rr = 0; rr < RMAX; ++rr) {
+            const int row = wave + rr * NWV;
+            if (row < 32) {
+#pragma unroll
+                for (int pp = 0; pp < NPASS; ++pp) {
+                    if (lane + 64 * pp < NK / 4) {
+                        const f32x4 v = (((okbits >> pp) & 1u) && row < C) ? Quad<TIN>::widen(rk[rr][pp]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        bf16x4 pc[NP];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            __bf16 t[NP];
+                            split<NP>(v[e], t);
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) pc[p][e] = t[p];
+                        }
+#pragma unroll
+                        for (int p = 0; p < NP; ++p)
+                            *reinterpret_cast<bf16x4 *>(&Img[p * PSE + row * RSE + 4 * (lane + 64 * pp)]) = pc[p];
+                    }
+                }
+            }
+        }
+    };
+
+    issue(tile);
+    commit();
+    bf16x8 qf[2][NP];
+    for (;;) {
+        const int x = tile % nx, bh = tile / nx;
+        const int w0 = x * TQW, kbase = w0 - Dk;
+        const int q = w0 + 32 * wave + l31;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = 16 * s + 8 * half + j;
+                __bf16 t[NP];
+                split<NP>((c < C && q < W) ? (float)qn[8 * s + j] * sc2 : 0.0f, t);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) qf[s][p][j] = t[p];
+            }
+        __syncthreads();  // the image is visible
+        const bool more = tile + 1 < tile_end;
+        if (more) issue(tile + 1);
+
+        if (w0 + 32 * wave < W) {  // wave-uniform
+            const bool neg_left = mask_mode == STEREO_MASK_NEGINF && kbase < 0;
+            float m = -INFINITY, ssum = 0.0f, esc = 0.0f;
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+#pragma unroll 1
+            for (int t = NT - 1; t >= 0; --t) {
+                f32x16 a;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a[r] = 0.0f;
+                // ---- S^T tile = K_t Q^T: A = K through the transposed read, B = Q pieces
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8 kf[NP];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt) {
+                            const __bf16 *src = &Img[p * PSE + k_off + (16 * s + 4 * tt) * RSE + 32 * t];
+                            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)src);
+                            const short tv[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) kf[p][4 * tt + e] = __builtin_bit_cast(__bf16, tv[e]);
+                        }
+                    }
+                    // smallest terms first
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[s][1], a, 0, 0, 0);
+                    if (NP == 3) {
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[s][NP - 1], a, 0, 0, 0);
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[NP - 1], qf[s][0], a, 0, 0, 0);
+                    }
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[s][1], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[s][0], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[s][0], a, 0, 0, 0);
+                }
+                // ---- masks + online softmax (v5)
+                const int cb = Dk - 32 * t + dl;
+                if (t == NT - 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (cb < (r & 3) + 8 * (r >> 2)) a[r] = -INFINITY;  // d < 0
+                }
+                if (Dk - 32 * t + 31 >= D) {
+                    const int lim = cb - D;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (lim >= (r & 3) + 8 * (r >> 2)) a[r] = -INFINITY;  // d >= D
+                }
+                if (neg_left) {
+                    const int lim = cb - q;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (lim > (r & 3) + 8 * (r >> 2)) a[r] = -INFINITY;  // key = q - d < 0
+                }
+                float mt = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) mt = fmaxf(mt, fmaxf(a[r], a[r + 1]));
+                mt = fmaxf(mt, __shfl_xor(mt, 32));
+                const float mn = fmaxf(m, mt);
+                const float alpha = __builtin_amdgcn_exp2f(m - mn);
+                m = mn;
+                float ts = 0.0f, ti = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pe = __builtin_amdgcn_exp2f(a[r] - mn);
+                    a[r] = pe;
+                    ts += pe;
+                    ti = fmaf(pe, (float)((r & 3) + 8 * (r >> 2)), ti);
+                }
+                ssum = fmaf(ssum, alpha, ts);
+                esc = fmaf(esc, alpha, fmaf((float)cb, ts, -ti));
+                if (out) {
+                    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {  // wave-uniform: the running maximum rarely moves after the nearest tiles
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[r] *= alpha;
+                    }
+                    // ---- O^T += V_t^T P: A = V^T rows from the image (accumulator key order), B = P as hi + mid
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        bf16x8 ph, pm;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const __bf16 h = (__bf16)a[8 * s + e];
+                            ph[e] = h;
+                            pm[e] = (__bf16)(a[8 * s + e] - (float)h);
+                        }
+                        bf16x8 vf[NP];
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) {
+                            const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(&Img[p * PSE + v_off + 32 * t + 16 * s]);
+                            const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(&Img[p * PSE + v_off + 32 * t + 16 * s + 8]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) vf[p][e] = lo[e], vf[p][4 + e] = hi[e];
+                        }
+                        if (NP == 3) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[NP - 1], ph, o, 0, 0, 0);
+                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pm, o, 0, 0, 0);
+                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pm, o, 0, 0, 0);
+                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], ph, o, 0, 0, 0);
+                        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], ph, o, 0, 0, 0);
+                    }
+                }
+            }
+            float e = esc;
+            ssum += __shfl_xor(ssum, 32);
+            e += __shfl_xor(e, 32);
+            const float inv = 1.0f / ssum;
+            if (q < W) {
+                if (disp && half == 0) disp[(size_t)bh * W + q] = e * inv;
+                if (out) {
+                    const int hh = bh % H, bb = bh / H;
+                    float *ob = out + ((size_t)bb * C * HWu + (size_t)hh * W);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (c < C) ob[(unsigned)c * HWu + (unsigned)q] = o[r] * inv;
+                    }
+                }
+            }
+        }
+        if (!more) break;
+        __syncthreads();  // every wave is done reading the image
+        commit();
+        ++tile;
+    }
+}
+
+template <int NT, int NWV, typename TIN>
+int launch_split(const TIN *left, const TIN *right, float *out, float *disp, int C, int H, int W, int D, int mask_mode, float sc,
+                 int nwg, int tpw, int ntl, hipStream_t st)
+{
+    constexpr int NK = 32 * NWV + 32 * (NT - 1);
+    const size_t lds = (size_t)Pieces<TIN>::NP * 32 * (NK + 4) * 2;
+    auto kern = cross_attention_split_kernel<NT, NWV, TIN>;
+    static std::atomic<unsigned long long> lds_done{0};
+    if (lds > 160 * 1024 || !lds_opt_in(kern, lds, lds_done)) return STEREO_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(NWV * 64), lds, st, left, right, out, disp, C, H, W, D, mask_mode, sc, tpw, ntl);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+}  // namespace
+
+// Library-internal (common.h).  Envelope as v5: C <= 32, D <= 192, W % 4 == 0, quad-aligned features, 32 H W < 2^31.
+template <typename TIN>
+int stereo_cross_attention_split(const TIN *left, const TIN *right, float *out, float *disp, int B, int C, int H, int W, int D,
+                                 int mask_mode, float sc, hipStream_t st)
+{
+    if (C > 32 || D > 192 || D < 1 || W % 4 != 0 || !aligned_quad<TIN>(left) || !aligned_quad<TIN>(right) ||
+        (long long)32 * H * W >= (1LL << 31))
+        return STEREO_ERR_UNSUPPORTED;
+    const int nt = (D + 31) / 32 + 1;
+    int nwv = W > 128 ? 8 : 4;
+    if (stereo_opt(OPT_ATT_WAVES) == 4 || stereo_opt(OPT_ATT_WAVES) == 8) nwv = stereo_opt(OPT_ATT_WAVES);  // test hook
+    const int ntl = ((W + 32 * nwv - 1) / (32 * nwv)) * H * B;
+    int tpw = (ntl + 255) / 256;  // one resident workgroup per CU (87 KB image)
+    if (stereo_opt(OPT_TILES_PER_WG) > 0) tpw = stereo_opt(OPT_TILES_PER_WG);  // test hook: short persistent runs
+    const int nwg = (ntl + tpw - 1) / tpw;
+#define SPL(NTV)                                                                                                      \
+    return nwv == 8 ? launch_split<NTV, 8, TIN>(left, right, out, disp, C, H, W, D, mask_mode, sc, nwg, tpw, ntl, st) \
+                    : launch_split<NTV, 4, TIN>(left, right, out, disp, C, H, W, D, mask_mode, sc, nwg, tpw, ntl, st)
+    if (nt <= 3) SPL(3);
+    if (nt <= 5) SPL(5);
+    SPL(7);
+#undef SPL
+}
+
+template int stereo_cross_attention_split<float>(const float *, const float *, float *, float *, int, int, int, int, int, int,
+                                                 float, hipStream_t);
+template int stereo_cross_attention_split<f16>(const f16 *, const f16 *, float *, float *, int, int, int, int, int, int, float,
+                                               hipStream_t);

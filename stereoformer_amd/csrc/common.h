@@ -17,7 +17,7 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 enum StereoOpt {
     OPT_CORR_MFMA = 0,   // 1 (default): matrix-core volume kernels where their envelope allows; 0: VALU kernels
     OPT_GWC_FUSED,       // 1 (default): A3 + group mean + A4 in one launch; 0: separate launches
-    OPT_ATT_KERNEL,      // 0 (default): by shape; 2: LDS-score-sheet kernel; 4: two-pass register kernel; 6: chunked pipeline
+    OPT_ATT_KERNEL,      // 0 (default): by shape; 2: LDS-score-sheet; 4: two-pass register; 5: fp32 online; 6: chunked; 7: split-bf16
     OPT_ATT_WAVES,       // 0 (default): by row length; 4 / 5 / 8: waves per workgroup of the persistent attention kernels
     OPT_TILES_PER_WG,    // 0 (default): sized to the resident workgroups; n > 0: tiles per persistent workgroup
     OPT_PROB_SINGLE_PASS,  // 1 (default): softmax column in registers (D <= 192); 0: two-pass kernel
@@ -132,3 +132,7 @@ int stereo_cross_attention_chunked(const TIN *L, const TIN *R, const TIN *V, flo
 template <typename TIN>
 int stereo_corr_volume_chunked(const TIN *L, const TIN *R, float *vol, float *disp, int B, int C, int H, int W, int D,
                                float sgn, hipStream_t st);
+// attention_bf16.hip: A7 for C <= 32, value = right features, on the bf16 matrix cores with split (hi + mid + lo) operands.
+template <typename TIN>
+int stereo_cross_attention_split(const TIN *left, const TIN *right, float *out, float *disp, int B, int C, int H, int W, int D,
+                                 int mask_mode, float sc, hipStream_t st);

@@ -415,11 +415,11 @@ def test_resize_vs_oracle(S, oracle, golden):
 @pytest.mark.parametrize("cfg", [(2, 16, 5, 40, 12), (1, 32, 3, 200, 192), (1, 48, 2, 70, 33), (1, 40, 2, 300, 230),
                                  (1, 256, 2, 312, 64), (1, 8, 1, 64, 1), (1, 32, 1, 130, 320), (1, 20, 1, 96, 32),
                                  (2, 32, 3, 960, 192), (1, 24, 2, 516, 250)])
-@pytest.mark.parametrize("variant", ["auto", "v4", "v2"])
+@pytest.mark.parametrize("variant", ["auto", "v4", "v2", "v5"])
 def test_cross_attention(S, oracle, cfg, variant):
-    # auto: v5 (online softmax, scores in registers; C <= 32 and value = right features) else v4 (two-pass, scores in
-    # registers); v2: per-tile MFMA kernel with an LDS score sheet (unaligned / ragged shapes, 256 < D <= 320)
-    with S._native.test_options(att_kernel={"auto": 0, "v4": 4, "v2": 2}[variant]):
+    # v2: per-tile MFMA kernel with an LDS score sheet (unaligned / ragged shapes, 256 < D <= 320)
+    # auto: v7 (split-bf16 matrix cores) for C <= 32 with value = right features, else v4; v5: the fp32 online-softmax kernel
+    with S._native.test_options(att_kernel={"auto": 0, "v4": 4, "v2": 2, "v5": 5}[variant]):
         _cross_attention(S, oracle, cfg)
 
 
@@ -455,8 +455,9 @@ def _cross_attention(S, oracle, cfg):
           mean_atol=2.5e-4 * max(1.0, D / 192.0))   # summation-order noise of a D-term expectation grows with D
 
 
+@pytest.mark.parametrize("kern", [0, 5])
 @pytest.mark.parametrize("nw,tpw", [(4, 0), (8, 0), (8, 1), (4, 3)])
-def test_cross_attention_online_workgroup_shapes(S, oracle, nw, tpw):
+def test_cross_attention_online_workgroup_shapes(S, oracle, nw, tpw, kern):
     """v5 with 4 / 8 waves (128 / 256 queries) per workgroup tile and 1 / 3 / auto tiles per persistent workgroup, incl.
     partial last tiles, every band size class (NT = 3, 5, 7, 9), both masks, disparity-only mode."""
     rng = np.random.default_rng(31)
@@ -465,7 +466,7 @@ def test_cross_attention_online_workgroup_shapes(S, oracle, nw, tpw):
         R = rng.standard_normal((B, C, H, W), dtype=np.float32)
         for mask in ("zero", "neginf"):
             oo, od = oracle.cross_attention(L, R, None, D, mask, "sqrt_c")
-            with S._native.test_options(att_waves=nw, tiles_per_wg=tpw):
+            with S._native.test_options(att_waves=nw, tiles_per_wg=tpw, att_kernel=kern):
                 o, d = S.CrossAttentionCostVolume(D, mask, "sqrt_c")(dev(L), dev(R))
                 _, d2 = S.CrossAttentionCostVolume(D, mask, "sqrt_c")(dev(L), dev(R), need_out=False)
             close(o, oo, rtol=1e-4, atol=5e-5)
