@@ -118,10 +118,14 @@ def main():
         if want("A7_cross_attention"):
             att = S.CrossAttentionCostVolume(D, "zero", "sqrt_c")
             band = D * W - D * (D - 1) / 2
-            add("A7_cross_attention cfg-3 C=32 D=192", timeit(lambda: att(L, R), 3, 1),
-                (4 * N * C * 4 + N * 4) / 1e9, 2 * 2 * B * H * C * band / 1e9, bound="mfma")
-            add("A7_cross_attention(disp only) cfg-3", timeit(lambda: att(L, R, need_out=False), 3, 1),
+            add("A7_cross_attention cfg-3 C=32 D=192", timeit(lambda: att(L, R), 10, 2),
+                (4 * N * C * 4 + N * 4) / 1e9, 2 * 2 * B * H * C * band / 1e9, bound="mfma",
+                note="split-bf16 kernel (v7); frac = fp32-equivalent useful flops / f32 MFMA peak")
+            add("A7_cross_attention(disp only) cfg-3", timeit(lambda: att(L, R, need_out=False), 10, 2),
                 (2 * N * C * 4 + N * 4) / 1e9, 2 * B * H * C * band / 1e9, bound="mfma")
+            with S._native.test_options(att_kernel=5):
+                add("A7_cross_attention cfg-3 [fp32 online-softmax kernel v5, for comparison]", timeit(lambda: att(L, R), 10, 2),
+                    (4 * N * C * 4 + N * 4) / 1e9, 2 * 2 * B * H * C * band / 1e9, bound="mfma")
         # ---- RAFT shapes (cfg-4 per GPU)
         Br, Cr, Hr, Wr = 8, 256, 136, 240
         f1 = torch.randn(Br, Cr, Hr, Wr, device=dev)
