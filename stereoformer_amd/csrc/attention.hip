@@ -715,12 +715,13 @@ extern "C" int stereo_cross_attention_f32(const float *left, const float *right,
                 const int rc5 = launch_online<float>(left, right, out, disp, B, C, H, W, D, mask_mode, sc, as_stream(stream));
                 if (rc5 != STEREO_ERR_UNSUPPORTED) return rc5;
             }
-            // v6 (channel-chunked item pipeline) serves the fp16-feature entry points; on fp32 features at C = 256 it
-            // measured 5-10 % behind v4 (0.36 vs 0.335 ms at [8,256,136,240] D=48: both sit on the executed f32-MFMA work
-            // of the 32-key band tiles), so fp32 calls take it only through the test hook
-            if (forced == 6) {
+            // Channel-chunked item pipeline (attention_chunked.hip).  Its split-bf16 form is the default for C > 32 at bands
+            // of <= 64 (0.28 vs 0.38 ms at [8,256,136,240] D=48, 0.15 vs 0.19 ms at [4,256,96,312] D=64 against the
+            // two-pass kernel below); its fp32-MFMA form measured 5-10 % behind the two-pass kernel and is reached through
+            // the test hook (6) only.  Hook 4 forces the two-pass kernel, 8 the split form.
+            if (forced == 6 || forced == 8 || (forced == 0 && nt <= 3 && C > 32)) {
                 const int rc6 = stereo_cross_attention_chunked<float>(left, right, value, out, disp, B, C, Cv, H, W, D,
-                                                                      mask_mode, sc, as_stream(stream));
+                                                                      mask_mode, sc, forced != 6, as_stream(stream));
                 if (rc6 != STEREO_ERR_UNSUPPORTED) return rc6;
             }
 #define ATT4(NTV)                                                                                                      \
@@ -802,5 +803,6 @@ extern "C" int stereo_cross_attention_f16(const void *left, const void *right, c
         const int rc = launch_online<f16>(L, R, out, disp, B, C, H, W, D, mask_mode, sc, as_stream(stream));
         if (rc != STEREO_ERR_UNSUPPORTED) return rc;
     }
-    return stereo_cross_attention_chunked<f16>(L, R, V, out, disp, B, C, Cv, H, W, D, mask_mode, sc, as_stream(stream));
+    return stereo_cross_attention_chunked<f16>(L, R, V, out, disp, B, C, Cv, H, W, D, mask_mode, sc,
+                                               stereo_opt(OPT_ATT_KERNEL) != 6, as_stream(stream));  // split form where it applies
 }

@@ -18,10 +18,6 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-
 template <typename TIN>
 struct Pieces;
 template <>
@@ -32,22 +28,6 @@ template <>
 struct Pieces<f16> {
     static constexpr int NP = 2;
 };
-
-// x = p[0] + p[1] (+ p[2]) exactly (fp32: three pieces; fp16-valued: the third would be 0 and is not produced)
-template <int NP>
-__device__ __forceinline__ void split(float x, __bf16 *p)
-{
-    const __bf16 h = (__bf16)x;
-    const float r = x - (float)h;
-    p[0] = h;
-    if (NP == 2) {
-        p[1] = (__bf16)r;
-    } else {
-        const __bf16 m = (__bf16)r;
-        p[1] = m;
-        p[2] = (__bf16)(r - (float)m);
-    }
-}
 
 template <int NT, int NWV, typename TIN>
 __global__ __launch_bounds__(NWV * 64) void cross_attention_split_kernel(const TIN *__restrict__ L, const TIN *__restrict__ R,
@@ -65,7 +45,7 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split_kernel(const T
     constexpr int NPASS = (NK / 4 + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) __bf16 Img[];   // [NP][32][RSE]
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l31 = lane & 31, half = lane >> 5;
     const unsigned HWu = (unsigned)H * (unsigned)W;  // launcher: 32 * H * W < 2^31
     const int nx = (W + TQW - 1) / TQW;
@@ -80,35 +60,34 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split_kernel(const T
     const int tile_end = (tile + tiles_per_wg < ntiles) ? tile + tiles_per_wg : ntiles;
     if (tile >= tile_end) return;
 
+    // Loads go through buffer resources (common.h): a key outside [0, W) is an out-of-range byte offset and reads 0 -- the zero
+    // padding of the band and what ZERO-mask mode wants for the values; channel rows >= C get an empty resource, Q channels
+    // >= C fall past the end of theirs.  No per-lane bound selects.
     typename Quad<TIN>::raw rk[RMAX][NPASS];
     TIN qn[16];
-    unsigned okbits = 0;
+    constexpr int ES = (int)sizeof(TIN);
     auto issue = [&](int tl) {
         const int x = tl % nx, bh = tl / nx;
         const int hh = bh % H, bb = bh / H;
         const int w0 = x * TQW, kbase = w0 - Dk;
         const TIN *Rb = R + ((size_t)bb * C * HWu + (size_t)hh * W);
         const TIN *Lb = L + ((size_t)bb * C * HWu + (size_t)hh * W);
-        okbits = 0;
+        int voff[NPASS];
 #pragma unroll
-        for (int pp = 0; pp < NPASS; ++pp) {
-            const int w = kbase + 4 * (lane + 64 * pp);
-            if (lane + 64 * pp < NK / 4 && w >= 0 && w + 3 < W) okbits |= 1u << pp;
-        }
+        for (int pp = 0; pp < NPASS; ++pp) voff[pp] = (lane + 64 * pp < NK / 4) ? (kbase + 4 * (lane + 64 * pp)) * ES : -1;
 #pragma unroll
-        for (int rr = 0; rr < RMAX; ++rr) {
+        for (int rr = 0; rr < RMAX; ++rr) {       // one resource per row: the range check sees voffset + soffset on gfx950
             const int row = wave + rr * NWV;
+            const __amdgpu_buffer_rsrc_t rs = buffer_rsrc(Rb + (size_t)row * HWu, row < C ? (unsigned)W * ES : 0u);
 #pragma unroll
-            for (int pp = 0; pp < NPASS; ++pp) {
-                const bool ok = ((okbits >> pp) & 1u) && row < C && row < 32;
-                rk[rr][pp] = Quad<TIN>::ld(Rb + (ok ? (unsigned)row * HWu + (unsigned)(kbase + 4 * (lane + 64 * pp)) : 0u));
-            }
+            for (int pp = 0; pp < NPASS; ++pp) rk[rr][pp] = BufLd<TIN>::quad(rs, voff[pp], 0);
         }
-        const int q = w0 + 32 * wave + l31;
+        const __amdgpu_buffer_rsrc_t rq = buffer_rsrc(Lb, ((unsigned)(C - 1) * HWu + (unsigned)W) * ES);
+        int vq = (int)(((unsigned)(8 * half) * HWu + (unsigned)(w0 + 32 * wave + l31)) * ES);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {           // B operand order: k-step s = i >> 3, element j = i & 7 -> channel 16 s + 8 half + j
-            const int c = 16 * (i >> 3) + 8 * half + (i & 7);
-            qn[i] = Lb[(c < C && q < W) ? (unsigned)c * HWu + (unsigned)q : 0u];
+            qn[i] = BufLd<TIN>::one(rq, vq, 0);
+            vq += (int)((i == 7 ? 9u : 1u) * HWu * ES);
         }
     };
     auto commit = [&]() {  // registers -> the bf16 piece images: one 8-byte store per quad and piece
@@ -119,18 +98,13 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split_kernel(const T
 #pragma unroll
                 for (int pp = 0; pp < NPASS; ++pp) {
                     if (lane + 64 * pp < NK / 4) {
-                        const f32x4 v = (((okbits >> pp) & 1u) && row < C) ? Quad<TIN>::widen(rk[rr][pp]) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                        bf16x4 pc[NP];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            __bf16 t[NP];
-                            split<NP>(v[e], t);
-#pragma unroll
-                            for (int p = 0; p < NP; ++p) pc[p][e] = t[p];
-                        }
+                        const f32x4 v = Quad<TIN>::widen(rk[rr][pp]);
+                        bf16x2 a[NP], b[NP];
+                        split_pair<NP>((f32x2){v[0], v[1]}, a);
+                        split_pair<NP>((f32x2){v[2], v[3]}, b);
 #pragma unroll
                         for (int p = 0; p < NP; ++p)
-                            *reinterpret_cast<bf16x4 *>(&Img[p * PSE + row * RSE + 4 * (lane + 64 * pp)]) = pc[p];
+                            *reinterpret_cast<bf16x4 *>(&Img[p * PSE + row * RSE + 4 * (lane + 64 * pp)]) = cat2(a[p], b[p]);
                     }
                 }
             }
@@ -145,15 +119,12 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split_kernel(const T
         const int w0 = x * TQW, kbase = w0 - Dk;
         const int q = w0 + 32 * wave + l31;
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s) {
+            float xq[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c = 16 * s + 8 * half + j;
-                __bf16 t[NP];
-                split<NP>((c < C && q < W) ? (float)qn[8 * s + j] * sc2 : 0.0f, t);
-#pragma unroll
-                for (int p = 0; p < NP; ++p) qf[s][p][j] = t[p];
-            }
+            for (int j = 0; j < 8; ++j) xq[j] = (float)qn[8 * s + j] * sc2;
+            split_oct<NP>(xq, qf[s]);
+        }
         __syncthreads();  // the image is visible
         const bool more = tile + 1 < tile_end;
         if (more) issue(tile + 1);
@@ -238,13 +209,12 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split_kernel(const T
                     // ---- O^T += V_t^T P: A = V^T rows from the image (accumulator key order), B = P as hi + mid
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        bf16x8 ph, pm;
+                        bf16x8 pq[2];                // P as hi + mid
+                        float xp[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const __bf16 h = (__bf16)a[8 * s + e];
-                            ph[e] = h;
-                            pm[e] = (__bf16)(a[8 * s + e] - (float)h);
-                        }
+                        for (int e = 0; e < 8; ++e) xp[e] = a[8 * s + e];
+                        split_oct<2>(xp, pq);
+                        const bf16x8 ph = pq[0], pm = pq[1];
                         bf16x8 vf[NP];
 #pragma unroll
                         for (int p = 0; p < NP; ++p) {
@@ -270,10 +240,13 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split_kernel(const T
                 if (out) {
                     const int hh = bh % H, bb = bh / H;
                     float *ob = out + ((size_t)bb * C * HWu + (size_t)hh * W);
+                    const __amdgpu_buffer_rsrc_t ro = buffer_rsrc(ob, ((unsigned)(C - 1) * HWu + (unsigned)W) * 4u);
+                    int vo = (int)(((unsigned)(4 * half) * HWu + (unsigned)q) * 4u);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (c < C) ob[(unsigned)c * HWu + (unsigned)q] = o[r] * inv;
+                    for (int r = 0; r < 16; ++r) {   // accumulator row r -> channel (r & 3) + 8 (r >> 2) + 4 half; >= C: dropped
+                        const float ov = o[r] * inv;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov), ro, vo, 0, 0);
+                        vo += (int)(((r & 3) == 3 ? 5u : 1u) * HWu * 4u);
                     }
                 }
             }
@@ -286,15 +259,25 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split_kernel(const T
 }
 
 template <int NT, int NWV, typename TIN>
-int launch_split(const TIN *left, const TIN *right, float *out, float *disp, int C, int H, int W, int D, int mask_mode, float sc,
-                 int nwg, int tpw, int ntl, hipStream_t st)
+int launch_split(const TIN *left, const TIN *right, float *out, float *disp, int B, int C, int H, int W, int D, int mask_mode,
+                 float sc, hipStream_t st)
 {
     constexpr int NK = 32 * NWV + 32 * (NT - 1);
     const size_t lds = (size_t)Pieces<TIN>::NP * 32 * (NK + 4) * 2;
     auto kern = cross_attention_split_kernel<NT, NWV, TIN>;
     static std::atomic<unsigned long long> lds_done{0};
+    static std::atomic<int> per_cu{0};
     if (lds > 160 * 1024 || !lds_opt_in(kern, lds, lds_done)) return STEREO_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(NWV * 64), lds, st, left, right, out, disp, C, H, W, D, mask_mode, sc, tpw, ntl);
+    const long long ntl = (long long)((W + 32 * NWV - 1) / (32 * NWV)) * H * B;
+    if (ntl >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
+    // persistent: every resident workgroup takes an equal run of tiles (two 8-wave workgroups share a CU at fp16's 58 KB
+    // image: one's load / split phase under the other's matrix phase)
+    const int resident = 256 * workgroups_per_cu(kern, NWV * 64, lds, per_cu);
+    int tpw = (int)((ntl + resident - 1) / resident);
+    if (stereo_opt(OPT_TILES_PER_WG) > 0) tpw = stereo_opt(OPT_TILES_PER_WG);  // test hook: short persistent runs
+    const int nwg = (int)((ntl + tpw - 1) / tpw);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(NWV * 64), lds, st, left, right, out, disp, C, H, W, D, mask_mode, sc, tpw,
+                       (int)ntl);
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }
@@ -310,15 +293,19 @@ int stereo_cross_attention_split(const TIN *left, const TIN *right, float *out, 
         (long long)32 * H * W >= (1LL << 31))
         return STEREO_ERR_UNSUPPORTED;
     const int nt = (D + 31) / 32 + 1;
-    int nwv = W > 128 ? 8 : 4;
-    if (stereo_opt(OPT_ATT_WAVES) == 4 || stereo_opt(OPT_ATT_WAVES) == 8) nwv = stereo_opt(OPT_ATT_WAVES);  // test hook
-    const int ntl = ((W + 32 * nwv - 1) / (32 * nwv)) * H * B;
-    int tpw = (ntl + 255) / 256;  // one resident workgroup per CU (87 KB image)
-    if (stereo_opt(OPT_TILES_PER_WG) > 0) tpw = stereo_opt(OPT_TILES_PER_WG);  // test hook: short persistent runs
-    const int nwg = (ntl + tpw - 1) / tpw;
-#define SPL(NTV)                                                                                                      \
-    return nwv == 8 ? launch_split<NTV, 8, TIN>(left, right, out, disp, C, H, W, D, mask_mode, sc, nwg, tpw, ntl, st) \
-                    : launch_split<NTV, 4, TIN>(left, right, out, disp, C, H, W, D, mask_mode, sc, nwg, tpw, ntl, st)
+    // waves (32 queries each) per workgroup: 8 (256-query tiles; the band halo is loaded and split once per tile, so wide tiles
+    // win even where they leave slots idle: W = 960 measured 0.89 ms with 8 waves against 1.03 with five exact 6-wave tiles);
+    // rows of <= 192 / <= 128 queries take one 6- / 4-wave tile
+    const int qt = (W + 31) / 32;
+    int nwv = qt <= 4 ? 4 : (qt <= 6 ? 6 : 8);
+    const int forced = stereo_opt(OPT_ATT_WAVES);  // test hook
+    if (forced == 4 || forced == 6 || forced == 8) nwv = forced;
+#define SPL(NTV)                                                                                            \
+    do {                                                                                                    \
+        if (nwv == 8) return launch_split<NTV, 8, TIN>(left, right, out, disp, B, C, H, W, D, mask_mode, sc, st); \
+        if (nwv == 6) return launch_split<NTV, 6, TIN>(left, right, out, disp, B, C, H, W, D, mask_mode, sc, st); \
+        return launch_split<NTV, 4, TIN>(left, right, out, disp, B, C, H, W, D, mask_mode, sc, st);               \
+    } while (0)
     if (nt <= 3) SPL(3);
     if (nt <= 5) SPL(5);
     SPL(7);

@@ -43,6 +43,19 @@ static inline bool lds_opt_in(K kern, size_t bytes, std::atomic<unsigned long lo
     return true;
 }
 
+// Workgroups of a kernel instantiation that fit one CU (registers, waves, LDS), asked of the runtime once per instantiation:
+// what a persistent launch divides its tiles by.
+template <typename K>
+static inline int workgroups_per_cu(K kern, int block, size_t lds, std::atomic<int> &cache)
+{
+    int n = cache.load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(kern), block, lds) != hipSuccess || n < 1)
+        n = 1;
+    cache.store(n, std::memory_order_relaxed);
+    return n;
+}
+
 #define STEREO_REQUIRE_PTR(p) \
     do {                      \
         if ((p) == nullptr) return STEREO_ERR_NULL_POINTER; \
@@ -81,6 +94,68 @@ struct Quad<f16> {
     static __device__ __forceinline__ raw ld(const f16 *p) { return *reinterpret_cast<const f16x4 *>(p); }
     static __device__ __forceinline__ f32x4 widen(raw r) { return __builtin_convertvector(r, f32x4); }
 };
+// The same loads through a buffer resource (raw, stride 0): the byte offset `voff` is range-checked against the resource's
+// num_records and an out-of-range lane reads 0 without touching memory (negative offsets wrap to huge unsigned ones).  On
+// gfx950 the check sees voff + soff (tools/buf_probe.hip), so a row index must go into the resource's base, not into soff.
+// Row- and channel-bound selects of a kernel's loaders disappear into it.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), (short)0, (int)bytes, 0x00020000);
+}
+template <typename T>
+struct BufLd;
+template <>
+struct BufLd<float> {
+    static __device__ __forceinline__ f32x4 quad(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+    {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    }
+    static __device__ __forceinline__ float one(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+    {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    }
+};
+template <>
+struct BufLd<f16> {
+    static __device__ __forceinline__ f16x4 quad(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+    {
+        return __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    }
+    static __device__ __forceinline__ f16 one(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+    {
+        return __builtin_bit_cast(f16, __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0));
+    }
+};
+// Split-bf16 operands (attention_bf16.hip, attention_chunked.hip): x = p[0] + p[1] (+ p[2]) exactly -- three bf16 pieces carry
+// an fp32 value's 24 mantissa bits, two an fp16 value's 11.  Two values at a time: one v_cvt_pk_bf16_f32, the two widenings
+// (shift / mask) and one v_pk_add_f32 per piece level.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+template <int NP>
+__device__ __forceinline__ void split_pair(f32x2 x, bf16x2 *p)
+{
+    p[0] = __builtin_convertvector(x, bf16x2);
+    const f32x2 r = x - __builtin_convertvector(p[0], f32x2);
+    p[1] = __builtin_convertvector(r, bf16x2);
+    if (NP == 3) p[2] = __builtin_convertvector(r - __builtin_convertvector(p[1], f32x2), bf16x2);
+}
+__device__ __forceinline__ bf16x4 cat2(bf16x2 a, bf16x2 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3); }
+__device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+// eight fp32 values -> NP bf16x8 MFMA operands
+template <int NP>
+__device__ __forceinline__ void split_oct(const float *x, bf16x8 *p)
+{
+    bf16x2 t[4][NP];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_pair<NP>((f32x2){x[2 * j], x[2 * j + 1]}, t[j]);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) p[q] = cat4(cat2(t[0][q], t[1][q]), cat2(t[2][q], t[3][q]));
+}
 // base pointers of quad loads: 16 B for fp32, 8 B for fp16
 template <typename T>
 static inline bool aligned_quad(const void *p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(T) - 1)) == 0; }
@@ -127,7 +202,7 @@ int stereo_corr_volume_bwd_mfma(const float *left, const float *right, const flo
 // attention_chunked.hip: A7 for any C / Cv / value tensor, channel-chunked and software-pipelined; features fp32 or fp16.
 template <typename TIN>
 int stereo_cross_attention_chunked(const TIN *L, const TIN *R, const TIN *V, float *out, float *disp, int B, int C, int Cv,
-                                   int H, int W, int D, int mask_mode, float sc, hipStream_t st);
+                                   int H, int W, int D, int mask_mode, float sc, bool split_bf16_form, hipStream_t st);
 // corr_chunked.hip: A1 (+ A4) for C > 32, channels in 32-channel chunks (D <= 128); same conventions as above.
 template <typename TIN>
 int stereo_corr_volume_chunked(const TIN *L, const TIN *R, float *vol, float *disp, int B, int C, int H, int W, int D,

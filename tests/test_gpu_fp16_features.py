@@ -97,7 +97,8 @@ def test_fp16_outside_the_matrix_core_envelope_is_widened_on_the_host(S, oracle)
 @pytest.mark.parametrize("cfg", [(2, 16, 5, 40, 12, None), (1, 32, 3, 200, 192, None), (1, 48, 2, 72, 33, 20), (1, 256, 2, 312, 64, None),
                                  (1, 256, 2, 240, 48, 256), (1, 8, 1, 64, 1, 5), (1, 20, 1, 96, 32, None), (1, 24, 2, 516, 150, 24),
                                  (2, 32, 3, 960, 192, None)])
-def test_cross_attention_fp16_features(S, oracle, cfg):
+@pytest.mark.parametrize("kern", [0, 8])
+def test_cross_attention_fp16_features(S, oracle, cfg, kern):
     """A7 on fp16 features: C <= 32 with value = right features -> online-softmax kernel; everything else -> the
     channel-chunked pipeline (incl. a separate value tensor, Cv != C, C = 256)."""
     B, C, H, W, D, Cv = cfg
@@ -107,19 +108,22 @@ def test_cross_attention_fp16_features(S, oracle, cfg):
     Vh, V = (None, None) if Cv is None else h16(rng.standard_normal((B, Cv, H, W), dtype=np.float32))
     for mask in ("zero", "neginf"):
         for scale in ("sqrt_c", "mean"):
-            o, d = S.CrossAttentionCostVolume(D, mask, scale)(Lh, Rh, Vh)
+            with S._native.test_options(att_kernel=kern):
+                o, d = S.CrossAttentionCostVolume(D, mask, scale)(Lh, Rh, Vh)
+                _, d2 = S.CrossAttentionCostVolume(D, mask, scale)(Lh, Rh, need_out=False)
             oo, od = oracle.cross_attention(L, R, V, D, mask, scale)
             close(o, oo, rtol=1e-4, atol=5e-5)
             disp_close(d, od, D)
-            _, d2 = S.CrossAttentionCostVolume(D, mask, scale)(Lh, Rh, need_out=False)
             disp_close(d2, od, D)
 
 
 @pytest.mark.parametrize("cfg", [(1, 256, 2, 240, 48), (1, 64, 3, 312, 64), (2, 40, 2, 128, 100), (1, 33, 1, 96, 20), (1, 256, 1, 516, 192)])
 @pytest.mark.parametrize("waves", [0, 4, 5, 8])
-def test_cross_attention_chunked_kernel_fp32(S, oracle, cfg, waves):
-    """The channel-chunked item pipeline on fp32 features (reached through the test hook; fp32 calls default to the two-pass
-    kernel, which measured faster): every workgroup shape, 1 / auto tiles per persistent workgroup, both masks."""
+@pytest.mark.parametrize("kern", [6, 8])
+def test_cross_attention_chunked_kernel_fp32(S, oracle, cfg, waves, kern):
+    """The channel-chunked item pipeline on fp32 features, in its fp32-MFMA form (hook 6) and its split-bf16 form (hook 8; bands
+    of <= 64, longer ones fall through to the fp32 form): every workgroup shape, 1 / auto tiles per persistent workgroup, both
+    masks."""
     B, C, H, W, D = cfg
     rng = np.random.default_rng(74)
     L = rng.standard_normal((B, C, H, W), dtype=np.float32)
@@ -129,7 +133,7 @@ def test_cross_attention_chunked_kernel_fp32(S, oracle, cfg, waves):
     for mask in ("zero", "neginf"):
         oo, od = oracle.cross_attention(L, R, V, D, mask, "sqrt_c")
         for tpw in (0, 1):
-            with S._native.test_options(att_kernel=6, att_waves=waves, tiles_per_wg=tpw):
+            with S._native.test_options(att_kernel=kern, att_waves=waves, tiles_per_wg=tpw):
                 o, d = S.CrossAttentionCostVolume(D, mask, "sqrt_c")(dev(L), dev(R), dev(V))
                 _, d2 = S.CrossAttentionCostVolume(D, mask, "sqrt_c")(dev(L), dev(R), need_out=False)
             close(o, oo, rtol=1e-4, atol=5e-5)

@@ -15,7 +15,8 @@ for (nm, bb, cc, hh, ww, dd) in (("cfg-3b [8,256,136,240] D=48", 8, 256, 136, 24
     a2 = S.CrossAttentionCostVolume(dd, "neginf", "sqrt_c")
     for half in (False, True):
         x1, x2 = (q1.half(), q2.half()) if half else (q1, q2)
-        for opts in ({"att_kernel": 4}, {"att_kernel": 6, "att_waves": 4}, {"att_kernel": 6, "att_waves": 5}, {"att_kernel": 6, "att_waves": 8}):
+        for opts in ({"att_kernel": 4}, {"att_kernel": 6, "att_waves": 4}, {"att_kernel": 6, "att_waves": 5}, {"att_kernel": 6, "att_waves": 8},
+                     {"att_kernel": 8, "att_waves": 4}, {"att_kernel": 8, "att_waves": 5}, {"att_kernel": 8, "att_waves": 8}):
             if half and opts["att_kernel"] == 4:
                 continue
             with S._native.test_options(**opts), torch.no_grad():
