@@ -526,10 +526,8 @@ int launch_chunked_split(const TIN *L, const TIN *R, const TIN *V, float *out, f
     if (lds > 160 * 1024 || !lds_opt_in(kern, lds, lds_done)) return STEREO_ERR_UNSUPPORTED;
     const long long ntl = (long long)((W + 32 * NWV - 1) / (32 * NWV)) * H * B;
     if (ntl >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
-    int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > 8 / NWV) per_cu = 8 / NWV;      // ~200 VGPRs: two waves per SIMD, eight per CU
-    if (per_cu < 1) per_cu = 1;
-    const int resident = 256 * per_cu;
+    static std::atomic<int> per_cu{0};
+    const int resident = 256 * workgroups_per_cu(kern, NWV * 64, lds, per_cu);
     int tpw = (int)((ntl + resident - 1) / resident);
     if (stereo_opt(OPT_TILES_PER_WG) > 0) tpw = stereo_opt(OPT_TILES_PER_WG);
     const int nwg = (int)((ntl + tpw - 1) / tpw);
@@ -591,11 +589,17 @@ int stereo_cross_attention_chunked(const TIN *L, const TIN *R, const TIN *V, flo
         if (nwv == 5) CH(NTV, 5, 2); \
         CH(NTV, 4, 2);               \
     } while (0)
-    if (nt <= 3 && split_bf16_form) {  // short bands: split operands on the bf16 matrix cores
+    if (nt <= 5 && split_bf16_form) {  // bands of <= 128: split operands on the bf16 matrix cores
+        // wide tiles: the band halo is loaded and split once per tile (W = 312: 8 waves 0.151 / 0.182 ms at D = 64 / 128, 5
+        // exact-fit waves 0.147 / 0.215)
+        if (stereo_opt(OPT_ATT_WAVES) == 0) nwv = qt <= 4 ? 4 : (qt == 5 ? 5 : 8);
         int rc;
-        if (nwv == 8) rc = launch_chunked_split<3, 8, TIN>(L, R, V, out, disp, B, C, Cv, H, W, D, mask_mode, sc, st);
-        else if (nwv == 5) rc = launch_chunked_split<3, 5, TIN>(L, R, V, out, disp, B, C, Cv, H, W, D, mask_mode, sc, st);
-        else rc = launch_chunked_split<3, 4, TIN>(L, R, V, out, disp, B, C, Cv, H, W, D, mask_mode, sc, st);
+#define SP(NTV)                                                                                                     \
+    (nwv == 8   ? launch_chunked_split<NTV, 8, TIN>(L, R, V, out, disp, B, C, Cv, H, W, D, mask_mode, sc, st)       \
+     : nwv == 5 ? launch_chunked_split<NTV, 5, TIN>(L, R, V, out, disp, B, C, Cv, H, W, D, mask_mode, sc, st)       \
+                : launch_chunked_split<NTV, 4, TIN>(L, R, V, out, disp, B, C, Cv, H, W, D, mask_mode, sc, st))
+        rc = nt <= 3 ? SP(3) : SP(5);
+#undef SP
         if (rc != STEREO_ERR_UNSUPPORTED) return rc;
     }
     if (nt <= 3) CH_NT(3);

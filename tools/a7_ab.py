@@ -9,7 +9,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import stereoformer_amd as S  # noqa: E402
 from tools.kernel_bench import timeit  # noqa: E402
 
-for (nm, bb, cc, hh, ww, dd) in (("cfg-3b [8,256,136,240] D=48", 8, 256, 136, 240, 48), ("cfg-5 [4,256,96,312] D=64", 4, 256, 96, 312, 64)):
+for (nm, bb, cc, hh, ww, dd) in (("cfg-3b [8,256,136,240] D=48", 8, 256, 136, 240, 48), ("cfg-5 [4,256,96,312] D=64", 4, 256, 96, 312, 64),
+                              ("[4,256,96,312] D=128", 4, 256, 96, 312, 128), ("[8,64,136,240] D=100", 8, 64, 136, 240, 100)):
     q1 = torch.randn(bb, cc, hh, ww, device="cuda")
     q2 = torch.randn(bb, cc, hh, ww, device="cuda")
     a2 = S.CrossAttentionCostVolume(dd, "neginf", "sqrt_c")

@@ -142,12 +142,16 @@ def main():
                 ms = timeit(lambda: a2(q1, q2), 20, 3)
                 # 11 flop/B: left of the f32 ridge (~20 flop/B) -> the HBM roofline is the relevant one; both are reported
                 add(f"A7_cross_attention {nm}", ms, gb, gf, bound="hbm",
-                    note=f"channel-chunked pipelined kernel; {gf / ms / MFMA_F32:.3f} of the f32 MFMA peak on algorithmic flops")
+                    note=f"channel-chunked item pipeline, split-bf16 form (v8); bytes = L + R + V + out; "
+                         f"{gf / ms / MFMA_F32:.3f} of the f32 MFMA peak on fp32-equivalent algorithmic flops")
                 add(f"A7_cross_attention(disp only) {nm}", timeit(lambda: a2(q1, q2, need_out=False), 20, 3),
                     (2 * bb * cc * hh * ww * 4 + bb * hh * ww * 4) / 1e9, gf / 2, bound="hbm")
                 with S._native.test_options(att_kernel=4):
-                    add(f"A7_cross_attention {nm} [two-pass kernel v4, for comparison]", timeit(lambda: a2(q1, q2), 20, 3),
+                    add(f"A7_cross_attention {nm} [two-pass fp32 kernel v4, for comparison]", timeit(lambda: a2(q1, q2), 20, 3),
                         gb, gf, bound="hbm")
+                with S._native.test_options(att_kernel=6):
+                    add(f"A7_cross_attention {nm} [chunked pipeline, fp32-MFMA form v6, for comparison]",
+                        timeit(lambda: a2(q1, q2), 20, 3), gb, gf, bound="hbm")
                 del q1, q2
         if want("N2_fp16"):   # fp16 feature operands (fp32 arithmetic / outputs) + the extractor epilogue
             Lh, Rh = L.half(), R.half()
