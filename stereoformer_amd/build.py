@@ -35,6 +35,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
              "-Wno-unused-function"]
     objs = []
     procs = []
+    # the split-bf16 attention kernels take their running maxima with nnan max (no NaN reaches them: a band's nearest key
+    # is never masked): without the flag every MFMA result is canonicalised (v_max x, x, x) before its first v_max
+    extra = {"attention_bf16.hip": ["-fno-honor-nans"], "attention_chunked.hip": ["-fno-honor-nans"]}
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
         objs.append(obj)
@@ -42,7 +45,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 and all(os.path.getmtime(obj) >= os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h")))
                 and os.path.getmtime(obj) >= os.path.getmtime(os.path.join(HERE, "..", "include", "stereo_hip.h"))):
             continue
-        cmd = [hipcc, *flags, "-c", src, "-o", obj]
+        cmd = [hipcc, *flags, *extra.get(os.path.basename(src), []), "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -191,14 +191,21 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split_kernel(const T
                 const float mn = fmaxf(m, mt);
                 const float alpha = __builtin_amdgcn_exp2f(m - mn);
                 m = mn;
-                float ts = 0.0f, ti = 0.0f;
+                // packed-f32 VALU on register pairs (2 x the scalar rate): register 2k sits at key offset 2 (k & 1) + 8 (k >> 1)
+                // of its tile, register 2k + 1 one further
+                const f32x2 nm = {-mn, -mn};
+                f32x2 T2 = {0.0f, 0.0f}, U2 = {0.0f, 0.0f};
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pe = __builtin_amdgcn_exp2f(a[r] - mn);
-                    a[r] = pe;
-                    ts += pe;
-                    ti = fmaf(pe, (float)((r & 3) + 8 * (r >> 2)), ti);
+                for (int k = 0; k < 8; ++k) {
+                    const f32x2 sh = (f32x2){a[2 * k], a[2 * k + 1]} + nm;
+                    const f32x2 pe = {__builtin_amdgcn_exp2f(sh[0]), __builtin_amdgcn_exp2f(sh[1])};
+                    a[2 * k] = pe[0];
+                    a[2 * k + 1] = pe[1];
+                    T2 += pe;
+                    const float base = (float)(2 * (k & 1) + 8 * (k >> 1));
+                    U2 = __builtin_elementwise_fma(pe, (f32x2){base, base}, U2);
                 }
+                const float ts = T2[0] + T2[1], ti = U2[0] + U2[1] + T2[1];
                 ssum = fmaf(ssum, alpha, ts);
                 esc = fmaf(esc, alpha, fmaf((float)cb, ts, -ti));
                 if (out) {
