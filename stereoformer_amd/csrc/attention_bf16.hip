@@ -47,7 +47,7 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split_kernel(const T
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l31 = lane & 31, half = lane >> 5;
-    const unsigned HWu = (unsigned)H * (unsigned)W;  // launcher: 32 * H * W < 2^31
+    const unsigned HWu = (unsigned)H * (unsigned)W;  // launcher: 32 * H * W < 2^30 (32-bit byte offsets)
     const int nx = (W + TQW - 1) / TQW;
     const float sc2 = scale * 1.44269504088896340736f;
     const int dl = l31 - 4 * half;
@@ -291,13 +291,14 @@ int launch_split(const TIN *left, const TIN *right, float *out, float *disp, int
 
 }  // namespace
 
-// Library-internal (common.h).  Envelope as v5: C <= 32, D <= 192, W % 4 == 0, quad-aligned features, 32 H W < 2^31.
+// Library-internal (common.h).  Envelope: C <= 32, D <= 192, W % 4 == 0, quad-aligned features, 32 H W < 2^30.
 template <typename TIN>
 int stereo_cross_attention_split(const TIN *left, const TIN *right, float *out, float *disp, int B, int C, int H, int W, int D,
                                  int mask_mode, float sc, hipStream_t st)
 {
+    // (32 H W < 2^30: the buffer resources address a 32-channel slab of a row with 32-bit BYTE offsets)
     if (C > 32 || D > 192 || D < 1 || W % 4 != 0 || !aligned_quad<TIN>(left) || !aligned_quad<TIN>(right) ||
-        (long long)32 * H * W >= (1LL << 31))
+        (long long)32 * H * W >= (1LL << 30))
         return STEREO_ERR_UNSUPPORTED;
     const int nt = (D + 31) / 32 + 1;
     // waves (32 queries each) per workgroup: 8 (256-query tiles; the band halo is loaded and split once per tile, so wide tiles

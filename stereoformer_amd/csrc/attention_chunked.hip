@@ -221,18 +221,14 @@ __global__ __launch_bounds__(NWV * 64, MINW) void cross_attention_chunked_kernel
         }
         // the V chunk's output rows leave AFTER the commit (whose vmcnt wait then covers loads only) and drain under the
         // next item's MFMAs
-        if (cj >= nck && wave_on && q < W) {      // channels past Cv fall outside the resource and are dropped
+        if (cj >= nck && wave_on && q < W) {
             const int hh = bh % H, bb = bh / H;
             const int c0 = 32 * (cj - nck);
-            const int nrow = Cv - c0 < 32 ? Cv - c0 : 32;
             float *ob = out + (((size_t)bb * Cv + c0) * HWu + (size_t)hh * W);
-            const __amdgpu_buffer_rsrc_t ro = buffer_rsrc(ob, ((unsigned)(nrow - 1) * HWu + (unsigned)W) * 4u);
-            int vo = (int)(((unsigned)(4 * half) * HWu + (unsigned)q) * 4u);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {        // accumulator row r -> channel (r & 3) + 8 (r >> 2) + 4 half
-                const float ov = o[r];            // (a bit_cast straight off the vector element reads element 0)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov), ro, vo, 0, 0);
-                vo += (int)(((r & 3) == 3 ? 5u : 1u) * HWu * 4u);
+            for (int r = 0; r < 16; ++r) {
+                const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (c0 + c < Cv) ob[(unsigned)c * HWu + (unsigned)q] = o[r];
             }
         }
         if (++cj == ipt) cj = 0, ++ct;
@@ -270,7 +266,7 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_chunked_split_kernel
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l31 = lane & 31, half = lane >> 5;
-    const unsigned HWu = (unsigned)H * (unsigned)W;
+    const unsigned HWu = (unsigned)H * (unsigned)W;  // launcher: 32 * H * W < 2^30 (32-bit byte offsets)
     const int nx = (W + TQW - 1) / TQW;
     const float sc2 = scale * 1.44269504088896340736f;
     const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
@@ -589,7 +585,9 @@ int stereo_cross_attention_chunked(const TIN *L, const TIN *R, const TIN *V, flo
         if (nwv == 5) CH(NTV, 5, 2); \
         CH(NTV, 4, 2);               \
     } while (0)
-    if (nt <= 5 && split_bf16_form) {  // bands of <= 128: split operands on the bf16 matrix cores
+    // bands of <= 128: split operands on the bf16 matrix cores (32 H W < 2^30: its buffer resources address a 32-channel slab
+    // of a row with 32-bit BYTE offsets)
+    if (nt <= 5 && split_bf16_form && (long long)32 * H * W < (1LL << 30)) {
         // wide tiles: the band halo is loaded and split once per tile (W = 312: 8 waves 0.151 / 0.182 ms at D = 64 / 128, 5
         // exact-fit waves 0.147 / 0.215)
         if (stereo_opt(OPT_ATT_WAVES) == 0) nwv = qt <= 4 ? 4 : (qt == 5 ? 5 : 8);

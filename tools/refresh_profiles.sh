@@ -5,12 +5,13 @@
 set -u
 R=${1:-r02}
 O=gpurun_out/refresh_$R
-mkdir -p $O profiles
+P=$O/profiles   # only gpurun_out/ travels back from the GPU box: copy $P/* into profiles/ afterwards
+mkdir -p $O $P
 # the bench line first, on a fresh box (after ~1 min of sustained convolution load the same launch runs ~8-15 % slower)
-timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err && cp $O/bench.json profiles/${R}_bench_line.json
+timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err && cp $O/bench.json $P/${R}_bench_line.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o run --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $O/bench_under_rocprof.log 2>&1
-cp $O/stats/run_kernel_stats.csv profiles/${R}_bench_kernel_stats.csv 2>/dev/null
-cp $O/bench_under_rocprof.log profiles/${R}_bench_under_rocprof.log 2>/dev/null
+cp $O/stats/run_kernel_stats.csv $P/${R}_bench_kernel_stats.csv 2>/dev/null
+cp $O/bench_under_rocprof.log $P/${R}_bench_under_rocprof.log 2>/dev/null
 for v in f32 f16; do
   X=""; [ $v = f16 ] && X="--fp16-features"
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_$v -o run --output-format csv -- python3 bench.py --no-cpu-baseline --no-other-configs --steps 3 --warmup 1 $X > $O/pmc_fetch_$v.log 2>&1
@@ -20,7 +21,7 @@ for v in f32 f16; do
 done
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/pmc_mfma -o run --output-format csv -- python3 tools/kernel_bench.py --only A7_ > $O/pmc_mfma_a7.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/pmc_mfma8 -o run --output-format csv -- python3 tools/kernel_bench.py --only A8_ > $O/pmc_mfma_a8.log 2>&1
-timeout -k 10 600 python3 tools/kernel_bench.py > $O/kernel_bench.log 2>&1 && cp gpurun_out/kernel_bench.json profiles/${R}_kernel_bench.json
+timeout -k 10 600 python3 tools/kernel_bench.py > $O/kernel_bench.log 2>&1 && cp gpurun_out/kernel_bench.json $P/${R}_kernel_bench.json
 python3 - $O $R <<'PY'
 import json, sys
 o, r = sys.argv[1], sys.argv[2]
@@ -35,8 +36,8 @@ for v, key in (("f32", "kernels"), ("f16", "kernels_fp16_features")):
         if e["hbm_read_bytes"] is not None and e["hbm_write_bytes"] is not None:
             e["hbm_bytes_per_launch"] = e["hbm_read_bytes"] + e["hbm_write_bytes"]
         out[key][k] = e
-json.dump(out, open("profiles/%s_pmc_traffic.json" % r, "w"), indent=1)
-json.dump(out, open("profiles/pmc_traffic_latest.json", "w"), indent=1)
+json.dump(out, open(o + "/profiles/%s_pmc_traffic.json" % r, "w"), indent=1)
+json.dump(out, open(o + "/profiles/pmc_traffic_latest.json", "w"), indent=1)
 PY
 python3 tools/pmc_summary.py $O/pmc_mfma cross_attention > $O/mfma7.json
 python3 tools/pmc_summary.py $O/pmc_mfma8 allpairs > $O/mfma8.json
@@ -47,6 +48,6 @@ k = json.load(open(o + "/mfma7.json")); k.update(json.load(open(o + "/mfma8.json
 json.dump({"source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES "
                      "SQ_BUSY_CYCLES on tools/kernel_bench.py --only A7_ / A8_ (own passes)",
            "note": "mfma_busy_fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)",
-           "kernels": k}, open("profiles/%s_pmc_mfma.json" % r, "w"), indent=1)
+           "kernels": k}, open(o + "/profiles/%s_pmc_mfma.json" % r, "w"), indent=1)
 PY
 cat $O/bench.json | cut -c1-600
