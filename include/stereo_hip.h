@@ -293,6 +293,13 @@ int stereo_allpairs_pyramid_f16(const void *fmap1, const void *fmap2, float *con
 long long stereo_instance_norm_workspace_bytes(int B, int C);
 int stereo_instance_norm_relu_f32(const float *x, const float *gamma, const float *beta, void *out, void *workspace,
                                   int out_is_f16, int B, int C, int H, int W, float eps, int relu, void *stream);
+/* The same with CHANNELS-LAST input: x is [B][H*W][C] (the memory of a torch.channels_last [B,C,H,W] tensor, which is how
+ * MIOpen's convolutions like to hand an extractor's activations over), fp32 (x_is_f16 = 0) or fp16 (1); out is NCHW as above,
+ * so the transpose in front of the cost-volume loaders rides on the normalisation's second read instead of being a pass of
+ * its own.  C % 4 == 0, C <= 256, 256 % (C / 4) == 0, H*W % 4 == 0, else STEREO_ERR_UNSUPPORTED. */
+int stereo_instance_norm_relu_nhwc(const void *x, int x_is_f16, const float *gamma, const float *beta, void *out,
+                                   void *workspace, int out_is_f16, int B, int C, int H, int W, float eps, int relu,
+                                   void *stream);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,7 @@ SIGNATURES = {
     "stereo_allpairs_pyramid_f16": [_vp, _vp, ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _i, _vp],
     "stereo_instance_norm_workspace_bytes": [_i, _i],
     "stereo_instance_norm_relu_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "stereo_instance_norm_relu_nhwc": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "stereo_soft_argmin_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_gwc_volume_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_local_lookup_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],

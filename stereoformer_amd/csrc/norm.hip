@@ -107,6 +107,106 @@ __global__ __launch_bounds__(IN_THREADS) void instance_norm_apply_kernel(const f
     }
 }
 
+// ---- channels-last input (what MIOpen's convolutions hand over when the extractor runs in torch.channels_last): x is
+// [B][H*W][C]; the output stays NCHW, so the transpose the cost-volume loaders would otherwise need as a pass of its own rides
+// on the normalisation's second read.  C % 4 == 0 and 256 % (C / 4) == 0 (C = 4 .. 256 in powers of two, or 12 .. ): a thread
+// keeps ONE channel quad for its whole chunk.
+constexpr int INH_PASSES = 64;  // pixels per thread and chunk in the statistics pass
+
+template <typename TIN>
+__global__ __launch_bounds__(IN_THREADS) void instance_norm_stats_nhwc_kernel(const TIN *__restrict__ x,
+                                                                               double *__restrict__ stats, int C, long long HW)
+{
+    extern __shared__ double acc[];  // [2][C]
+    const int b = blockIdx.y, CQ = C / 4, PP = IN_THREADS / CQ;
+    const int cq = threadIdx.x % CQ, pi = threadIdx.x / CQ;
+    for (int i = threadIdx.x; i < 2 * C; i += IN_THREADS) acc[i] = 0.0;
+    __syncthreads();
+    const TIN *xb = x + (size_t)b * HW * C + 4 * cq;
+    const long long p0 = (long long)blockIdx.x * PP * INH_PASSES + pi;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int k = 0; k < INH_PASSES; ++k) {
+        const long long p = p0 + (long long)k * PP;
+        if (p < HW) {
+            const f32x4 v = Quad<TIN>::widen(Quad<TIN>::ld(xb + p * C));
+            s += v;
+            ss += v * v;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        atomicAdd(&acc[4 * cq + i], (double)s[i]);
+        atomicAdd(&acc[C + 4 * cq + i], (double)ss[i]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += IN_THREADS) {
+        const int c = i % C, which = i / C;
+        atomicAdd(stats + 2 * ((size_t)b * C + c) + which, acc[i]);
+    }
+}
+
+template <typename TIN, typename TOUT, int TP>
+__global__ __launch_bounds__(IN_THREADS) void instance_norm_apply_nhwc_kernel(const TIN *__restrict__ x,
+                                                                               const double *__restrict__ stats,
+                                                                               const float *__restrict__ gamma,
+                                                                               const float *__restrict__ beta,
+                                                                               TOUT *__restrict__ out, int C, long long HW,
+                                                                               float eps, int relu)
+{
+    extern __shared__ float tile[];  // [C][TP + 1] + g[C] + sh[C]
+    float *gs = tile + (size_t)C * (TP + 1), *shs = gs + C;
+    const int b = blockIdx.y, CQ = C / 4;
+    for (int c = threadIdx.x; c < C; c += IN_THREADS) {
+        const size_t plane = (size_t)b * C + c;
+        const double mean = stats[2 * plane] / (double)HW;
+        double var = stats[2 * plane + 1] / (double)HW - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[c] * rstd : rstd;
+        gs[c] = g;
+        shs[c] = (beta ? beta[c] : 0.0f) - (float)mean * g;
+    }
+    __syncthreads();
+    const long long p0 = (long long)blockIdx.x * TP;
+    const float lo = relu ? 0.0f : -INFINITY;
+    const TIN *xb = x + ((size_t)b * HW + p0) * C;
+    for (int idx = threadIdx.x; idx < TP * CQ; idx += IN_THREADS) {   // coalesced along the channels of consecutive pixels
+        const int p = idx / CQ, cq = idx % CQ;
+        if (p0 + p < HW) {
+            const f32x4 v = Quad<TIN>::widen(Quad<TIN>::ld(xb + (size_t)p * C + 4 * cq));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                tile[(4 * cq + i) * (TP + 1) + p] = fmaxf(fmaf(v[i], gs[4 * cq + i], shs[4 * cq + i]), lo);
+        }
+    }
+    __syncthreads();
+    TOUT *ob = out + (size_t)b * C * HW + p0;
+    for (int idx = threadIdx.x; idx < C * (TP / 4); idx += IN_THREADS) {  // rows of TP pixels per channel
+        const int c = idx / (TP / 4), pq = idx % (TP / 4);
+        if (p0 + 4 * pq + 3 < HW) {
+            const float *t = tile + c * (TP + 1) + 4 * pq;
+            store_quad<TOUT>(ob + (size_t)c * HW + 4 * pq, (f32x4){t[0], t[1], t[2], t[3]});
+        }
+    }
+}
+
+template <typename TIN, typename TOUT>
+int launch_nhwc(const TIN *x, const double *stats, const float *gamma, const float *beta, TOUT *out, int B, int C, long long HW,
+                float eps, int relu, hipStream_t st)
+{
+#define APPLY(TPV)                                                                                                         \
+    hipLaunchKernelGGL((instance_norm_apply_nhwc_kernel<TIN, TOUT, TPV>), dim3((unsigned)((HW + TPV - 1) / TPV), (unsigned)B), \
+                       dim3(IN_THREADS), ((size_t)C * (TPV + 1) + 2 * (size_t)C) * sizeof(float), st, x, stats, gamma, beta, out, \
+                       C, HW, eps, relu)
+    if (C <= 64) APPLY(128);
+    else if (C <= 128) APPLY(64);
+    else APPLY(32);
+#undef APPLY
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
 }  // namespace
 
 extern "C" long long stereo_instance_norm_workspace_bytes(int B, int C)
@@ -144,4 +244,43 @@ extern "C" int stereo_instance_norm_relu_f32(const float *x, const float *gamma,
                            static_cast<float *>(out), C, HW, eps, relu);
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
+}
+
+extern "C" int stereo_instance_norm_relu_nhwc(const void *x, int x_is_f16, const float *gamma, const float *beta, void *out,
+                                              void *workspace, int out_is_f16, int B, int C, int H, int W, float eps, int relu,
+                                              void *stream)
+{
+    if (B < 0 || C < 0 || H < 0 || W < 0 || !(eps >= 0.0f)) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || C == 0 || H == 0 || W == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(x);
+    STEREO_REQUIRE_PTR(out);
+    STEREO_REQUIRE_PTR(workspace);
+    const long long HW = (long long)H * W;
+    const uintptr_t xa = x_is_f16 ? 7u : 15u;
+    if (C % 4 != 0 || C > 256 || IN_THREADS % (C / 4) != 0 || HW % 4 != 0 || !fits_grid_yz(B) ||
+        (reinterpret_cast<uintptr_t>(x) & xa) != 0 || (reinterpret_cast<uintptr_t>(workspace) & 7u) != 0 ||
+        (out_is_f16 ? (reinterpret_cast<uintptr_t>(out) & 7u) != 0 : !aligned16(out)) || HW / 32 >= (1LL << 31))
+        return STEREO_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    double *stats = static_cast<double *>(workspace);
+    if (hipMemsetAsync(stats, 0, (size_t)B * C * 2 * sizeof(double), st) != hipSuccess) return STEREO_ERR_LAUNCH;
+    const long long per_wg = (long long)(IN_THREADS / (C / 4)) * INH_PASSES;  // pixels per statistics workgroup
+    dim3 sgrid((unsigned)((HW + per_wg - 1) / per_wg), (unsigned)B);
+    const size_t slds = (size_t)2 * C * sizeof(double);
+    if (x_is_f16)
+        hipLaunchKernelGGL(instance_norm_stats_nhwc_kernel<f16>, sgrid, dim3(IN_THREADS), slds, st, static_cast<const f16 *>(x),
+                           stats, C, HW);
+    else
+        hipLaunchKernelGGL(instance_norm_stats_nhwc_kernel<float>, sgrid, dim3(IN_THREADS), slds, st,
+                           static_cast<const float *>(x), stats, C, HW);
+    STEREO_LAUNCH_CHECK();
+    if (x_is_f16)
+        return out_is_f16 ? launch_nhwc<f16, f16>(static_cast<const f16 *>(x), stats, gamma, beta, static_cast<f16 *>(out), B, C,
+                                                  HW, eps, relu, st)
+                          : launch_nhwc<f16, float>(static_cast<const f16 *>(x), stats, gamma, beta, static_cast<float *>(out),
+                                                    B, C, HW, eps, relu, st);
+    return out_is_f16 ? launch_nhwc<float, f16>(static_cast<const float *>(x), stats, gamma, beta, static_cast<f16 *>(out), B, C,
+                                                HW, eps, relu, st)
+                      : launch_nhwc<float, float>(static_cast<const float *>(x), stats, gamma, beta, static_cast<float *>(out),
+                                                  B, C, HW, eps, relu, st);
 }

@@ -15,14 +15,33 @@ import torch.nn as nn
 from . import _native as N
 
 
+def _channels_last_operand(x):
+    """True when ``x`` can go to the channels-last kernel as it is: a HIP [B,C,H,W] tensor in torch.channels_last memory (and
+    not also NCHW-contiguous), fp32 or fp16, C a multiple of 4 with 256 % (C / 4) == 0, C <= 256, H*W a multiple of 4."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.float16)):
+        return False
+    if torch.is_grad_enabled() and x.requires_grad:
+        return False
+    if x.is_contiguous() or not x.is_contiguous(memory_format=torch.channels_last):
+        return False
+    C, hw = x.shape[1], x.shape[2] * x.shape[3]
+    return C % 4 == 0 and C <= 256 and 256 % (C // 4) == 0 and hw % 4 == 0
+
+
 def instance_norm_relu(x, weight=None, bias=None, eps=1e-5, relu=True, out_dtype=torch.float16):
     """``relu(F.instance_norm(x, weight=weight, bias=bias, eps=eps))`` -> ``out_dtype`` (fp16 or fp32), NCHW.
+    A ``torch.channels_last`` input (fp32 or fp16 -- what MIOpen's convolutions hand over) is read in place: the transpose to
+    the NCHW layout of the cost-volume loaders happens inside the normalisation's second pass.
     Forward-only (the extractor is out of scope for training parity): raises under grad like the other forward-only ops."""
-    x = N.dev_f32(x, "instance_norm_relu: x")
-    if x.dim() != 4:
-        raise ValueError("instance_norm_relu: expected [B,C,H,W]")
     if out_dtype not in (torch.float16, torch.float32):
         raise TypeError("instance_norm_relu: out_dtype must be torch.float16 or torch.float32")
+    nhwc = _channels_last_operand(x)
+    if not nhwc:
+        if isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float16:
+            x = x.float()   # fp16 activations outside the channels-last kernel's envelope: widened (one extra pass)
+        x = N.dev_f32(x, "instance_norm_relu: x")
+    if x.dim() != 4:
+        raise ValueError("instance_norm_relu: expected [B,C,H,W]")
     B, C, H, W = x.shape
     w = None if weight is None else N.dev_f32(weight, "instance_norm_relu: weight")
     b = None if bias is None else N.dev_f32(bias, "instance_norm_relu: bias")
@@ -33,6 +52,11 @@ def instance_norm_relu(x, weight=None, bias=None, eps=1e-5, relu=True, out_dtype
     ws = torch.empty(max(1, lib.stereo_instance_norm_workspace_bytes(B, C) // 8), device=x.device, dtype=torch.float64)
     with torch.cuda.device(x.device):
         try:
+            if nhwc:   # channels-last activations (fp32 / fp16) straight from the convolution: no .contiguous() pass
+                N.call("stereo_instance_norm_relu_nhwc", N.ptr(x), 1 if x.dtype == torch.float16 else 0, N.ptr(w), N.ptr(b),
+                       N.ptr(out), N.ptr(ws), 1 if out_dtype == torch.float16 else 0, B, C, H, W, float(eps), 1 if relu else 0,
+                       N.stream_ptr(x.device))
+                return out
             N.call("stereo_instance_norm_relu_f32", N.ptr(x), N.ptr(w), N.ptr(b), N.ptr(out), N.ptr(ws),
                    1 if out_dtype == torch.float16 else 0, B, C, H, W, float(eps), 1 if relu else 0, N.stream_ptr(x.device))
         except N.StereoHipError as e:

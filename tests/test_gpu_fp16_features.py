@@ -238,3 +238,34 @@ def test_corr_volume_channel_chunked(S, oracle, shape, half):
             disp_close(d, oracle.soft_argmin(ref, sim), D)
     with S._native.test_options(corr_mfma=0):        # the VALU kernel it replaces at these shapes
         close(S.CostVolume(D)(Ld.float(), Rd.float()), ref, **VOL_TOL)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 12, 40), (1, 64, 135, 244), (2, 128, 9, 36), (1, 256, 5, 16), (1, 4, 3, 8), (1, 48, 6, 10)])
+def test_instance_norm_relu_channels_last_input(S, oracle, shape):
+    """N2, channels-last hand-over: a torch.channels_last activation (fp32 or fp16) is normalised and written NCHW in one op
+    (no .contiguous() pass): equal to the oracle on the same values; equal to the NCHW kernel's fp16 output up to the last
+    fp32 bit of the statistics (<= 1 fp16 ulp); affine, no-ReLU and the unsupported-C fallback."""
+    from stereoformer_amd import extractor_epilogue as E
+    rng = np.random.default_rng(77)
+    B, C, H, W = shape
+    x = (rng.standard_normal(shape, dtype=np.float32) * 1.5 + 0.7).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    xcl = xt.contiguous(memory_format=torch.channels_last)
+    assert E._channels_last_operand(xcl) == (C % 4 == 0 and 256 % (C // 4) == 0 and not xcl.is_contiguous())
+    ref = oracle.instance_norm_relu(x)
+    o32 = S.instance_norm_relu(xcl, out_dtype=torch.float32)
+    assert o32.is_contiguous() and o32.shape == xt.shape
+    close(o32, ref, rtol=1e-4, atol=2e-5)
+    o16 = S.instance_norm_relu(xcl)
+    assert o16.dtype == torch.float16 and o16.is_contiguous()
+    close(o16.float(), ref, rtol=2e-3, atol=1e-3)
+    assert (o16.float() - S.instance_norm_relu(xt).float()).abs().max().item() <= 2e-3   # vs the NCHW kernel
+    # fp16 activations (autocast extractor): the oracle on the rounded values
+    xh = xcl.half()
+    assert xh.is_contiguous(memory_format=torch.channels_last)
+    close(S.instance_norm_relu(xh, out_dtype=torch.float32), oracle.instance_norm_relu(xh.float().cpu().numpy()), rtol=1e-4, atol=2e-5)
+    # affine, no ReLU
+    g = rng.standard_normal(C).astype(np.float32)
+    bt = rng.standard_normal(C).astype(np.float32)
+    close(S.instance_norm_relu(xcl, torch.from_numpy(g).cuda(), torch.from_numpy(bt).cuda(), eps=1e-3, relu=False, out_dtype=torch.float32),
+          oracle.instance_norm_relu(x, g, bt, eps=1e-3, relu=False), rtol=1e-4, atol=5e-5)

@@ -169,6 +169,12 @@ def main():
                 (N * C * (4 + 4 + 2)) / 1e9, note="two reads of x (statistics, apply) + one fp16 write")
             add("N2 instance_norm_relu [8,32,540,960] -> fp32", timeit(lambda: S.instance_norm_relu(raw, out_dtype=torch.float32), args.reps),
                 (N * C * (4 + 4 + 4)) / 1e9)
+            rawcl = raw.contiguous(memory_format=torch.channels_last)
+            add("N2 instance_norm_relu [8,32,540,960] channels-last in -> NCHW fp16", timeit(lambda: S.instance_norm_relu(rawcl), args.reps),
+                (N * C * (4 + 4 + 2)) / 1e9, note="the layout change rides on the second read (no transpose pass)")
+            add("N2 [for comparison] .contiguous() of the channels-last tensor alone", timeit(lambda: rawcl.contiguous(), args.reps),
+                (N * C * (4 + 4)) / 1e9)
+            del rawcl
             del Lh, Rh, raw
             f1h, f2h = f1.half(), f2.half()
             pyr_b = Br * Hr * Wr * (Wr + Wr // 2 + Wr // 4 + Wr // 8 + Wr // 16) * 4
