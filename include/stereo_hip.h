@@ -301,6 +301,12 @@ int stereo_instance_norm_relu_nhwc(const void *x, int x_is_f16, const float *gam
                                    void *workspace, int out_is_f16, int B, int C, int H, int W, float eps, int relu,
                                    void *stream);
 
+/* Channels-last -> NCHW relayout of a feature tensor, x [B][H*W][C] fp32 / fp16 -> out [B,C,H,W] fp32 / fp16 (widening or
+ * rounding once if the two differ): for an extractor that ends in a plain convolution (raft_stereo.py's fnet, extractor.py:201)
+ * and runs in torch.channels_last.  C % 4 == 0, C <= 256, H*W % 4 == 0, else STEREO_ERR_UNSUPPORTED. */
+int stereo_relayout_nhwc_to_nchw(const void *x, int x_is_f16, void *out, int out_is_f16, int B, int C, int H, int W,
+                                 void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -158,6 +158,11 @@ __global__ __launch_bounds__(IN_THREADS) void instance_norm_apply_nhwc_kernel(co
     float *gs = tile + (size_t)C * (TP + 1), *shs = gs + C;
     const int b = blockIdx.y, CQ = C / 4;
     for (int c = threadIdx.x; c < C; c += IN_THREADS) {
+        if (stats == nullptr) {  // plain relayout (stereo_relayout_nhwc_to_nchw): y = x
+            gs[c] = 1.0f;
+            shs[c] = 0.0f;
+            continue;
+        }
         const size_t plane = (size_t)b * C + c;
         const double mean = stats[2 * plane] / (double)HW;
         double var = stats[2 * plane + 1] / (double)HW - mean * mean;
@@ -283,4 +288,30 @@ extern "C" int stereo_instance_norm_relu_nhwc(const void *x, int x_is_f16, const
                                                 HW, eps, relu, st)
                       : launch_nhwc<float, float>(static_cast<const float *>(x), stats, gamma, beta, static_cast<float *>(out),
                                                   B, C, HW, eps, relu, st);
+}
+
+/* NHWC -> NCHW relayout of a feature tensor (the apply pass above with the identity map): what a channels-last extractor
+ * output needs in front of the cost-volume loaders when no normalisation closes the stage (raft_stereo's fnet ends in a
+ * plain 1x1 convolution). */
+extern "C" int stereo_relayout_nhwc_to_nchw(const void *x, int x_is_f16, void *out, int out_is_f16, int B, int C, int H, int W,
+                                            void *stream)
+{
+    if (B < 0 || C < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || C == 0 || H == 0 || W == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(x);
+    STEREO_REQUIRE_PTR(out);
+    const long long HW = (long long)H * W;
+    if (C % 4 != 0 || C > 256 || HW % 4 != 0 || !fits_grid_yz(B) || (reinterpret_cast<uintptr_t>(x) & (x_is_f16 ? 7u : 15u)) != 0 ||
+        (out_is_f16 ? (reinterpret_cast<uintptr_t>(out) & 7u) != 0 : !aligned16(out)) || HW / 32 >= (1LL << 31))
+        return STEREO_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    if (x_is_f16)
+        return out_is_f16 ? launch_nhwc<f16, f16>(static_cast<const f16 *>(x), nullptr, nullptr, nullptr, static_cast<f16 *>(out),
+                                                  B, C, HW, 0.0f, 0, st)
+                          : launch_nhwc<f16, float>(static_cast<const f16 *>(x), nullptr, nullptr, nullptr,
+                                                    static_cast<float *>(out), B, C, HW, 0.0f, 0, st);
+    return out_is_f16 ? launch_nhwc<float, f16>(static_cast<const float *>(x), nullptr, nullptr, nullptr, static_cast<f16 *>(out),
+                                                B, C, HW, 0.0f, 0, st)
+                      : launch_nhwc<float, float>(static_cast<const float *>(x), nullptr, nullptr, nullptr,
+                                                  static_cast<float *>(out), B, C, HW, 0.0f, 0, st);
 }

@@ -269,3 +269,29 @@ def test_instance_norm_relu_channels_last_input(S, oracle, shape):
     bt = rng.standard_normal(C).astype(np.float32)
     close(S.instance_norm_relu(xcl, torch.from_numpy(g).cuda(), torch.from_numpy(bt).cuda(), eps=1e-3, relu=False, out_dtype=torch.float32),
           oracle.instance_norm_relu(x, g, bt, eps=1e-3, relu=False), rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_channels_last_features_take_the_relayout_kernel(S, dtype):
+    """Channels-last feature tensors (an extractor running in torch.channels_last that ends in a plain convolution) are brought
+    to NCHW by the library's relayout kernel: bit-identical to the NCHW tensor, and every feature-consuming surface gives the
+    same numbers for both layouts; shapes outside the kernel's envelope (C % 4 != 0, ragged H*W) take contiguous()."""
+    from stereoformer_amd import _native as N
+    torch.manual_seed(78)
+    for shape in ((2, 32, 6, 40), (1, 256, 5, 16), (1, 8, 3, 12), (1, 6, 3, 12), (1, 8, 3, 5)):
+        x = torch.randn(*shape, device="cuda").to(dtype)
+        xcl = x.contiguous(memory_format=torch.channels_last)
+        y = N.nchw(xcl)
+        assert y.is_contiguous() and y.dtype == dtype and torch.equal(y, x)
+        assert N.nchw(x) is x
+    L = torch.randn(2, 32, 6, 40, device="cuda").to(dtype)
+    R = torch.randn(2, 32, 6, 40, device="cuda").to(dtype)
+    Lc, Rc = (t.contiguous(memory_format=torch.channels_last) for t in (L, R))
+    with torch.no_grad():
+        assert torch.equal(S.CostVolume(12)(Lc, Rc), S.CostVolume(12)(L, R))
+        a, b = S.build_gwc_volume_with_disparity(Lc, Rc, 12, 8), S.build_gwc_volume_with_disparity(L, R, 12, 8)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        a, b = S.CrossAttentionCostVolume(12)(Lc, Rc), S.CrossAttentionCostVolume(12)(L, R)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        for la, lb in zip(S.CorrBlock1D(Lc, Rc, 2, 2).corr_pyramid, S.CorrBlock1D(L, R, 2, 2).corr_pyramid):
+            assert torch.equal(la, lb)

@@ -174,6 +174,8 @@ def main():
                 (N * C * (4 + 4 + 2)) / 1e9, note="the layout change rides on the second read (no transpose pass)")
             add("N2 [for comparison] .contiguous() of the channels-last tensor alone", timeit(lambda: rawcl.contiguous(), args.reps),
                 (N * C * (4 + 4)) / 1e9)
+            add("N2 relayout channels-last -> NCHW [8,32,540,960] fp32 (N.nchw)", timeit(lambda: S._native.nchw(rawcl), args.reps),
+                (N * C * (4 + 4)) / 1e9)
             del rawcl
             del Lh, Rh, raw
             f1h, f2h = f1.half(), f2.half()
