@@ -307,6 +307,22 @@ int stereo_instance_norm_relu_nhwc(const void *x, int x_is_f16, const float *gam
 int stereo_relayout_nhwc_to_nchw(const void *x, int x_is_f16, void *out, int out_is_f16, int B, int C, int H, int W,
                                  void *stream);
 
+/* A14's convolutions (update/update.py:6-33,66-91,130-178: nn.Conv2d, stride 1, "same" padding, 3x3 or 1x1) over
+ * channels-last fp32 activations, on the bf16 matrix cores with split operands (fp32-faithful: every operand is hi + mid + lo
+ * exactly, six piece products per fp32 product, fp32 accumulation).
+ *   stereo_conv_pack_weights: weight [Cout][Cin][k][k] fp32 (nn.Conv2d.weight, contiguous) -> `packed`
+ *       (stereo_conv_packed_bytes(Cout, Cin, k) bytes, 16-byte aligned), once per weight tensor.  Cin % 16 == 0.
+ *   stereo_conv_nhwc_f32: the K dimension runs over `nsrc` (<= 4) source tensors [B][H][W][src_channels[i]] in concatenation
+ *       order (= conv(torch.cat(srcs, 1)) without the concatenation; every src_channels[i] % 16 == 0); output channels go, in
+ *       order, to `nout` destination tensors [B][H][W][out_channels[j]] (every out_channels[j] but the last a multiple of 128;
+ *       at most 512 output channels in all): out = conv + bias (bias [sum out_channels] or NULL), ReLU if `relu`.
+ *   A source image must stay below 2 GB (H*W*C*4 < 2^31), else STEREO_ERR_UNSUPPORTED. */
+long long stereo_conv_packed_bytes(int Cout, int Cin, int ksize);
+int stereo_conv_pack_weights(const float *weight, void *packed, int Cout, int Cin, int ksize, void *stream);
+int stereo_conv_nhwc_f32(const float *const *srcs, const int *src_channels, int nsrc, const void *packed, const float *bias,
+                         float *const *outs, const int *out_channels, int nout, int ksize, int relu, int B, int H, int W,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,103 @@
+"""Stride-1 "same" convolutions of the update block (A14, ``update/update.py:6-33,66-91,130-178``) on the HIP path.
+
+``conv_nhwc(srcs, convs, relu)`` is ``[m(torch.cat(srcs, 1)) for m in convs]`` (each ``m`` an ``nn.Conv2d`` with a 3x3 or 1x1
+kernel, stride 1, padding k // 2, the same input) for channels-last fp32 activations, as ONE launch of
+``csrc/conv_split.hip``: the concatenation is never materialised (the kernel's K loop walks the sources), the bias and an
+optional ReLU ride in the epilogue, and several modules that read the same input (``convz`` | ``convr``; ``flow_head.conv1`` |
+``mask[0]``) run as one convolution whose output channels are scattered to one tensor per module.  Arithmetic: fp32-faithful
+split-bf16 on ``v_mfma_f32_32x32x16_bf16`` (see the kernel's header).
+
+Inference only (no autograd formula: the training path keeps the library convolutions); ``supported(...)`` tells a caller whether
+its tensors are inside the kernel's envelope."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _native as N
+
+_PACKED: dict = {}
+
+
+def _is_cl(t):
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def supported(srcs, convs) -> bool:
+    """Channels-last fp32 HIP tensors without grad, every source channel count a multiple of 16 (<= 4 sources), 3x3 / 1x1 stride-1
+    'same' convolutions without groups or dilation, all but the last module with a multiple of 128 output channels, <= 512 in
+    all."""
+    if torch.is_grad_enabled() and any(t.requires_grad for t in srcs):
+        return False
+    if not (1 <= len(srcs) <= 4) or not convs:
+        return False
+    t0 = srcs[0]
+    for t in srcs:
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and _is_cl(t)):
+            return False
+        if t.shape[0] != t0.shape[0] or t.shape[2:] != t0.shape[2:] or t.shape[1] % 16 != 0 or t.shape[1] < 16:
+            return False
+        if t.shape[1] * t.shape[2] * t.shape[3] * 4 >= 2 ** 31:
+            return False
+    cin = sum(t.shape[1] for t in srcs)
+    k = convs[0].kernel_size
+    total = 0
+    for i, m in enumerate(convs):
+        if not isinstance(m, torch.nn.Conv2d) or m.kernel_size != k or k not in ((3, 3), (1, 1)):
+            return False
+        if m.stride != (1, 1) or m.dilation != (1, 1) or m.groups != 1 or m.padding != (k[0] // 2, k[0] // 2):
+            return False
+        if m.in_channels != cin or m.weight.dtype != torch.float32 or m.padding_mode != "zeros":
+            return False
+        if i + 1 < len(convs) and m.out_channels % 128 != 0:
+            return False
+        total += m.out_channels
+    return total <= 512
+
+
+def _packed(convs, device):
+    """Packed split-bf16 weights (+ the concatenated bias) of a group of modules; rebuilt when a weight changes in place."""
+    key = tuple((m.weight.data_ptr(), m.weight._version, None if m.bias is None else (m.bias.data_ptr(), m.bias._version))
+                for m in convs) + (device.index,)
+    hit = _PACKED.get(key)
+    if hit is not None:
+        return hit
+    with torch.no_grad():
+        w = torch.cat([m.weight.detach().contiguous() for m in convs], 0).contiguous()
+        bias = None
+        if any(m.bias is not None for m in convs):
+            bias = torch.cat([m.bias.detach() if m.bias is not None else torch.zeros(m.out_channels, device=device)
+                              for m in convs]).contiguous()
+        cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+        nbytes = N.load().stereo_conv_packed_bytes(cout, cin, k)
+        if nbytes <= 0:
+            raise ValueError(f"conv_nhwc: unsupported weight shape {tuple(w.shape)}")
+        packed = torch.empty(nbytes, device=device, dtype=torch.uint8)
+        with torch.cuda.device(device):
+            N.call("stereo_conv_pack_weights", N.ptr(w), N.ptr(packed), cout, cin, k, N.stream_ptr(device))
+    if len(_PACKED) > 256:          # stale entries of weights that were updated or freed
+        _PACKED.clear()
+    _PACKED[key] = (packed, bias, k)
+    return _PACKED[key]
+
+
+def conv_nhwc(srcs, convs, relu=False):
+    """``[m(torch.cat(srcs, 1)) for m in convs]`` (optionally followed by ReLU), channels-last fp32 in and out, one launch."""
+    srcs = list(srcs)
+    convs = list(convs)
+    if not supported(srcs, convs):
+        raise ValueError("conv_nhwc: operands outside the kernel's envelope (see conv_split.supported)")
+    dev = srcs[0].device
+    packed, bias, k = _packed(convs, dev)
+    B, _, H, W = srcs[0].shape
+    outs = [torch.empty((B, m.out_channels, H, W), device=dev, dtype=torch.float32, memory_format=torch.channels_last)
+            for m in convs]
+    sp = (N._vp * len(srcs))(*[t.data_ptr() for t in srcs])
+    sc = (N._i * len(srcs))(*[t.shape[1] for t in srcs])
+    op = (N._vp * len(outs))(*[t.data_ptr() for t in outs])
+    oc = (N._i * len(outs))(*[t.shape[1] for t in outs])
+    with torch.cuda.device(dev):
+        N.call("stereo_conv_nhwc_f32", sp, sc, len(srcs), N.ptr(packed), N.ptr(bias), op, oc, len(outs), k, 1 if relu else 0,
+               B, H, W, N.stream_ptr(dev))
+    return outs

@@ -1,0 +1,24 @@
+"""dev: split-bf16 convolution kernel vs MIOpen fp32 at the update block's shapes.   python tools/conv_ab.py"""
+import os, sys, torch, torch.nn as nn
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import stereoformer_amd as S
+from stereoformer_amd import conv_split as C
+from tools.kernel_bench import timeit
+cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+for (nm, B, H, W, cs, co, relu) in (("gru08 convz|convr [8,384,136,240] -> 128+128", 8, 136, 240, (128, 128, 128), (128, 128), False),
+                                    ("gru08 convq 384 -> 128", 8, 136, 240, (128, 128, 128), (128,), False),
+                                    ("flow_head.conv1|mask[0] 128 -> 256+256", 8, 136, 240, (128,), (256, 256), True),
+                                    ("encoder.conv 128 -> 126", 8, 136, 240, (64, 64), (126,), True),
+                                    ("encoder.convc2 64 -> 64", 8, 136, 240, (64,), (64,), True),
+                                    ("gru16 convz|convr [8,384,68,120]", 8, 68, 120, (128, 128, 128), (128, 128), False),
+                                    ("gru32 convz|convr [8,256,34,60]", 8, 34, 60, (128, 128), (128, 128), False)):
+    srcs = [cl(torch.randn(B, c, H, W, device="cuda")) for c in cs]
+    convs = [nn.Conv2d(sum(cs), c, 3, padding=1).cuda().to(memory_format=torch.channels_last) for c in co]
+    gf = 2 * B * H * W * sum(cs) * sum(co) * 9 / 1e9
+    with torch.no_grad():
+        ms = timeit(lambda: C.conv_nhwc(srcs, convs, relu=relu), 10, 3)
+        x = torch.cat(srcs, 1)
+        ms_lib = timeit(lambda: [m(x) for m in convs], 10, 3)
+        ms_lib_all = timeit(lambda: [torch.relu(m(torch.cat(srcs, 1))) if relu else m(torch.cat(srcs, 1)) for m in convs], 10, 3)
+    print(f"{nm}: split {ms:.3f} ms = {gf / ms:.0f} TFLOP/s fp32-equivalent | MIOpen convs alone {ms_lib:.3f} ms = {gf / ms_lib:.0f} | "
+          f"MIOpen + cat (+ relu) {ms_lib_all:.3f} ms", flush=True)
