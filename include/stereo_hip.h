@@ -165,6 +165,10 @@ int stereo_upsample_convex_f32(const float *disp, const float *mask, float *out,
  * out = scale * interp(in) */
 int stereo_resize_bilinear_f32(const float *in, float *out, int NC, int Hi, int Wi, int Ho, int Wo,
                                int align_corners, float scale, void *stream);
+/* The same on channels-last tensors: in [N][Hi][Wi][C] -> out [N][Ho][Wo][C], C % 4 == 0 (the update block's `interp` when the
+ * block runs in torch.channels_last, update.py:125-127). */
+int stereo_resize_bilinear_nhwc_f32(const float *in, float *out, int N, int C, int Hi, int Wi, int Ho, int Wo,
+                                    int align_corners, float scale, void *stream);
 
 /* A7  epipolar cross-attention (build-defined; reference file is empty:
  *     models/CrossAttentionCostVolume/cross_attention_cost_volume.py)
@@ -316,12 +320,14 @@ int stereo_relayout_nhwc_to_nchw(const void *x, int x_is_f16, void *out, int out
  *       order (= conv(torch.cat(srcs, 1)) without the concatenation; every src_channels[i] % 16 == 0); output channels go, in
  *       order, to `nout` destination tensors [B][H][W][out_channels[j]] (every out_channels[j] but the last a multiple of 128;
  *       at most 512 output channels in all): out = conv + bias (bias [sum out_channels] or NULL), ReLU if `relu`.
+ *       out_strides[j] (NULL: = out_channels[j]) is the channel count of destination j's pixels when the convolution fills
+ *       only its first out_channels[j] channels (the motion encoder's 126 + 2 layout, update.py:89-91).
  *   A source image must stay below 2 GB (H*W*C*4 < 2^31), else STEREO_ERR_UNSUPPORTED. */
 long long stereo_conv_packed_bytes(int Cout, int Cin, int ksize);
 int stereo_conv_pack_weights(const float *weight, void *packed, int Cout, int Cin, int ksize, void *stream);
 int stereo_conv_nhwc_f32(const float *const *srcs, const int *src_channels, int nsrc, const void *packed, const float *bias,
-                         float *const *outs, const int *out_channels, int nout, int ksize, int relu, int B, int H, int W,
-                         void *stream);
+                         float *const *outs, const int *out_channels, const int *out_strides, int nout, int ksize, int relu,
+                         int B, int H, int W, void *stream);
 
 #ifdef __cplusplus
 }

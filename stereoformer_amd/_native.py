@@ -49,6 +49,7 @@ SIGNATURES = {
     "stereo_disp_warp_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_upsample_convex_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_resize_bilinear_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "stereo_resize_bilinear_nhwc_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
     "stereo_cross_attention_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_cross_attention_f16": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_corr_volume_f16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -63,8 +64,8 @@ SIGNATURES = {
     "stereo_relayout_nhwc_to_nchw": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_conv_packed_bytes": [_i, _i, _i],
     "stereo_conv_pack_weights": [_vp, _vp, _i, _i, _i, _vp],
-    "stereo_conv_nhwc_f32": [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _i,
-                             _i, _i, _i, _i, _vp],
+    "stereo_conv_nhwc_f32": [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_i),
+                             ctypes.POINTER(_i), _i, _i, _i, _i, _i, _i, _vp],
     "stereo_soft_argmin_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_gwc_volume_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_local_lookup_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],

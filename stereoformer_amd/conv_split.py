@@ -82,22 +82,27 @@ def _packed(convs, device):
     return _PACKED[key]
 
 
-def conv_nhwc(srcs, convs, relu=False):
-    """``[m(torch.cat(srcs, 1)) for m in convs]`` (optionally followed by ReLU), channels-last fp32 in and out, one launch."""
+def conv_nhwc(srcs, convs, relu=False, out_channels_total=None):
+    """``[m(torch.cat(srcs, 1)) for m in convs]`` (optionally followed by ReLU), channels-last fp32 in and out, one launch.
+    ``out_channels_total`` (single module only): allocate the output with that many channels and fill the first
+    ``out_channels`` of them -- the caller owns the rest (the motion encoder appends the 2 flow channels, update.py:89-91)."""
     srcs = list(srcs)
     convs = list(convs)
     if not supported(srcs, convs):
         raise ValueError("conv_nhwc: operands outside the kernel's envelope (see conv_split.supported)")
+    if out_channels_total is not None and (len(convs) != 1 or out_channels_total < convs[0].out_channels):
+        raise ValueError("conv_nhwc: out_channels_total applies to one module and must cover its output channels")
     dev = srcs[0].device
     packed, bias, k = _packed(convs, dev)
     B, _, H, W = srcs[0].shape
-    outs = [torch.empty((B, m.out_channels, H, W), device=dev, dtype=torch.float32, memory_format=torch.channels_last)
-            for m in convs]
+    widths = [m.out_channels for m in convs] if out_channels_total is None else [int(out_channels_total)]
+    outs = [torch.empty((B, c, H, W), device=dev, dtype=torch.float32, memory_format=torch.channels_last) for c in widths]
     sp = (N._vp * len(srcs))(*[t.data_ptr() for t in srcs])
     sc = (N._i * len(srcs))(*[t.shape[1] for t in srcs])
     op = (N._vp * len(outs))(*[t.data_ptr() for t in outs])
-    oc = (N._i * len(outs))(*[t.shape[1] for t in outs])
+    oc = (N._i * len(outs))(*[m.out_channels for m in convs])
+    os_ = (N._i * len(outs))(*widths)
     with torch.cuda.device(dev):
-        N.call("stereo_conv_nhwc_f32", sp, sc, len(srcs), N.ptr(packed), N.ptr(bias), op, oc, len(outs), k, 1 if relu else 0,
-               B, H, W, N.stream_ptr(dev))
+        N.call("stereo_conv_nhwc_f32", sp, sc, len(srcs), N.ptr(packed), N.ptr(bias), op, oc, os_, len(outs), k,
+               1 if relu else 0, B, H, W, N.stream_ptr(dev))
     return outs

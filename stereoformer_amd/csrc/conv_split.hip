@@ -234,8 +234,8 @@ extern "C" int stereo_conv_pack_weights(const float *weight, void *packed, int C
 }
 
 extern "C" int stereo_conv_nhwc_f32(const float *const *srcs, const int *src_channels, int nsrc, const void *packed,
-                                    const float *bias, float *const *outs, const int *out_channels, int nout, int ksize,
-                                    int relu, int B, int H, int W, void *stream)
+                                    const float *bias, float *const *outs, const int *out_channels, const int *out_strides,
+                                    int nout, int ksize, int relu, int B, int H, int W, void *stream)
 {
     if (nsrc < 1 || nsrc > CV_MAXSRC || nout < 1 || nout > CV_MAXNT || (ksize != 1 && ksize != 3) || B < 0 || H < 0 || W < 0)
         return STEREO_ERR_BAD_SHAPE;
@@ -259,11 +259,12 @@ extern "C" int stereo_conv_nhwc_f32(const float *const *srcs, const int *src_cha
     for (int i = 0; i < nout; ++i) {
         STEREO_REQUIRE_PTR(outs[i]);
         const int c = out_channels[i];
-        if (c < 1 || (i + 1 < nout && c % 128 != 0)) return STEREO_ERR_UNSUPPORTED;
+        const int cs = out_strides ? out_strides[i] : c;   // channels of the destination tensor (>= c: the rest is the caller's)
+        if (c < 1 || cs < c || (i + 1 < nout && c % 128 != 0)) return STEREO_ERR_UNSUPPORTED;
         for (int o = 0; o < c; o += 128) {
             if (ntn >= CV_MAXNT) return STEREO_ERR_UNSUPPORTED;
             d.p[ntn] = outs[i];
-            d.stride[ntn] = c;
+            d.stride[ntn] = cs;
             d.coff[ntn] = o;
             d.nvalid[ntn] = c - o < 128 ? c - o : 128;
             ++ntn;

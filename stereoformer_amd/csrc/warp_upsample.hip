@@ -328,6 +328,73 @@ extern "C" int stereo_resize_bilinear_f32(const float *in, float *out, int NC, i
     return STEREO_OK;
 }
 
+// The same on channels-last tensors, in [N][Hi][Wi][C] -> out [N][Ho][Wo][C] (C % 4 == 0): a thread owns four channels of one
+// output pixel (16-B loads of the four taps); the same formula per element.
+__global__ __launch_bounds__(256) void resize_bilinear_nhwc_kernel(const float *__restrict__ in, float *__restrict__ out, int C4,
+                                                                   int Hi, int Wi, int Ho, int Wo, int align_corners,
+                                                                   float scale, float rh, float rw, long long nout)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nout;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int cq = (int)(t % C4);
+        long long r = t / C4;
+        const int x = (int)(r % Wo);
+        r /= Wo;
+        const int y = (int)(r % Ho);
+        const long long n = r / Ho;
+        float sy, sx;
+        if (align_corners) {
+            sy = rh * (float)y;
+            sx = rw * (float)x;
+        } else {
+            sy = __fsub_rn(__fmul_rn(rh, (float)y + 0.5f), 0.5f);
+            sx = __fsub_rn(__fmul_rn(rw, (float)x + 0.5f), 0.5f);
+            sy = sy < 0.0f ? 0.0f : sy;
+            sx = sx < 0.0f ? 0.0f : sx;
+        }
+        int y0 = (int)sy, x0 = (int)sx;
+        y0 = y0 > Hi - 1 ? Hi - 1 : y0;
+        x0 = x0 > Wi - 1 ? Wi - 1 : x0;
+        const int y1 = y0 < Hi - 1 ? y0 + 1 : y0, x1 = x0 < Wi - 1 ? x0 + 1 : x0;
+        const float ay = sy - (float)y0, ax = sx - (float)x0;
+        const float *im = in + (size_t)n * Hi * Wi * 4 * C4 + 4 * cq;
+        const f32x4 a = ld4(im + ((size_t)y0 * Wi + x0) * 4 * C4), b = ld4(im + ((size_t)y0 * Wi + x1) * 4 * C4);
+        const f32x4 c = ld4(im + ((size_t)y1 * Wi + x0) * 4 * C4), d = ld4(im + ((size_t)y1 * Wi + x1) * 4 * C4);
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float top = a[i] * (1.0f - ax) + b[i] * ax;
+            const float bot = c[i] * (1.0f - ax) + d[i] * ax;
+            o[i] = scale * (top * (1.0f - ay) + bot * ay);
+        }
+        st4(out + t * 4, o);
+    }
+}
+
+extern "C" int stereo_resize_bilinear_nhwc_f32(const float *in, float *out, int N, int C, int Hi, int Wi, int Ho, int Wo,
+                                               int align_corners, float scale, void *stream)
+{
+    if (N < 0 || C < 0 || Hi < 0 || Wi < 0 || Ho < 0 || Wo < 0) return STEREO_ERR_BAD_SHAPE;
+    if (N == 0 || C == 0 || Ho == 0 || Wo == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(in);
+    STEREO_REQUIRE_PTR(out);
+    if (Hi == 0 || Wi == 0) return STEREO_ERR_BAD_SHAPE;
+    if (C % 4 != 0 || !aligned16(in) || !aligned16(out)) return STEREO_ERR_UNSUPPORTED;
+    float rh, rw;
+    if (align_corners) {
+        rh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.0f;
+        rw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.0f;
+    } else {
+        rh = (float)Hi / (float)Ho;
+        rw = (float)Wi / (float)Wo;
+    }
+    const long long nout = (long long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(resize_bilinear_nhwc_kernel, dim3(grid_for(nout)), dim3(256), 0, as_stream(stream), in, out, C / 4, Hi, Wi,
+                       Ho, Wo, align_corners, scale, rh, rw, nout);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
 extern "C" int stereo_bilinear_sampler_f32(const float *img, const float *coords, float *out, float *mask, int N, int C,
                                            int H, int W, int Ho, int Wo, void *stream)
 {

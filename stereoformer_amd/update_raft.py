@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import conv_split
 from .update_dlc import gru_blend, gru_reset
 from .upsample import interp
 
@@ -62,6 +63,24 @@ def _gru_step(h, x, conv_z, conv_r, conv_q, cz=None, cr=None, cq=None):
     return gru_blend(_f32(h), _f32(z_pre), _f32(conv_q(torch.cat((gated, x), 1))), _f32(cz), _f32(cq))
 
 
+def _split_ok(*ts):
+    """Inference on channels-last fp32 HIP activations outside autocast: the envelope of ``conv_split.conv_nhwc``."""
+    if torch.is_grad_enabled() or torch.is_autocast_enabled("cuda"):
+        return False
+    return all(t is None or (t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and not t.is_contiguous()
+                             and t.is_contiguous(memory_format=torch.channels_last)) for t in ts)
+
+
+def _gru_step_split(h, xs, conv_z, conv_r, conv_q, cz, cr, cq):
+    """The ConvGRU update with its convolutions on ``conv_split`` (inference, channels-last fp32): ``convz`` and ``convr`` are
+    ONE launch over the sources ``[h | x...]`` (no concatenation is materialised), ``convq`` a second one over
+    ``[r * h | x...]``; same gate kernels as ``_gru_step``."""
+    z_pre, r_pre = conv_split.conv_nhwc([h, *xs], [conv_z, conv_r])
+    gated = gru_reset(h, r_pre, cr)
+    (q_pre,) = conv_split.conv_nhwc([gated, *xs], [conv_q])
+    return gru_blend(h, z_pre, q_pre, cz, cq)
+
+
 class ConvGRU(nn.Module):
     """update.py:16-33.  ``forward(h, cz, cr, cq, *x_list)``: the context tensors are added to the gate
     pre-activations."""
@@ -72,6 +91,9 @@ class ConvGRU(nn.Module):
             setattr(self, "conv" + gate, _conv(hidden_dim + input_dim, hidden_dim, kernel_size))
 
     def forward(self, h, cz, cr, cq, *x_list):
+        if (_split_ok(h, cz, cr, cq, *x_list) and conv_split.supported([h, *x_list], [self.convz, self.convr])
+                and conv_split.supported([h, *x_list], [self.convq])):
+            return _gru_step_split(h, list(x_list), self.convz, self.convr, self.convq, cz, cr, cq)
         if _fp16_inference():
             x_list = [_to16(t) for t in x_list]   # cast the small pieces, not their concatenation
         return _gru_step(h, torch.cat(x_list, 1), self.convz, self.convr, self.convq, cz, cr, cq)
@@ -118,8 +140,16 @@ class BasicMotionEncoder_LZH(nn.Module):
         self.conv = _conv(128, 126, 3)
 
     def forward(self, flow, corr):
-        c = F.relu(self.convc2(F.relu(self.convc1(corr))))
-        f = F.relu(self.convf2(F.relu(self.convf1(flow))))
+        c1, f1 = F.relu(self.convc1(corr)), F.relu(self.convf1(flow))   # 1x1 over 36 and 7x7 over 2 channels: the library's
+        if (_split_ok(c1, f1, flow) and conv_split.supported([c1], [self.convc2]) and conv_split.supported([f1], [self.convf2])
+                and conv_split.supported([c1, f1], [self.conv])):
+            (c,) = conv_split.conv_nhwc([c1], [self.convc2], relu=True)
+            (f,) = conv_split.conv_nhwc([f1], [self.convf2], relu=True)
+            (out,) = conv_split.conv_nhwc([c, f], [self.conv], relu=True, out_channels_total=self.conv.out_channels + flow.shape[1])
+            out[:, self.conv.out_channels:] = flow     # the appended flow channels (:91), written in place
+            return out
+        c = F.relu(self.convc2(c1))
+        f = F.relu(self.convf2(f1))
         return torch.cat((F.relu(self.conv(torch.cat((c, f), 1))), flow), 1)
 
 
@@ -161,5 +191,12 @@ class BasicMultiUpdateBlock_LZH(nn.Module):
             net[0] = self.gru08(net[0], *inp[0], self.encoder(self._like(flow, net[0]), self._like(corr, net[0])), *extra)
         if not update:
             return net
+        h0 = net[0]
+        heads = [self.flow_head.conv1] + ([self.mask[0]] if need_mask else [])
+        if _split_ok(h0) and conv_split.supported([h0], heads):
+            # flow_head.conv1 | mask[0] read the same hidden state: one launch, ReLU in the epilogue
+            outs = conv_split.conv_nhwc([h0], heads, relu=True)
+            mask = 0.25 * self.mask[2](outs[1]) if need_mask else None
+            return net, mask, self.flow_head.conv2(outs[0])
         mask = 0.25 * self.mask(net[0]) if need_mask else None  # scaled to balance gradients (:176)
         return net, mask, self.flow_head(net[0])

@@ -98,9 +98,18 @@ def resize_bilinear(x, size, align_corners, scale=1.0):
     """``scale * F.interpolate(x, size, mode='bilinear', align_corners=...)`` in one kernel (HIP backward)."""
     if torch.is_grad_enabled() and x.requires_grad:
         return _ResizeBilinearFn.apply(x.contiguous(), (int(size[0]), int(size[1])), bool(align_corners), float(scale))
+    ho, wo = int(size[0]), int(size[1])
+    if (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] % 4 == 0
+            and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)):
+        # channels-last in, channels-last out (the update block in torch.channels_last): no layout round trip
+        n, c, hi, wi = x.shape
+        out = torch.empty((n, c, ho, wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        with torch.cuda.device(x.device):
+            N.call("stereo_resize_bilinear_nhwc_f32", N.ptr(x), N.ptr(out), n, c, hi, wi, ho, wo,
+                   1 if align_corners else 0, float(scale), N.stream_ptr(x.device))
+        return out
     x = N.dev_f32(x, "resize_bilinear: x")
     n, c, hi, wi = x.shape
-    ho, wo = int(size[0]), int(size[1])
     out = torch.empty((n, c, ho, wo), device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
         N.call("stereo_resize_bilinear_f32", N.ptr(x), N.ptr(out), n * c, hi, wi, ho, wo,

@@ -81,3 +81,49 @@ def test_conv_nhwc_repacks_after_an_in_place_weight_update_and_refuses_outside_i
     assert not C.supported([x.requires_grad_()], [m])                               # training keeps the library path
     with pytest.raises(ValueError):
         C.conv_nhwc([x.detach().contiguous()], [m])
+
+
+def test_resize_bilinear_channels_last(S):
+    torch.manual_seed(83)
+    for (n, c, hi, wi, ho, wo, ac) in ((2, 128, 9, 15, 17, 30, True), (1, 8, 5, 7, 40, 56, True), (1, 4, 6, 6, 3, 9, False)):
+        x = torch.randn(n, c, hi, wi, device="cuda")
+        a = S.upsample.resize_bilinear(x, (ho, wo), ac, 1.5)
+        b = S.upsample.resize_bilinear(_cl(x), (ho, wo), ac, 1.5)
+        assert b.is_contiguous(memory_format=torch.channels_last)
+        assert torch.allclose(a, b.contiguous(), rtol=1e-6, atol=1e-6)   # same formula; FMA contraction may differ by an ulp
+
+
+def test_update_block_on_the_split_convolutions_matches_the_library_path(S, monkeypatch):
+    """BasicMultiUpdateBlock_LZH in torch.channels_last under no_grad takes conv_split for its 3x3 convolutions (GRU gates as
+    one convz|convr launch over the un-concatenated sources, motion encoder, flow / mask heads): same outputs as the library
+    path (torch.cat + MIOpen) to fp32 rounding, over several chained iterations."""
+    from stereoformer_amd import conv_split as C
+    torch.manual_seed(84)
+    B, H, W = 2, 24, 40
+    blk = S.BasicMultiUpdateBlock_LZH(4, 4, 3, 2, [128, 128, 128]).cuda().eval().to(memory_format=torch.channels_last)
+    mk = lambda c, h, w: _cl(torch.randn(B, c, h, w, device="cuda") * 0.5)
+    nets0 = [torch.tanh(mk(128, H, W)), torch.tanh(mk(128, H // 2, W // 2)), torch.tanh(mk(128, H // 4, W // 4))]
+    inps = [[mk(128, H, W) for _ in range(3)], [mk(128, H // 2, W // 2) for _ in range(3)], [mk(128, H // 4, W // 4) for _ in range(3)]]
+    corr = torch.randn(B, 36, H, W, device="cuda")
+    flow = torch.randn(B, 2, H, W, device="cuda")
+    calls = []
+    real = C.conv_nhwc
+    monkeypatch.setattr(C, "conv_nhwc", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+
+    def run(split):
+        if not split:
+            monkeypatch.setattr(C, "supported", lambda *a, **k: False)
+        nets = [n.clone() for n in nets0]
+        with torch.no_grad():
+            for it in range(3):
+                nets, mask, delta = blk(nets, inps, corr, flow + 0.1 * it, need_mask=it == 2)
+        return nets, mask, delta
+
+    a = run(True)
+    n_split = len(calls)
+    assert n_split == 3 * (3 * 2 + 3 + 1)          # per iteration: 3 GRUs x 2 launches, 3 encoder convolutions, the heads
+    b = run(False)
+    assert len(calls) == n_split
+    for x, y in zip([*a[0], a[1], a[2]], [*b[0], b[1], b[2]]):
+        assert x.shape == y.shape
+        assert float((x - y).abs().max()) <= 2e-5 * max(1.0, float(y.abs().max())), float((x - y).abs().max())
