@@ -12,7 +12,7 @@
 //
 //   GEMM view      M = pixels (A operand, from LDS), N = output channels (B operand, pre-packed weights), K = (tap, channel)
 //   workgroup      4 waves, tile = 8 rows x 32 columns of pixels x 128 output channels; wave (wm, wn) owns rows 4 wm .. 4 wm + 3
-//                  (four 32-pixel M blocks) x channels 64 wn .. + 63 (two N blocks): 8 accumulator blocks = 128 registers
+//                  (four M blocks of 2 rows x 16 columns) x channels 64 wn .. + 63 (two N blocks): 8 accumulator blocks = 128 registers
 //   K loop         sources in concatenation order, 16 input channels at a time: the (8 + 2) x (32 + 2) halo tile of the chunk is
 //                  fetched into registers (16-B quads through one buffer resource per source image: pixels outside the image read
 //                  0 = the zero padding), split into its three bf16 pieces and written to LDS as [piece][pixel][16 ch + pad]
@@ -22,10 +22,11 @@
 //                  fragment is one 16-B load per lane, 1 KB contiguous per wave, served by L2 (2.6 MB for 384 -> 128 channels)
 //   epilogue       + bias, optional ReLU, every accumulator register is a 128-B row of 32 consecutive output channels of one pixel
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
-constexpr int CV_TH = 8, CV_TW = 32;   // output pixel tile
+constexpr int CV_TW = 32;               // output pixel tile: TH (8 or 4) rows x 32 columns
 constexpr int CV_PXB = 48;             // LDS bytes per pixel and piece: 16 channels x bf16 + 16 B pad (conflict-free b128 reads)
 constexpr int CV_MAXSRC = 4, CV_MAXNT = 4;
 
@@ -66,26 +67,29 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, __bf16 *__restrict
     for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8 *>(packed + (base + (size_t)p * 64) * 8) = pc[p];
 }
 
-template <int KS>
-__global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvSrcs src, const __bf16 *__restrict__ packed,
+template <int KS, int TH>
+__global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSrcs src, const __bf16 *__restrict__ packed,
                                                          const float *__restrict__ bias, ConvDsts dst, int relu, int H, int W,
-                                                         int tiles_x, int tiles_y, int NB, int Cout)
+                                                         int tiles_x, int tiles_y, int NB, int Cout, int ntn)
 {
     constexpr int HALO = KS / 2, TAPS = KS * KS;
-    constexpr int HCOLS = CV_TW + 2 * HALO, HROWS = CV_TH + 2 * HALO, NPX = HROWS * HCOLS;
+    constexpr int WN = TH == 8 ? 2 : 4;          // waves along the output channels (the other 4 / WN along the rows)
+    constexpr int NBW = 4 / WN;                  // 32-channel N blocks per wave
+    constexpr int HCOLS = CV_TW + 2 * HALO, HROWS = TH + 2 * HALO, NPX = HROWS * HCOLS;
     constexpr int PS = NPX * CV_PXB;             // piece stride (bytes)
     constexpr int NQ = NPX * 4, NPASS = (NQ + 255) / 256;
     __shared__ __attribute__((aligned(16))) char img[3 * PS];
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l31 = lane & 31, half = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nt = blockIdx.y;
-    int t = blockIdx.x;
+    const int wm = wave / WN, wn = wave % WN;
+    int t = blockIdx.x;                      // N tile fastest: the workgroups sharing a pixel tile's activations run together
+    const int nt = t % ntn;
+    t /= ntn;
     const int tx = t % tiles_x;
     t /= tiles_x;
     const int ty = t % tiles_y, b = t / tiles_y;
-    const int x0 = tx * CV_TW, y0 = ty * CV_TH;
+    const int x0 = tx * CV_TW, y0 = ty * TH;
 
     // halo-tile quads of this thread: pixel index inside the image (or -1) and LDS byte offset
     int pix[NPASS], lw[NPASS];
@@ -130,80 +134,116 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvSrcs src, const 
     for (int s = 0; s < CV_MAXSRC; ++s)
         if (s < src.n) nchunks += src.c[s] / 16;
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][NBW];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
 
-    // A fragment of (M block mb, tap (ky, kx), piece p): pixel (4 wm + mb + ky, l31 + kx) of the halo tile, channels 8 half ..
-    const char *abase = img + ((4 * wm) * HCOLS + l31) * CV_PXB + half * 16;
-    // B fragments of this wave: n blocks 4 nt + 2 wn + {0, 1}
-    const __bf16 *wbase = packed + ((size_t)(4 * nt + 2 * wn) * 3 * 64 + lane) * 8;
+    // M block mb = (row pair rp = mb >> 1, column half ch = mb & 1) is 2 rows x 16 columns of pixels: MFMA row i of the block is
+    // pixel (4 wm + 2 rp + (i >> 4), 16 ch + (i & 15)) of the tile, so an image whose width is a multiple of 16 (240, 120 ...)
+    // wastes no matrix work in its last tile -- blocks entirely outside the image are skipped (wave-uniform).
+    // A fragment of (mb, tap (ky, kx), piece p): that pixel shifted by the tap in the halo tile, channels 8 half ..
+    const char *abase = img + ((4 * wm + (l31 >> 4)) * HCOLS + (l31 & 15)) * CV_PXB + half * 16;
+    // B fragments of this wave: n blocks 4 nt + NBW wn + {0 .. NBW - 1}
+    const __bf16 *wbase = packed + ((size_t)(4 * nt + NBW * wn) * 3 * 64 + lane) * 8;
     const size_t kstep = (size_t)NB * 3 * 64 * 8;   // elements per k-step (one tap of one chunk)
 
-    issue();
-    for (int g = 0; g < nchunks; ++g) {
-        commit();
-        __syncthreads();   // the chunk's pieces are visible
-        if (g + 1 < nchunks) issue();
-        const __bf16 *wk = wbase + (size_t)g * TAPS * kstep;
+    // which of this wave's four M blocks lie inside the image (wave-uniform): all of them (the common case), the left column
+    // half only (last tile of a row whose width is 16 mod 32), or some other subset (bottom edge)
+    bool mbv[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) mbv[mb] = y0 + 4 * wm + 2 * (mb >> 1) < H && x0 + 16 * (mb & 1) < W;
+    const int mode = (mbv[0] && mbv[1] && mbv[2] && mbv[3]) ? 0 : ((mbv[0] && mbv[2] && !mbv[1] && !mbv[3]) ? 1 : 2);
+
+    // one chunk's 9 taps; MODE selects the M blocks.  (Four waves per SIMD hide the dependent six-MFMA chain of a block; a
+    // variant that alternated two blocks' chains and fetched the B fragments a tap ahead needed 142 registers -- three waves per
+    // SIMD -- and measured 4 % slower.)
+    auto load_b = [&](bf16x8 (&bf)[NBW][3], const __bf16 *wt) {
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[nb][p] = *reinterpret_cast<const bf16x8 *>(wt + ((size_t)nb * 3 + p) * 64 * 8);
+    };
+    auto load_a = [&](bf16x8 (&af)[3], int mb, int ky, int kx) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            af[p] = *reinterpret_cast<const bf16x8 *>(abase + p * PS + ((2 * (mb >> 1) + ky) * HCOLS + 16 * (mb & 1) + kx) * CV_PXB);
+    };
+    // piece products, smallest first: (a1 b1) (a0 b2) (a2 b0) (a0 b1) (a1 b0) (a0 b0)
+    constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+    auto single = [&](int m0, int ky, int kx, const bf16x8 (&bf)[NBW][3]) {
+        bf16x8 a0[3];
+        load_a(a0, m0, ky, kx);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+                acc[m0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[PA[q]], bf[nb][PB[q]], acc[m0][nb], 0, 0, 0);
+    };
+    auto chunk = [&](auto mode_tag, const __bf16 *wk) {
+        constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int ky = tap / KS, kx = tap % KS;
-            bf16x8 bf[2][3];
+            bf16x8 bc[NBW][3];
+            load_b(bc, wk + (size_t)tap * kstep);
+            if (MODE == 0) {
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    bf[nb][p] = *reinterpret_cast<const bf16x8 *>(wk + (size_t)tap * kstep + ((size_t)nb * 3 + p) * 64 * 8);
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                if (y0 + 4 * wm + mb < H) {   // wave-uniform: rows below the image do no work
-                    bf16x8 af[3];
-#pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        af[p] = *reinterpret_cast<const bf16x8 *>(abase + p * PS + ((mb + ky) * HCOLS + kx) * CV_PXB);
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) {
-                        f32x16 a = acc[mb][nb];   // smallest terms first
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[nb][1], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[nb][2], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[nb][0], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[nb][1], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[nb][0], a, 0, 0, 0);
-                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[nb][0], a, 0, 0, 0);
-                        acc[mb][nb] = a;
-                    }
+                for (int mb = 0; mb < 4; ++mb) {
+                    single(mb, ky, kx, bc);
+                    __builtin_amdgcn_sched_barrier(0);   // (hoisting every block's fragments over the unrolled taps spills)
                 }
+            } else if (MODE == 1) {
+                single(0, ky, kx, bc);
+                __builtin_amdgcn_sched_barrier(0);
+                single(2, ky, kx, bc);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+                    if (mbv[mb]) single(mb, ky, kx, bc);
             }
         }
-        __syncthreads();   // every wave is done with the chunk before the next commit overwrites it
-    }
+    };
 
-    // ---- epilogue: register r of lane (l31, half) = pixel x0 + (r & 3) + 8 (r >> 2) + 4 half, channel 64 wn + 32 nb + l31
+    // the mode is fixed for the tile: one clean K loop per mode (a switch inside the loop makes the accumulators flow through
+    // three alternative paths per iteration, which costs registers)
+    auto run = [&](auto mode_tag) {
+        issue();
+        for (int g = 0; g < nchunks; ++g) {
+            commit();
+            __syncthreads();   // the chunk's pieces are visible
+            if (g + 1 < nchunks) issue();
+            chunk(mode_tag, wbase + (size_t)g * TAPS * kstep);
+            __syncthreads();   // every wave is done with the chunk before the next commit overwrites it
+        }
+    };
+    if (mode == 0) run(std::integral_constant<int, 0>{});
+    else if (mode == 1) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 2>{});
+
+    // ---- epilogue: register r of lane (l31, half) holds MFMA row i = (r & 3) + 8 (r >> 2) + 4 half of its M block, i.e. pixel
+    // (row + (r >> 3), 16 ch + (r & 3) + 8 ((r >> 2) & 1) + 4 half), output channel 32 (NBW wn + nb) + l31: a 128-B row per store
     float *ob = dst.p[nt];
     const int ostride = dst.stride[nt], coff = dst.coff[nt], nvalid = dst.nvalid[nt];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const int cl = 64 * wn + 32 * nb + l31;
+    for (int nb = 0; nb < NBW; ++nb) {
+        const int cl = 32 * (NBW * wn + nb) + l31;
         const int cg = 128 * nt + cl;
         const float bv = (bias != nullptr && cg < Cout) ? bias[cg] : 0.0f;
         if (cl < nvalid) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
-                const int y = y0 + 4 * wm + mb;
-                if (y < H) {
-                    float *orow = ob + ((size_t)b * H + y) * W * ostride + coff + cl;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        float v = acc[mb][nb][r] + bv;
-                        if (relu) v = fmaxf(v, 0.0f);
-                        if (x < W) orow[(size_t)x * ostride] = v;
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int y = y0 + 4 * wm + 2 * (mb >> 1) + (r >> 3);
+                    const int x = x0 + 16 * (mb & 1) + (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
+                    float v = acc[mb][nb][r] + bv;
+                    if (relu) v = fmaxf(v, 0.0f);
+                    if (y < H && x < W) ob[(((size_t)b * H + y) * W + x) * ostride + coff + cl] = v;
                 }
             }
         }
@@ -271,18 +311,22 @@ extern "C" int stereo_conv_nhwc_f32(const float *const *srcs, const int *src_cha
         }
         Cout += c;
     }
-    const int tiles_x = (W + CV_TW - 1) / CV_TW, tiles_y = (H + CV_TH - 1) / CV_TH;
-    const long long nt = (long long)tiles_x * tiles_y * B;
-    if (nt >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
     const int NB = 4 * ((Cout + 127) / 128);
     (void)Cin;
-    dim3 grid((unsigned)nt, (unsigned)ntn);
-    if (ksize == 3)
-        hipLaunchKernelGGL(conv_split_kernel<3>, grid, dim3(256), 0, as_stream(stream), s, static_cast<const __bf16 *>(packed), bias,
-                           d, relu, H, W, tiles_x, tiles_y, NB, Cout);
-    else
-        hipLaunchKernelGGL(conv_split_kernel<1>, grid, dim3(256), 0, as_stream(stream), s, static_cast<const __bf16 *>(packed), bias,
-                           d, relu, H, W, tiles_x, tiles_y, NB, Cout);
+    const int tiles_x = (W + CV_TW - 1) / CV_TW;
+    // pixel tile: 4 rows x 32 columns, a wave = 4 rows x 32 output channels (an 8-row tile with 64 channels per wave measured equal
+    // at the large shapes and 7-18 % behind at 1/8 and 1/16 scale: finer workgroups spread a launch more evenly over the chip)
+    constexpr int th = 4;
+    const int tiles_y = (H + th - 1) / th;
+    const long long nt = (long long)tiles_x * tiles_y * B;
+    if (nt * ntn >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)(nt * ntn));
+#define CONV_LAUNCH(KSV)                                                                                                  \
+    hipLaunchKernelGGL((conv_split_kernel<KSV, th>), grid, dim3(256), 0, as_stream(stream), s, static_cast<const __bf16 *>(packed), \
+                       bias, d, relu, H, W, tiles_x, tiles_y, NB, Cout, ntn)
+    if (ksize == 3) CONV_LAUNCH(3);
+    else CONV_LAUNCH(1);
+#undef CONV_LAUNCH
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }

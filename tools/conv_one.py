@@ -1,0 +1,12 @@
+"""dev: a few launches of the gru08 convz|convr shape for PMC passes.   python tools/conv_one.py"""
+import os, sys, torch, torch.nn as nn
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import stereoformer_amd as S
+from stereoformer_amd import conv_split as C
+cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+srcs = [cl(torch.randn(8, 128, 136, 240, device="cuda")) for _ in range(3)]
+convs = [nn.Conv2d(384, 128, 3, padding=1).cuda() for _ in range(2)]
+with torch.no_grad():
+    for _ in range(4):
+        C.conv_nhwc(srcs, convs)
+torch.cuda.synchronize()
