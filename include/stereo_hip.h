@@ -329,6 +329,12 @@ int stereo_conv_nhwc_f32(const float *const *srcs, const int *src_channels, int 
                          float *const *outs, const int *out_channels, const int *out_strides, int nout, int ksize, int relu,
                          int B, int H, int W, void *stream);
 
+/* 3x3 stride-1 "same" convolution with 1..4 output channels (flow_head.conv2, update.py:11-14: 256 -> 2) on the fp32 vector
+ * units: x [B][H][W][Cin] channels-last (Cin % 32 == 0), weight_tco = weight.permute(2, 3, 1, 0) contiguous, i.e.
+ * [3][3][Cin][Cout]; bias [Cout] or NULL; out_nchw [B][Cout][H][W]. */
+int stereo_conv3x3_small_nhwc_f32(const float *x, const float *weight_tco, const float *bias, float *out_nchw, int B, int Cin,
+                                  int Cout, int H, int W, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

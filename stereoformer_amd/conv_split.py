@@ -17,9 +17,6 @@ import torch
 
 from . import _native as N
 
-_PACKED: dict = {}
-
-
 def _is_cl(t):
     return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
 
@@ -28,10 +25,11 @@ def supported(srcs, convs) -> bool:
     """Channels-last fp32 HIP tensors without grad, every source channel count a multiple of 16 (<= 4 sources), 3x3 / 1x1 stride-1
     'same' convolutions without groups or dilation, all but the last module with a multiple of 128 output channels, <= 512 in
     all."""
-    if torch.is_grad_enabled() and any(t.requires_grad for t in srcs):
-        return False
     if not (1 <= len(srcs) <= 4) or not convs:
         return False
+    if torch.is_grad_enabled() and (any(t.requires_grad for t in srcs) or
+                                    any(p.requires_grad for m in convs if isinstance(m, torch.nn.Module) for p in m.parameters())):
+        return False     # no autograd formula: training keeps the library convolutions
     t0 = srcs[0]
     for t in srcs:
         if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and _is_cl(t)):
@@ -56,30 +54,48 @@ def supported(srcs, convs) -> bool:
     return total <= 512
 
 
+def _signature(convs, device):
+    """What a packed copy depends on: the identity, storage address and in-place version of every parameter involved."""
+    sig = [device.index]
+    for m in convs:
+        for p in (m.weight, m.bias):
+            sig.append(None if p is None else (id(p), p.data_ptr(), p._version, tuple(p.shape)))
+    return tuple(sig)
+
+
+def _cached(convs, tag, device, build):
+    """Per-module cache (it lives on the first module of the group and dies with it -- a global table keyed by storage
+    addresses would hand a freed weight's packed copy to whatever tensor is allocated at the same address next)."""
+    store = convs[0].__dict__.setdefault("_stereo_conv_cache", {})
+    key = (tag,) + tuple(id(m) for m in convs[1:])
+    sig = _signature(convs, device)
+    hit = store.get(key)
+    if hit is not None and hit[0] == sig:
+        return hit[1]
+    val = build()
+    store[key] = (sig, val)
+    return val
+
+
 def _packed(convs, device):
-    """Packed split-bf16 weights (+ the concatenated bias) of a group of modules; rebuilt when a weight changes in place."""
-    key = tuple((m.weight.data_ptr(), m.weight._version, None if m.bias is None else (m.bias.data_ptr(), m.bias._version))
-                for m in convs) + (device.index,)
-    hit = _PACKED.get(key)
-    if hit is not None:
-        return hit
-    with torch.no_grad():
-        w = torch.cat([m.weight.detach().contiguous() for m in convs], 0).contiguous()
-        bias = None
-        if any(m.bias is not None for m in convs):
-            bias = torch.cat([m.bias.detach() if m.bias is not None else torch.zeros(m.out_channels, device=device)
-                              for m in convs]).contiguous()
-        cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
-        nbytes = N.load().stereo_conv_packed_bytes(cout, cin, k)
-        if nbytes <= 0:
-            raise ValueError(f"conv_nhwc: unsupported weight shape {tuple(w.shape)}")
-        packed = torch.empty(nbytes, device=device, dtype=torch.uint8)
-        with torch.cuda.device(device):
-            N.call("stereo_conv_pack_weights", N.ptr(w), N.ptr(packed), cout, cin, k, N.stream_ptr(device))
-    if len(_PACKED) > 256:          # stale entries of weights that were updated or freed
-        _PACKED.clear()
-    _PACKED[key] = (packed, bias, k)
-    return _PACKED[key]
+    """Packed split-bf16 weights (+ the concatenated bias) of a group of modules; rebuilt when a parameter is replaced or
+    updated in place."""
+    def build():
+        with torch.no_grad():
+            w = torch.cat([m.weight.detach().contiguous() for m in convs], 0).contiguous()
+            bias = None
+            if any(m.bias is not None for m in convs):
+                bias = torch.cat([m.bias.detach() if m.bias is not None else torch.zeros(m.out_channels, device=device)
+                                  for m in convs]).contiguous()
+            cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+            nbytes = N.load().stereo_conv_packed_bytes(cout, cin, k)
+            if nbytes <= 0:
+                raise ValueError(f"conv_nhwc: unsupported weight shape {tuple(w.shape)}")
+            packed = torch.empty(nbytes, device=device, dtype=torch.uint8)
+            with torch.cuda.device(device):
+                N.call("stereo_conv_pack_weights", N.ptr(w), N.ptr(packed), cout, cin, k, N.stream_ptr(device))
+        return packed, bias, k
+    return _cached(convs, "split", device, build)
 
 
 def conv_nhwc(srcs, convs, relu=False, out_channels_total=None):
@@ -106,3 +122,26 @@ def conv_nhwc(srcs, convs, relu=False, out_channels_total=None):
         N.call("stereo_conv_nhwc_f32", sp, sc, len(srcs), N.ptr(packed), N.ptr(bias), op, oc, os_, len(outs), k,
                1 if relu else 0, B, H, W, N.stream_ptr(dev))
     return outs
+
+
+def small_supported(x, conv) -> bool:
+    """3x3 stride-1 'same' convolution with <= 4 output channels over a channels-last fp32 HIP tensor, Cin % 32 == 0."""
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in conv.parameters())):
+        return False
+    return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros" and conv.out_channels <= 4
+            and conv.weight.dtype == torch.float32 and x.is_cuda and x.dtype == torch.float32 and _is_cl(x)
+            and x.shape[1] == conv.in_channels and x.shape[1] % 32 == 0 and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 2 ** 31)
+
+
+def conv3x3_small(x, conv):
+    """``conv(x)`` for a 3x3 convolution with <= 4 output channels (``flow_head.conv2``): channels-last in, NCHW-contiguous out."""
+    if not small_supported(x, conv):
+        raise ValueError("conv3x3_small: operands outside the kernel's envelope (see conv_split.small_supported)")
+    wt = _cached([conv], "tco", x.device, lambda: conv.weight.detach().permute(2, 3, 1, 0).contiguous())   # [3][3][Cin][Cout]
+    B, C, H, W = x.shape
+    out = torch.empty((B, conv.out_channels, H, W), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        N.call("stereo_conv3x3_small_nhwc_f32", N.ptr(x), N.ptr(wt), N.ptr(None if conv.bias is None else conv.bias.detach()),
+               N.ptr(out), B, C, conv.out_channels, H, W, N.stream_ptr(x.device))
+    return out

@@ -250,7 +250,96 @@ __global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSr
     }
 }
 
+// ---- 3x3 convolutions with a handful of output channels (flow_head.conv2: 256 -> 2, update.py:11-14): a 32-channel MFMA N
+// block would be 1/16 full, and the library's implicit GEMM takes 0.46 ms for these 2.4 GFLOP.  Plain fp32 FMAs instead: a
+// thread owns one pixel of an 8 x 32 tile, the halo tile goes through LDS 32 input channels at a time ([pixel][32 + 4 pad]:
+// conflict-free 16-B reads), the weights are wave-uniform (scalar loads).  Channels-last in, NCHW out (the consumer adds the
+// result to the NCHW coordinate grid).
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_small_kernel(const float *__restrict__ x, const float *__restrict__ wt,
+                                                            const float *__restrict__ bias, float *__restrict__ out, int Cin,
+                                                            int H, int W, int tiles_x, int tiles_y)
+{
+    constexpr int HC = 34, HR = 10, NPX = HC * HR, PXS = 36;   // halo tile, floats per pixel in LDS
+    constexpr int NQ = NPX * 8, NPASS = (NQ + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float tile[NPX * PXS];
+    const int tid = threadIdx.x, row = tid >> 5, col = tid & 31;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int x0 = 32 * tx, y0 = 8 * ty;
+    const __amdgpu_buffer_rsrc_t rs = buffer_rsrc(x + (size_t)b * H * W * Cin, (unsigned)H * (unsigned)W * (unsigned)Cin * 4u);
+    int voff[NPASS], lw[NPASS];
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const int q = tid + 256 * i;
+        const int px = q >> 3, cq = q & 7;
+        const int hy = px / HC, hx = px - hy * HC;
+        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+        voff[i] = (q < NQ && yy >= 0 && yy < H && xx >= 0 && xx < W) ? ((yy * W + xx) * Cin + 4 * cq) * 4 : (int)0x80000000;
+        lw[i] = q < NQ ? px * PXS + 4 * cq : -1;
+    }
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = bias ? bias[o] : 0.0f;
+    const float *tp = tile + (row * HC + col) * PXS;
+    for (int c0 = 0; c0 < Cin; c0 += 32) {
+        f32x4 rk[NPASS];
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) rk[i] = BufLd<float>::quad(rs, voff[i], c0 * 4);   // (soffset is range-checked with voffset)
+        __syncthreads();   // the previous chunk has been consumed
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i)
+            if (lw[i] >= 0) *reinterpret_cast<f32x4 *>(tile + lw[i]) = rk[i];
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float *pp = tp + ((tap / 3) * HC + tap % 3) * PXS;
+            const float *wk = wt + ((size_t)tap * Cin + c0) * COUT;   // [tap][channel][COUT]
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(pp + 4 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int o = 0; o < COUT; ++o) acc[o] = fmaf(v[i], wk[(4 * q + i) * COUT + o], acc[o]);
+            }
+        }
+    }
+    const int y = y0 + row, xo = x0 + col;
+    if (y < H && xo < W) {
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) out[(((size_t)b * COUT + o) * H + y) * W + xo] = acc[o];
+    }
+}
+
 }  // namespace
+
+extern "C" int stereo_conv3x3_small_nhwc_f32(const float *x, const float *weight_tco, const float *bias, float *out_nchw, int B,
+                                             int Cin, int Cout, int H, int W, void *stream)
+{
+    if (B < 0 || Cin < 0 || Cout < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0 || Cout == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(x);
+    STEREO_REQUIRE_PTR(weight_tco);
+    STEREO_REQUIRE_PTR(out_nchw);
+    if (Cin < 32 || Cin % 32 != 0 || Cout > 4 || !aligned16(x) || (long long)H * W * Cin * 4 >= (1LL << 31))
+        return STEREO_ERR_UNSUPPORTED;
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
+    const long long nt = (long long)tiles_x * tiles_y * B;
+    if (nt >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
+#define SMALL(CO) \
+    hipLaunchKernelGGL(conv3x3_small_kernel<CO>, dim3((unsigned)nt), dim3(256), 0, as_stream(stream), x, weight_tco, bias, out_nchw, \
+                       Cin, H, W, tiles_x, tiles_y)
+    if (Cout == 1) SMALL(1);
+    else if (Cout == 2) SMALL(2);
+    else if (Cout == 3) SMALL(3);
+    else SMALL(4);
+#undef SMALL
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
 
 extern "C" long long stereo_conv_packed_bytes(int Cout, int Cin, int ksize)
 {

@@ -197,6 +197,8 @@ class BasicMultiUpdateBlock_LZH(nn.Module):
             # flow_head.conv1 | mask[0] read the same hidden state: one launch, ReLU in the epilogue
             outs = conv_split.conv_nhwc([h0], heads, relu=True)
             mask = 0.25 * self.mask[2](outs[1]) if need_mask else None
+            if conv_split.small_supported(outs[0], self.flow_head.conv2):
+                return net, mask, conv_split.conv3x3_small(outs[0], self.flow_head.conv2)   # 256 -> 2: fp32 FMAs, NCHW out
             return net, mask, self.flow_head.conv2(outs[0])
         mask = 0.25 * self.mask(net[0]) if need_mask else None  # scaled to balance gradients (:176)
         return net, mask, self.flow_head(net[0])

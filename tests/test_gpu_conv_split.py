@@ -48,8 +48,9 @@ def test_conv_nhwc_matches_fp64_and_miopen(S, case):
     torch.manual_seed(81)
     srcs = [_cl(torch.randn(B, c, H, W, device="cuda")) for c in cs]
     convs = [nn.Conv2d(sum(cs), c, k, padding=k // 2, bias=bias).cuda() for c in co]
-    assert C.supported(srcs, convs)
+    assert not C.supported(srcs, convs)          # grad mode with trainable weights: the library path
     with torch.no_grad():
+        assert C.supported(srcs, convs)
         outs = C.conv_nhwc(srcs, convs, relu=relu)
         lib = [m(torch.cat(srcs, 1)) for m in convs]
     ref = _ref64(srcs, convs, relu)
@@ -75,12 +76,12 @@ def test_conv_nhwc_repacks_after_an_in_place_weight_update_and_refuses_outside_i
         m.bias.zero_()
         b = C.conv_nhwc([x], [m])[0]
         assert torch.allclose(b, m(x), rtol=1e-5, atol=1e-5) and not torch.allclose(a, b)
-    assert not C.supported([x.contiguous()], [m])                                   # NCHW
-    assert not C.supported([x], [nn.Conv2d(16, 32, 3, padding=1, stride=2).cuda()])  # strided
-    assert not C.supported([x[:, :8]], [nn.Conv2d(8, 32, 3, padding=1).cuda()])      # channels not a multiple of 16
-    assert not C.supported([x.requires_grad_()], [m])                               # training keeps the library path
-    with pytest.raises(ValueError):
-        C.conv_nhwc([x.detach().contiguous()], [m])
+        assert not C.supported([x.contiguous()], [m])                                   # NCHW
+        assert not C.supported([x], [nn.Conv2d(16, 32, 3, padding=1, stride=2).cuda()])  # strided
+        assert not C.supported([x[:, :8]], [nn.Conv2d(8, 32, 3, padding=1).cuda()])      # channels not a multiple of 16
+        with pytest.raises(ValueError):
+            C.conv_nhwc([x.detach().contiguous()], [m])
+    assert not C.supported([x], [m])                                                    # training keeps the library path
 
 
 def test_resize_bilinear_channels_last(S):
@@ -127,3 +128,20 @@ def test_update_block_on_the_split_convolutions_matches_the_library_path(S, monk
     for x, y in zip([*a[0], a[1], a[2]], [*b[0], b[1], b[2]]):
         assert x.shape == y.shape
         assert float((x - y).abs().max()) <= 2e-5 * max(1.0, float(y.abs().max())), float((x - y).abs().max())
+
+
+@pytest.mark.parametrize("case", [(2, 32, 9, 37, 2), (1, 256, 17, 70, 2), (1, 64, 8, 32, 4), (1, 96, 5, 5, 1), (2, 128, 3, 100, 3)])
+def test_conv3x3_small_output_channels(S, case):
+    """flow_head.conv2 (256 -> 2) on the fp32 vector kernel: channels-last in, NCHW out, against fp64."""
+    from stereoformer_amd import conv_split as C
+    B, cin, H, W, cout = case
+    torch.manual_seed(85)
+    x = _cl(torch.randn(B, cin, H, W, device="cuda"))
+    m = nn.Conv2d(cin, cout, 3, padding=1).cuda()
+    with torch.no_grad():
+        assert C.small_supported(x, m)
+        o = C.conv3x3_small(x, m)
+        assert not C.small_supported(x, nn.Conv2d(cin, 8, 3, padding=1).cuda())
+    r = F.conv2d(x.double().cpu(), m.weight.detach().double().cpu(), m.bias.detach().double().cpu(), padding=1)
+    assert o.shape == r.shape and o.is_contiguous()
+    assert float((o.double().cpu() - r).abs().max()) <= 5e-6 * float(r.abs().max()) + 2e-6   # sequential fp32 sums of 9 Cin terms

@@ -23,3 +23,10 @@ for (nm, B, H, W, cs, co, relu) in (("gru08 convz|convr [8,384,136,240] -> 128+1
         ms_lib_all = timeit(lambda: [torch.relu(m(torch.cat(srcs, 1))) if relu else m(torch.cat(srcs, 1)) for m in convs], 10, 3)
     print(f"{nm}: split {ms:.3f} ms (8-row tiles {ms8:.3f}, 4-row tiles {ms4:.3f}) = {gf / ms:.0f} TFLOP/s fp32-equivalent | MIOpen convs alone {ms_lib:.3f} ms = {gf / ms_lib:.0f} | "
           f"MIOpen + cat (+ relu) {ms_lib_all:.3f} ms", flush=True)
+
+x = cl(torch.randn(8, 256, 136, 240, device="cuda"))
+m = nn.Conv2d(256, 2, 3, padding=1).cuda().to(memory_format=torch.channels_last)
+with torch.no_grad():
+    a = timeit(lambda: C.conv3x3_small(x, m), 10, 3)
+    b = timeit(lambda: m(x), 10, 3)
+print(f"flow_head.conv2 256 -> 2: fp32 vector kernel {a:.3f} ms | MIOpen {b:.3f} ms", flush=True)
