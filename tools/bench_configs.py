@@ -264,10 +264,31 @@ def cfg3(dev, rank, world, steps, warmup, cpu):
                  "split-bf16 form) + disparity regression, batch=8 per GPU", B, world, sec, per_rank, steps, warmup, roof, cb)
 
 
+def conv_split_roofline(B, Hq, Wq, dev):
+    """The launch that dominates a RAFT-loop iteration: convz | convr of the 1/4-scale GRU over [h | motion | interp] (384 -> 256
+    channels, 3x3) on the split-bf16 kernel.  `achieved` counts fp32-equivalent flops; the matrix cores execute 6 bf16 piece
+    products per fp32 product, so the dense bf16 peak / 6 is the peak of this formulation."""
+    import torch.nn as nn
+    from stereoformer_amd import conv_split as C
+    cl = torch.channels_last
+    srcs = [torch.randn(B, 128, Hq, Wq, device=dev).contiguous(memory_format=cl) for _ in range(3)]
+    convs = [nn.Conv2d(384, 128, 3, padding=1).to(dev) for _ in range(2)]
+    with torch.no_grad():
+        ms = event_ms(lambda: C.conv_nhwc(srcs, convs))
+    gf = 2 * B * Hq * Wq * 384 * 256 * 9 / 1e9
+    tf = gf / ms
+    return {"bound": "mfma", "kernel": "conv_split_kernel<3,4> (A14: convz | convr of the 1/4-scale ConvGRU, 384 -> 256 channels, "
+                                       "fp32-faithful split-bf16 on v_mfma_f32_32x32x16_bf16; ~84 % of the loop's time is this kernel)",
+            "achieved": round(tf, 1), "peak": round(2500.0 / 6, 1), "unit": "TFLOP/s", "frac": round(tf / (2500.0 / 6), 4),
+            "traffic": None, "avg_launch_ms": round(ms, 4), "executed_bf16_tflops": round(6 * tf, 1),
+            "frac_of_f32_mfma_peak": round(tf / MFMA_F32_PEAK, 4),
+            "note": "fp32-equivalent flops; MIOpen's fp32 implicit GEMM runs the same launch at ~128 TFLOP/s (0.81 of the f32 MFMA peak)"}
+
+
 def cfg4(dev, rank, world, steps, warmup, cpu, mixed=False):
     B, Hq, Wq = 8, 136, 240  # 544x960 / 4
     f1, f2, nets, inps = raft_inputs(B, Hq, Wq, dev, 400 + rank)
-    roof = allpairs_roofline(f1, f2) if rank == 0 else None
+    roof = conv_split_roofline(B, Hq, Wq, dev) if rank == 0 else None
     torch.manual_seed(4)
     out = []
     for mp in ((False, True) if mixed else (False,)):
@@ -287,7 +308,9 @@ def cfg4(dev, rank, world, steps, warmup, cpu, mixed=False):
                          "convex upsampling, batch=8 per GPU (64 pairs over 8 GPUs)"
                          + (", update-block convolutions under fp16 autocast (the reference's mixed_precision flag; NOT the "
                             "parity configuration)" if mp else ", fp32"), B, world, sec, per_rank, steps, warmup, roof, cb,
-                         {"bounded_by": "MIOpen convolutions of the update block (1.2 TFLOP per iteration for 8 pairs)",
+                         {"bounded_by": ("MIOpen fp16 convolutions of the update block" if mp else
+                                         "the update block's convolutions (1.2 TFLOP fp32-equivalent per iteration for 8 pairs) on "
+                                         "the split-bf16 matrix-core kernel"),
                           "dtype": "f32 (+ f16 convs)" if mp else "f32"}))
         del loop
     del f1, f2, nets, inps
@@ -353,7 +376,8 @@ def cfg5(dev, rank, world, steps, warmup, cpu):
         cb = _guard(leg)
     return entry("cfg-5", "KITTI 1242x375 (padded 1248x384) D=256: cross-attention at 1/4 resolution [4,256,96,312] (band 64) "
                  "-> initial disparity -> 16-iteration IterativeLocalCostVolume loop, batch=4 per GPU (32 pairs over 8 GPUs), fp32",
-                 B, world, sec, per_rank, steps, warmup, roof, cb, {"bounded_by": "MIOpen convolutions of the update block"})
+                 B, world, sec, per_rank, steps, warmup, roof, cb,
+                 {"bounded_by": "the update block's convolutions (split-bf16 matrix-core kernel, csrc/conv_split.hip)"})
 
 
 def run_all(dev, rank=0, world=1, cpu=False, rehearsal=False, steps=3, warmup=2, only=None, mixed=False):

@@ -244,8 +244,36 @@ def main():
             inps = [[torch.randn(8, 128, Hr >> i, Wr >> i, device=dev) for _ in range(3)] for i in range(3)]
             corr = torch.randn(8, 36, Hr, Wr, device=dev)
             flow = torch.randn(8, 2, Hr, Wr, device=dev)
-            add("A14 one iteration B=8 @136x240", timeit(lambda: blk14(list(nets), inps, corr, flow), 3, 1), None,
+            add("A14 one iteration B=8 @136x240 [NCHW: library convolutions + torch.cat]", timeit(lambda: blk14(list(nets), inps, corr, flow), 3, 1), None,
                 8 * 168.0, bound="miopen", note="168 GFLOP/iter/pair of convs (MIOpen); informational")
+            cl = torch.channels_last
+            blk14 = blk14.to(memory_format=cl)
+            nets_cl = [t.contiguous(memory_format=cl) for t in nets]
+            inps_cl = [[t.contiguous(memory_format=cl) for t in lvl] for lvl in inps]
+            add("A14 one iteration B=8 @136x240 [channels-last: split-bf16 conv kernel, no concatenations]",
+                timeit(lambda: blk14(list(nets_cl), inps_cl, corr, flow), 3, 1), None, 8 * 168.0, bound="mfma",
+                note="fp32-equivalent flops; frac is against the f32 MFMA peak (157.3): the split-bf16 formulation is not bound by it")
+            import torch.nn as nn
+            from stereoformer_amd import conv_split as CS
+            for (nm, cs, co, relu) in (("convz|convr of gru08: [8,384,136,240] -> 128+128", (128, 128, 128), (128, 128), False),
+                                       ("flow_head.conv1|mask[0]: [8,128,136,240] -> 256+256 (+ReLU)", (128,), (256, 256), True),
+                                       ("encoder.conv: [8,64+64,136,240] -> 126 (+ReLU)", (64, 64), (126,), True)):
+                srcs = [torch.randn(8, c, Hr, Wr, device=dev).contiguous(memory_format=cl) for c in cs]
+                convs = [nn.Conv2d(sum(cs), c, 3, padding=1).to(dev).to(memory_format=cl) for c in co]
+                gf = 2 * 8 * Hr * Wr * sum(cs) * sum(co) * 9 / 1e9
+                ms = timeit(lambda: CS.conv_nhwc(srcs, convs, relu=relu), 10, 3)
+                add(f"A14 conv_split {nm}", ms, None, gf, bound="mfma",
+                    note=f"{gf / ms / (2500.0 / 6):.3f} of the split formulation's peak (dense bf16 2500 / 6 piece products)")
+                xc = torch.cat(srcs, 1)
+                add(f"A14 [library, for comparison] {nm}", timeit(lambda: [m(xc) for m in convs], 10, 3), None, gf, bound="mfma",
+                    note="MIOpen fp32 implicit GEMM on the pre-concatenated input (torch.cat and ReLU not included)")
+                del srcs, convs, xc
+            xs = torch.randn(8, 256, Hr, Wr, device=dev).contiguous(memory_format=cl)
+            ms_ = nn.Conv2d(256, 2, 3, padding=1).to(dev).to(memory_format=cl)
+            add("A14 flow_head.conv2 [8,256,136,240] -> 2 (fp32 vector kernel)", timeit(lambda: CS.conv3x3_small(xs, ms_), 10, 3),
+                (8 * 256 * Hr * Wr * 4) / 1e9, 2 * 8 * Hr * Wr * 256 * 2 * 9 / 1e9)
+            add("A14 [library, for comparison] flow_head.conv2", timeit(lambda: ms_(xs), 10, 3), (8 * 256 * Hr * Wr * 4) / 1e9)
+            del xs, ms_
         if want("bwd"):
             torch.set_grad_enabled(True)
             Lg, Rg = L.detach().requires_grad_(True), R.detach().requires_grad_(True)
