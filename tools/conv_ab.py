@@ -17,11 +17,11 @@ for (nm, B, H, W, cs, co, relu) in (("gru08 convz|convr [8,384,136,240] -> 128+1
     gf = 2 * B * H * W * sum(cs) * sum(co) * 9 / 1e9
     with torch.no_grad():
         ms = timeit(lambda: C.conv_nhwc(srcs, convs, relu=relu), 10, 3)
-        ms8 = ms4 = ms
+
         x = torch.cat(srcs, 1)
         ms_lib = timeit(lambda: [m(x) for m in convs], 10, 3)
         ms_lib_all = timeit(lambda: [torch.relu(m(torch.cat(srcs, 1))) if relu else m(torch.cat(srcs, 1)) for m in convs], 10, 3)
-    print(f"{nm}: split {ms:.3f} ms (8-row tiles {ms8:.3f}, 4-row tiles {ms4:.3f}) = {gf / ms:.0f} TFLOP/s fp32-equivalent | MIOpen convs alone {ms_lib:.3f} ms = {gf / ms_lib:.0f} | "
+    print(f"{nm}: split {ms:.3f} ms = {gf / ms:.0f} TFLOP/s fp32-equivalent | MIOpen convs alone {ms_lib:.3f} ms = {gf / ms_lib:.0f} | "
           f"MIOpen + cat (+ relu) {ms_lib_all:.3f} ms", flush=True)
 
 x = cl(torch.randn(8, 256, 136, 240, device="cuda"))
