@@ -75,7 +75,10 @@ def _gru_step_split(h, xs, conv_z, conv_r, conv_q, cz, cr, cq):
     """The ConvGRU update with its convolutions on ``conv_split`` (inference, channels-last fp32): ``convz`` and ``convr`` are
     ONE launch over the sources ``[h | x...]`` (no concatenation is materialised), ``convq`` a second one over
     ``[r * h | x...]``; same gate kernels as ``_gru_step``."""
-    z_pre, r_pre = conv_split.conv_nhwc([h, *xs], [conv_z, conv_r])
+    if conv_split.supported([h, *xs], [conv_z, conv_r]):
+        z_pre, r_pre = conv_split.conv_nhwc([h, *xs], [conv_z, conv_r])
+    else:   # hidden sizes that do not fill whole 128-channel output tiles: one launch per gate
+        (z_pre,), (r_pre,) = conv_split.conv_nhwc([h, *xs], [conv_z]), conv_split.conv_nhwc([h, *xs], [conv_r])
     gated = gru_reset(h, r_pre, cr)
     (q_pre,) = conv_split.conv_nhwc([gated, *xs], [conv_q])
     return gru_blend(h, z_pre, q_pre, cz, cq)
@@ -91,8 +94,8 @@ class ConvGRU(nn.Module):
             setattr(self, "conv" + gate, _conv(hidden_dim + input_dim, hidden_dim, kernel_size))
 
     def forward(self, h, cz, cr, cq, *x_list):
-        if (_split_ok(h, cz, cr, cq, *x_list) and conv_split.supported([h, *x_list], [self.convz, self.convr])
-                and conv_split.supported([h, *x_list], [self.convq])):
+        if (_split_ok(h, cz, cr, cq, *x_list) and conv_split.supported([h, *x_list], [self.convz])
+                and conv_split.supported([h, *x_list], [self.convr]) and conv_split.supported([h, *x_list], [self.convq])):
             return _gru_step_split(h, list(x_list), self.convz, self.convr, self.convq, cz, cr, cq)
         if _fp16_inference():
             x_list = [_to16(t) for t in x_list]   # cast the small pieces, not their concatenation
@@ -193,9 +196,12 @@ class BasicMultiUpdateBlock_LZH(nn.Module):
             return net
         h0 = net[0]
         heads = [self.flow_head.conv1] + ([self.mask[0]] if need_mask else [])
-        if _split_ok(h0) and conv_split.supported([h0], heads):
+        if _split_ok(h0) and all(conv_split.supported([h0], [m]) for m in heads):
             # flow_head.conv1 | mask[0] read the same hidden state: one launch, ReLU in the epilogue
-            outs = conv_split.conv_nhwc([h0], heads, relu=True)
+            if conv_split.supported([h0], heads):
+                outs = conv_split.conv_nhwc([h0], heads, relu=True)
+            else:
+                outs = [conv_split.conv_nhwc([h0], [m], relu=True)[0] for m in heads]
             mask = 0.25 * self.mask[2](outs[1]) if need_mask else None
             if conv_split.small_supported(outs[0], self.flow_head.conv2):
                 return net, mask, conv_split.conv3x3_small(outs[0], self.flow_head.conv2)   # 256 -> 2: fp32 FMAs, NCHW out

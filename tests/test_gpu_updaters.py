@@ -148,9 +148,14 @@ def test_raft_stereo_loop_end_to_end_g9(S, golden):
     assert (lo_g - flow_lo).abs().max().item() < 5e-5 and (up_g - flow_up).abs().max().item() < 1e-4
 
 
-def test_raft_loop_channels_last_matches_reference(S, golden):
-    """NHWC weights / activations through the update block: same arithmetic, so the golden outputs of the reference
-    RAFT_Stereo (G9) must still be reproduced at the fp32 parity tolerances."""
+def test_raft_loop_channels_last_matches_reference(S, golden, monkeypatch):
+    """NHWC weights / activations through the update block -- whose 3x3 convolutions then run on the split-bf16 matrix-core
+    kernel (csrc/conv_split.hip; asserted) -- must still reproduce the golden outputs of the reference RAFT_Stereo (G9) at the
+    fp32 parity tolerances."""
+    from stereoformer_amd import conv_split as C
+    calls = []
+    real = C.conv_nhwc
+    monkeypatch.setattr(C, "conv_nhwc", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     g = golden("g9_raft_loop")
     loop = S.RAFTStereoLoop(hidden_dims=[32, 32, 32], channels_last=True).eval()
     fill_state_dict_(loop.update_block, seed=0.125, keys=list(g["keys"]), prefix="update_block.")
@@ -161,6 +166,7 @@ def test_raft_loop_channels_last_matches_reference(S, golden):
         close(flow_lo, g["flow_lo"], rtol=1e-4, atol=1e-3)
         close(flow_up, g["flow_up"], rtol=1e-4, atol=2e-3)
         f1, f2, net, inp = _raft_inputs(g)
+        assert len(calls) >= 4 * (3 * 3 + 3 + 1)     # per iteration: 3 GRUs x (z, r, q), 3 encoder convolutions, the head(s)
         lo_g, up_g = loop(f1, f2, net, inp, iters=4, test_mode=True, use_graph=True)
         assert (up_g - flow_up).abs().max().item() < 1e-4
     assert flow_up.is_contiguous()
