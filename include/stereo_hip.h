@@ -328,6 +328,15 @@ int stereo_conv_pack_weights(const float *weight, void *packed, int Cout, int Ci
 int stereo_conv_nhwc_f32(const float *const *srcs, const int *src_channels, int nsrc, const void *packed, const float *bias,
                          float *const *outs, const int *out_channels, const int *out_strides, int nout, int ksize, int relu,
                          int B, int H, int W, void *stream);
+/* The same for fp16 activations (the update block under the reference's mixed_precision flag, raft_stereo.py:176: fp16 autocast
+ * around the block): sources and destinations fp16 channels-last, weights rounded to fp16 by stereo_conv_pack_weights_f16
+ * (what autocast hands the library), v_mfma_f32_32x32x16_f16 with fp32 accumulation, bias (fp32) added before the one rounding
+ * to fp16.  `packed` from stereo_conv_pack_weights_f16 / stereo_conv_packed_bytes_f16. */
+long long stereo_conv_packed_bytes_f16(int Cout, int Cin, int ksize);
+int stereo_conv_pack_weights_f16(const float *weight, void *packed, int Cout, int Cin, int ksize, void *stream);
+int stereo_conv_nhwc_f16(const void *const *srcs, const int *src_channels, int nsrc, const void *packed, const float *bias,
+                         void *const *outs, const int *out_channels, const int *out_strides, int nout, int ksize, int relu,
+                         int B, int H, int W, void *stream);
 
 /* 3x3 stride-1 "same" convolution with 1..4 output channels (flow_head.conv2, update.py:11-14: 256 -> 2) on the fp32 vector
  * units: x [B][H][W][Cin] channels-last (Cin % 32 == 0), weight_tco = weight.permute(2, 3, 1, 0) contiguous, i.e.

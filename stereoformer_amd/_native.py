@@ -64,7 +64,11 @@ SIGNATURES = {
     "stereo_relayout_nhwc_to_nchw": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_conv3x3_small_nhwc_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_conv_packed_bytes": [_i, _i, _i],
+    "stereo_conv_packed_bytes_f16": [_i, _i, _i],
     "stereo_conv_pack_weights": [_vp, _vp, _i, _i, _i, _vp],
+    "stereo_conv_pack_weights_f16": [_vp, _vp, _i, _i, _i, _vp],
+    "stereo_conv_nhwc_f16": [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_i),
+                             ctypes.POINTER(_i), _i, _i, _i, _i, _i, _i, _vp],
     "stereo_conv_nhwc_f32": [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_i),
                              ctypes.POINTER(_i), _i, _i, _i, _i, _i, _i, _vp],
     "stereo_soft_argmin_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -88,7 +92,8 @@ SIGNATURES = {
     "stereo_gru_blend_f16": [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp],
 }
 _RESTYPE = {"stereo_strerror": ctypes.c_char_p, "stereo_alt_corr_workspace_floats": _ll,
-            "stereo_instance_norm_workspace_bytes": _ll, "stereo_conv_packed_bytes": _ll}
+            "stereo_instance_norm_workspace_bytes": _ll, "stereo_conv_packed_bytes": _ll,
+            "stereo_conv_packed_bytes_f16": _ll}
 
 _lib = None
 

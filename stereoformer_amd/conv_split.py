@@ -22,7 +22,7 @@ def _is_cl(t):
 
 
 def supported(srcs, convs) -> bool:
-    """Channels-last fp32 HIP tensors without grad, every source channel count a multiple of 16 (<= 4 sources), 3x3 / 1x1 stride-1
+    """Channels-last fp32 (or all-fp16: the mixed_precision form) HIP tensors without grad, every source channel count a multiple of 16 (<= 4 sources), 3x3 / 1x1 stride-1
     'same' convolutions without groups or dilation, all but the last module with a multiple of 128 output channels, <= 512 in
     all."""
     if not (1 <= len(srcs) <= 4) or not convs:
@@ -31,8 +31,10 @@ def supported(srcs, convs) -> bool:
                                     any(p.requires_grad for m in convs if isinstance(m, torch.nn.Module) for p in m.parameters())):
         return False     # no autograd formula: training keeps the library convolutions
     t0 = srcs[0]
+    if not isinstance(t0, torch.Tensor) or t0.dtype not in (torch.float32, torch.float16):
+        return False
     for t in srcs:
-        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and _is_cl(t)):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == t0.dtype and _is_cl(t)):
             return False
         if t.shape[0] != t0.shape[0] or t.shape[2:] != t0.shape[2:] or t.shape[1] % 16 != 0 or t.shape[1] < 16:
             return False
@@ -77,9 +79,11 @@ def _cached(convs, tag, device, build):
     return val
 
 
-def _packed(convs, device):
-    """Packed split-bf16 weights (+ the concatenated bias) of a group of modules; rebuilt when a parameter is replaced or
-    updated in place."""
+def _packed(convs, device, half=False):
+    """Packed weights (split-bf16 pieces for fp32 activations, fp16 for fp16 ones; + the concatenated fp32 bias) of a group of
+    modules; rebuilt when a parameter is replaced or updated in place."""
+    sfx = "_f16" if half else ""
+
     def build():
         with torch.no_grad():
             w = torch.cat([m.weight.detach().contiguous() for m in convs], 0).contiguous()
@@ -88,18 +92,19 @@ def _packed(convs, device):
                 bias = torch.cat([m.bias.detach() if m.bias is not None else torch.zeros(m.out_channels, device=device)
                                   for m in convs]).contiguous()
             cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
-            nbytes = N.load().stereo_conv_packed_bytes(cout, cin, k)
+            nbytes = getattr(N.load(), "stereo_conv_packed_bytes" + sfx)(cout, cin, k)
             if nbytes <= 0:
                 raise ValueError(f"conv_nhwc: unsupported weight shape {tuple(w.shape)}")
             packed = torch.empty(nbytes, device=device, dtype=torch.uint8)
             with torch.cuda.device(device):
-                N.call("stereo_conv_pack_weights", N.ptr(w), N.ptr(packed), cout, cin, k, N.stream_ptr(device))
+                N.call("stereo_conv_pack_weights" + sfx, N.ptr(w), N.ptr(packed), cout, cin, k, N.stream_ptr(device))
         return packed, bias, k
-    return _cached(convs, "split", device, build)
+    return _cached(convs, "split" + sfx, device, build)
 
 
 def conv_nhwc(srcs, convs, relu=False, out_channels_total=None):
-    """``[m(torch.cat(srcs, 1)) for m in convs]`` (optionally followed by ReLU), channels-last fp32 in and out, one launch.
+    """``[m(torch.cat(srcs, 1)) for m in convs]`` (optionally followed by ReLU), channels-last fp32 (or fp16: what the modules give
+    under fp16 autocast) in and out, one launch.
     ``out_channels_total`` (single module only): allocate the output with that many channels and fill the first
     ``out_channels`` of them -- the caller owns the rest (the motion encoder appends the 2 flow channels, update.py:89-91)."""
     srcs = list(srcs)
@@ -109,17 +114,19 @@ def conv_nhwc(srcs, convs, relu=False, out_channels_total=None):
     if out_channels_total is not None and (len(convs) != 1 or out_channels_total < convs[0].out_channels):
         raise ValueError("conv_nhwc: out_channels_total applies to one module and must cover its output channels")
     dev = srcs[0].device
-    packed, bias, k = _packed(convs, dev)
+    half = srcs[0].dtype == torch.float16
+    packed, bias, k = _packed(convs, dev, half)
     B, _, H, W = srcs[0].shape
     widths = [m.out_channels for m in convs] if out_channels_total is None else [int(out_channels_total)]
-    outs = [torch.empty((B, c, H, W), device=dev, dtype=torch.float32, memory_format=torch.channels_last) for c in widths]
+    outs = [torch.empty((B, c, H, W), device=dev, dtype=srcs[0].dtype, memory_format=torch.channels_last) for c in widths]
     sp = (N._vp * len(srcs))(*[t.data_ptr() for t in srcs])
     sc = (N._i * len(srcs))(*[t.shape[1] for t in srcs])
     op = (N._vp * len(outs))(*[t.data_ptr() for t in outs])
     oc = (N._i * len(outs))(*[m.out_channels for m in convs])
     os_ = (N._i * len(outs))(*widths)
     with torch.cuda.device(dev):
-        N.call("stereo_conv_nhwc_f32", sp, sc, len(srcs), N.ptr(packed), N.ptr(bias), op, oc, os_, len(outs), k,
+        N.call("stereo_conv_nhwc_f16" if half else "stereo_conv_nhwc_f32", sp, sc, len(srcs), N.ptr(packed), N.ptr(bias), op, oc, os_,
+               len(outs), k,
                1 if relu else 0, B, H, W, N.stream_ptr(dev))
     return outs
 

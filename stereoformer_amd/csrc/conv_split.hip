@@ -31,21 +31,46 @@ constexpr int CV_PXB = 48;             // LDS bytes per pixel and piece: 16 chan
 constexpr int CV_MAXSRC = 4, CV_MAXNT = 4;
 
 struct ConvSrcs {
-    const float *p[CV_MAXSRC];
+    const void *p[CV_MAXSRC];
     int c[CV_MAXSRC];
     int n;
 };
 struct ConvDsts {          // one entry per N tile of 128 output channels
-    float *p[CV_MAXNT];
+    void *p[CV_MAXNT];
     int stride[CV_MAXNT];  // channels of the destination tensor (pixel stride)
     int coff[CV_MAXNT];    // first channel of this tile inside it
     int nvalid[CV_MAXNT];  // output channels of this tile that exist (<= 128)
 };
 
-// weights [Cout][Cin][KS][KS] fp32 -> packed[(((chunk * TAPS + tap) * NB + nb) * 3 + piece) * 64 + lane][8] bf16, where lane l of
-// n block nb holds output channel 32 nb + (l & 31), input channels 16 chunk + 8 (l >> 5) + 0..7 (the MFMA's B fragment)
-__global__ void conv_pack_kernel(const float *__restrict__ w, __bf16 *__restrict__ packed, int Cout, int Cin, int taps, int NB)
+// Operand formulation by activation type.  float: three bf16 pieces per value, six piece products (fp32-faithful).  f16 (the
+// update block under the reference's mixed_precision flag, raft_stereo.py:176: fp16 autocast): the values ARE the operands of
+// v_mfma_f32_32x32x16_f16 -- one product, fp32 accumulation, fp16 output, what the library's fp16 convolution computes.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <typename TIN>
+struct ConvOp;
+template <>
+struct ConvOp<float> {
+    static constexpr int NP = 3, QCH = 4;   // pieces; channels per 16-B quad
+    typedef bf16x8 frag;
+    typedef __bf16 welem;
+    static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct ConvOp<f16> {
+    static constexpr int NP = 1, QCH = 8;
+    typedef f16x8 frag;
+    typedef _Float16 welem;
+    static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+// weights [Cout][Cin][KS][KS] fp32 -> packed[(((chunk * TAPS + tap) * NB + nb) * NP + piece) * 64 + lane][8], where lane l of
+// n block nb holds output channel 32 nb + (l & 31), input channels 16 chunk + 8 (l >> 5) + 0..7 (the MFMA's B fragment);
+// float activations: NP = 3 bf16 pieces; f16 activations: the weight rounded to fp16 (what autocast hands the library)
+template <typename TIN>
+__global__ void conv_pack_kernel(const float *__restrict__ w, typename ConvOp<TIN>::welem *__restrict__ packed, int Cout, int Cin,
+                                 int taps, int NB)
 {
+    constexpr int NP = ConvOp<TIN>::NP;
     const long long total = (long long)(Cin / 16) * taps * NB * 64;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -54,31 +79,44 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, __bf16 *__restrict
     const int tap = (int)((i / 64 / NB) % taps);
     const int chunk = (int)(i / 64 / NB / taps);
     const int n = 32 * nb + (lane & 31);
-    bf16x8 pc[3];
     float x[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = 16 * chunk + 8 * (lane >> 5) + j;
         x[j] = n < Cout ? w[((size_t)n * Cin + c) * taps + tap] : 0.0f;
     }
-    split_oct<3>(x, pc);
-    const size_t base = ((((size_t)chunk * taps + tap) * NB + nb) * 3) * 64 + lane;
+    const size_t base = ((((size_t)chunk * taps + tap) * NB + nb) * NP) * 64 + lane;
+    if constexpr (NP == 3) {
+        bf16x8 pc[3];
+        split_oct<3>(x, pc);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8 *>(packed + (base + (size_t)p * 64) * 8) = pc[p];
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8 *>(packed + (base + (size_t)p * 64) * 8) = pc[p];
+    } else {
+        f16x8 h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = (_Float16)x[j];
+        *reinterpret_cast<f16x8 *>(packed + base * 8) = h;
+    }
 }
 
-template <int KS, int TH>
-__global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSrcs src, const __bf16 *__restrict__ packed,
-                                                         const float *__restrict__ bias, ConvDsts dst, int relu, int H, int W,
-                                                         int tiles_x, int tiles_y, int NB, int Cout, int ntn)
+template <int KS, int TH, typename TIN>
+__global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSrcs src,
+                                                                           const typename ConvOp<TIN>::welem *__restrict__ packed,
+                                                                           const float *__restrict__ bias, ConvDsts dst, int relu,
+                                                                           int H, int W, int tiles_x, int tiles_y, int NB, int Cout,
+                                                                           int ntn)
 {
+    typedef ConvOp<TIN> Op;
+    typedef typename Op::frag frag;
+    typedef typename Op::welem welem;
+    constexpr int NP = Op::NP, QCH = Op::QCH, QPP = 16 / QCH, ES = (int)sizeof(TIN);
     constexpr int HALO = KS / 2, TAPS = KS * KS;
     constexpr int WN = TH == 8 ? 2 : 4;          // waves along the output channels (the other 4 / WN along the rows)
     constexpr int NBW = 4 / WN;                  // 32-channel N blocks per wave
     constexpr int HCOLS = CV_TW + 2 * HALO, HROWS = TH + 2 * HALO, NPX = HROWS * HCOLS;
     constexpr int PS = NPX * CV_PXB;             // piece stride (bytes)
-    constexpr int NQ = NPX * 4, NPASS = (NQ + 255) / 256;
-    __shared__ __attribute__((aligned(16))) char img[3 * PS];
+    constexpr int NQ = NPX * QPP, NPASS = (NQ + 255) / 256;   // 16-B quads of the halo tile's chunk
+    __shared__ __attribute__((aligned(16))) char img[NP * PS];
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l31 = lane & 31, half = lane >> 5;
@@ -96,22 +134,23 @@ __global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSr
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
         const int q = tid + 256 * i;
-        const int px = q >> 2, cq = q & 3;
+        const int px = q / QPP, cq = q % QPP;
         const int hy = px / HCOLS, hx = px - hy * HCOLS;
         const int y = y0 - HALO + hy, x = x0 - HALO + hx;
         pix[i] = (q < NQ && y >= 0 && y < H && x >= 0 && x < W) ? y * W + x : -1;
-        lw[i] = q < NQ ? px * CV_PXB + cq * 8 : -1;
+        lw[i] = q < NQ ? px * CV_PXB + cq * QCH * 2 : -1;
     }
-    f32x4 rk[NPASS];
+    u32x4_t rk[NPASS];   // raw 16-B quads: 4 floats / 8 halves
     int is_s = 0, is_c = 0;  // source / first channel of the chunk to issue next
     auto issue = [&]() {
         const int Cs = src.c[is_s];
-        const __amdgpu_buffer_rsrc_t rs = buffer_rsrc(src.p[is_s] + (size_t)b * H * W * Cs, (unsigned)H * (unsigned)W * (unsigned)Cs * 4u);
+        const __amdgpu_buffer_rsrc_t rs = buffer_rsrc(static_cast<const TIN *>(src.p[is_s]) + (size_t)b * H * W * Cs,
+                                                      (unsigned)H * (unsigned)W * (unsigned)Cs * (unsigned)ES);
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             // 0x80000000: beyond any image of < 2 GB (launcher), whatever the chunk offset added to it
-            const int voff = pix[i] >= 0 ? (pix[i] * Cs + is_c + 4 * (tid & 3)) * 4 : (int)0x80000000;
-            rk[i] = BufLd<float>::quad(rs, voff, 0);
+            const int voff = pix[i] >= 0 ? (pix[i] * Cs + is_c + QCH * (tid % QPP)) * ES : (int)0x80000000;
+            rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
         }
         is_c += 16;
         if (is_c >= Cs) is_c = 0, ++is_s;
@@ -120,11 +159,16 @@ __global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSr
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             if (lw[i] >= 0) {
-                bf16x2 a[3], c[3];
-                split_pair<3>((f32x2){rk[i][0], rk[i][1]}, a);
-                split_pair<3>((f32x2){rk[i][2], rk[i][3]}, c);
+                if constexpr (NP == 3) {
+                    const f32x4 v = __builtin_bit_cast(f32x4, rk[i]);
+                    bf16x2 a[3], c[3];
+                    split_pair<3>((f32x2){v[0], v[1]}, a);
+                    split_pair<3>((f32x2){v[2], v[3]}, c);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4 *>(img + p * PS + lw[i]) = cat2(a[p], c[p]);
+                    for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4 *>(img + p * PS + lw[i]) = cat2(a[p], c[p]);
+                } else {
+                    *reinterpret_cast<u32x4_t *>(img + lw[i]) = rk[i];
+                }
             }
         }
     };
@@ -148,8 +192,8 @@ __global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSr
     // A fragment of (mb, tap (ky, kx), piece p): that pixel shifted by the tap in the halo tile, channels 8 half ..
     const char *abase = img + ((4 * wm + (l31 >> 4)) * HCOLS + (l31 & 15)) * CV_PXB + half * 16;
     // B fragments of this wave: n blocks 4 nt + NBW wn + {0 .. NBW - 1}
-    const __bf16 *wbase = packed + ((size_t)(4 * nt + NBW * wn) * 3 * 64 + lane) * 8;
-    const size_t kstep = (size_t)NB * 3 * 64 * 8;   // elements per k-step (one tap of one chunk)
+    const welem *wbase = packed + ((size_t)(4 * nt + NBW * wn) * NP * 64 + lane) * 8;
+    const size_t kstep = (size_t)NB * NP * 64 * 8;   // elements per k-step (one tap of one chunk)
 
     // which of this wave's four M blocks lie inside the image (wave-uniform): all of them (the common case), the left column
     // half only (last tile of a row whose width is 16 mod 32), or some other subset (bottom edge)
@@ -161,34 +205,35 @@ __global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSr
     // one chunk's 9 taps; MODE selects the M blocks.  (Four waves per SIMD hide the dependent six-MFMA chain of a block; a
     // variant that alternated two blocks' chains and fetched the B fragments a tap ahead needed 142 registers -- three waves per
     // SIMD -- and measured 4 % slower.)
-    auto load_b = [&](bf16x8 (&bf)[NBW][3], const __bf16 *wt) {
+    auto load_b = [&](frag (&bf)[NBW][NP], const welem *wt) {
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[nb][p] = *reinterpret_cast<const bf16x8 *>(wt + ((size_t)nb * 3 + p) * 64 * 8);
+            for (int p = 0; p < NP; ++p) bf[nb][p] = *reinterpret_cast<const frag *>(wt + ((size_t)nb * NP + p) * 64 * 8);
     };
-    auto load_a = [&](bf16x8 (&af)[3], int mb, int ky, int kx) {
+    auto load_a = [&](frag (&af)[NP], int mb, int ky, int kx) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-            af[p] = *reinterpret_cast<const bf16x8 *>(abase + p * PS + ((2 * (mb >> 1) + ky) * HCOLS + 16 * (mb & 1) + kx) * CV_PXB);
+        for (int p = 0; p < NP; ++p)
+            af[p] = *reinterpret_cast<const frag *>(abase + p * PS + ((2 * (mb >> 1) + ky) * HCOLS + 16 * (mb & 1) + kx) * CV_PXB);
     };
     // piece products, smallest first: (a1 b1) (a0 b2) (a2 b0) (a0 b1) (a1 b0) (a0 b0)
-    constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
-    auto single = [&](int m0, int ky, int kx, const bf16x8 (&bf)[NBW][3]) {
-        bf16x8 a0[3];
+    constexpr int NPROD = NP == 3 ? 6 : 1;
+    constexpr int PA[6] = {NP == 3 ? 1 : 0, 0, NP == 3 ? 2 : 0, 0, NP == 3 ? 1 : 0, 0};
+    constexpr int PB[6] = {NP == 3 ? 1 : 0, NP == 3 ? 2 : 0, 0, NP == 3 ? 1 : 0, 0, 0};
+    auto single = [&](int m0, int ky, int kx, const frag (&bf)[NBW][NP]) {
+        frag a0[NP];
         load_a(a0, m0, ky, kx);
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
+        for (int q = 6 - NPROD; q < 6; ++q)     // (one piece: the last entry, a0 b0)
 #pragma unroll
-            for (int nb = 0; nb < NBW; ++nb)
-                acc[m0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[PA[q]], bf[nb][PB[q]], acc[m0][nb], 0, 0, 0);
+            for (int nb = 0; nb < NBW; ++nb) acc[m0][nb] = Op::mma(a0[PA[q]], bf[nb][PB[q]], acc[m0][nb]);
     };
-    auto chunk = [&](auto mode_tag, const __bf16 *wk) {
+    auto chunk = [&](auto mode_tag, const welem *wk) {
         constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int ky = tap / KS, kx = tap % KS;
-            bf16x8 bc[NBW][3];
+            frag bc[NBW][NP];
             load_b(bc, wk + (size_t)tap * kstep);
             if (MODE == 0) {
 #pragma unroll
@@ -227,7 +272,7 @@ __global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSr
 
     // ---- epilogue: register r of lane (l31, half) holds MFMA row i = (r & 3) + 8 (r >> 2) + 4 half of its M block, i.e. pixel
     // (row + (r >> 3), 16 ch + (r & 3) + 8 ((r >> 2) & 1) + 4 half), output channel 32 (NBW wn + nb) + l31: a 128-B row per store
-    float *ob = dst.p[nt];
+    TIN *ob = static_cast<TIN *>(dst.p[nt]);
     const int ostride = dst.stride[nt], coff = dst.coff[nt], nvalid = dst.nvalid[nt];
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
@@ -243,7 +288,7 @@ __global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSr
                     const int x = x0 + 16 * (mb & 1) + (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
                     float v = acc[mb][nb][r] + bv;
                     if (relu) v = fmaxf(v, 0.0f);
-                    if (y < H && x < W) ob[(((size_t)b * H + y) * W + x) * ostride + coff + cl] = v;
+                    if (y < H && x < W) ob[(((size_t)b * H + y) * W + x) * ostride + coff + cl] = (TIN)v;
                 }
             }
         }
@@ -341,30 +386,35 @@ extern "C" int stereo_conv3x3_small_nhwc_f32(const float *x, const float *weight
     return STEREO_OK;
 }
 
-extern "C" long long stereo_conv_packed_bytes(int Cout, int Cin, int ksize)
+namespace {
+
+template <typename TIN>
+long long packed_bytes(int Cout, int Cin, int ksize)
 {
     if (Cout < 1 || Cin < 16 || Cin % 16 != 0 || (ksize != 1 && ksize != 3)) return 0;
     const long long NB = 4LL * ((Cout + 127) / 128);
-    return (long long)(Cin / 16) * ksize * ksize * NB * 3 * 64 * 8 * 2;
+    return (long long)(Cin / 16) * ksize * ksize * NB * ConvOp<TIN>::NP * 64 * 8 * 2;
 }
 
-extern "C" int stereo_conv_pack_weights(const float *weight, void *packed, int Cout, int Cin, int ksize, void *stream)
+template <typename TIN>
+int pack_weights(const float *weight, void *packed, int Cout, int Cin, int ksize, void *stream)
 {
-    if (stereo_conv_packed_bytes(Cout, Cin, ksize) == 0) return STEREO_ERR_BAD_SHAPE;
+    if (packed_bytes<TIN>(Cout, Cin, ksize) == 0) return STEREO_ERR_BAD_SHAPE;
     STEREO_REQUIRE_PTR(weight);
     STEREO_REQUIRE_PTR(packed);
     if (!aligned16(packed)) return STEREO_ERR_UNSUPPORTED;
     const int NB = 4 * ((Cout + 127) / 128), taps = ksize * ksize;
     const long long total = (long long)(Cin / 16) * taps * NB * 64;
-    hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), weight,
-                       static_cast<__bf16 *>(packed), Cout, Cin, taps, NB);
+    hipLaunchKernelGGL(conv_pack_kernel<TIN>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), weight,
+                       static_cast<typename ConvOp<TIN>::welem *>(packed), Cout, Cin, taps, NB);
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }
 
-extern "C" int stereo_conv_nhwc_f32(const float *const *srcs, const int *src_channels, int nsrc, const void *packed,
-                                    const float *bias, float *const *outs, const int *out_channels, const int *out_strides,
-                                    int nout, int ksize, int relu, int B, int H, int W, void *stream)
+template <typename TIN>
+int conv_nhwc(const void *const *srcs, const int *src_channels, int nsrc, const void *packed, const float *bias,
+              void *const *outs, const int *out_channels, const int *out_strides, int nout, int ksize, int relu, int B, int H,
+              int W, void *stream)
 {
     if (nsrc < 1 || nsrc > CV_MAXSRC || nout < 1 || nout > CV_MAXNT || (ksize != 1 && ksize != 3) || B < 0 || H < 0 || W < 0)
         return STEREO_ERR_BAD_SHAPE;
@@ -374,14 +424,13 @@ extern "C" int stereo_conv_nhwc_f32(const float *const *srcs, const int *src_cha
     ConvSrcs s{};
     ConvDsts d{};
     s.n = nsrc;
-    int Cin = 0;
     for (int i = 0; i < nsrc; ++i) {
         STEREO_REQUIRE_PTR(srcs[i]);
         if (src_channels[i] < 16 || src_channels[i] % 16 != 0) return STEREO_ERR_UNSUPPORTED;
-        if (!aligned16(srcs[i]) || (long long)H * W * src_channels[i] * 4 >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
+        if (!aligned16(srcs[i]) || (long long)H * W * src_channels[i] * (long long)sizeof(TIN) >= (1LL << 31))
+            return STEREO_ERR_UNSUPPORTED;
         s.p[i] = srcs[i];
         s.c[i] = src_channels[i];
-        Cin += src_channels[i];
     }
     // destinations: every one but the last must fill whole 128-channel N tiles
     int Cout = 0, ntn = 0;
@@ -401,7 +450,6 @@ extern "C" int stereo_conv_nhwc_f32(const float *const *srcs, const int *src_cha
         Cout += c;
     }
     const int NB = 4 * ((Cout + 127) / 128);
-    (void)Cin;
     const int tiles_x = (W + CV_TW - 1) / CV_TW;
     // pixel tile: 4 rows x 32 columns, a wave = 4 rows x 32 output channels (an 8-row tile with 64 channels per wave measured equal
     // at the large shapes and 7-18 % behind at 1/8 and 1/16 scale: finer workgroups spread a launch more evenly over the chip)
@@ -410,12 +458,39 @@ extern "C" int stereo_conv_nhwc_f32(const float *const *srcs, const int *src_cha
     const long long nt = (long long)tiles_x * tiles_y * B;
     if (nt * ntn >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
     dim3 grid((unsigned)(nt * ntn));
-#define CONV_LAUNCH(KSV)                                                                                                  \
-    hipLaunchKernelGGL((conv_split_kernel<KSV, th>), grid, dim3(256), 0, as_stream(stream), s, static_cast<const __bf16 *>(packed), \
+    typedef typename ConvOp<TIN>::welem welem;
+#define CONV_LAUNCH(KSV)                                                                                                        \
+    hipLaunchKernelGGL((conv_split_kernel<KSV, th, TIN>), grid, dim3(256), 0, as_stream(stream), s, static_cast<const welem *>(packed), \
                        bias, d, relu, H, W, tiles_x, tiles_y, NB, Cout, ntn)
     if (ksize == 3) CONV_LAUNCH(3);
     else CONV_LAUNCH(1);
 #undef CONV_LAUNCH
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
+}
+
+}  // namespace
+
+extern "C" long long stereo_conv_packed_bytes(int Cout, int Cin, int ksize) { return packed_bytes<float>(Cout, Cin, ksize); }
+extern "C" long long stereo_conv_packed_bytes_f16(int Cout, int Cin, int ksize) { return packed_bytes<f16>(Cout, Cin, ksize); }
+extern "C" int stereo_conv_pack_weights(const float *weight, void *packed, int Cout, int Cin, int ksize, void *stream)
+{
+    return pack_weights<float>(weight, packed, Cout, Cin, ksize, stream);
+}
+extern "C" int stereo_conv_pack_weights_f16(const float *weight, void *packed, int Cout, int Cin, int ksize, void *stream)
+{
+    return pack_weights<f16>(weight, packed, Cout, Cin, ksize, stream);
+}
+extern "C" int stereo_conv_nhwc_f32(const float *const *srcs, const int *src_channels, int nsrc, const void *packed,
+                                    const float *bias, float *const *outs, const int *out_channels, const int *out_strides,
+                                    int nout, int ksize, int relu, int B, int H, int W, void *stream)
+{
+    return conv_nhwc<float>(reinterpret_cast<const void *const *>(srcs), src_channels, nsrc, packed, bias,
+                            reinterpret_cast<void *const *>(outs), out_channels, out_strides, nout, ksize, relu, B, H, W, stream);
+}
+extern "C" int stereo_conv_nhwc_f16(const void *const *srcs, const int *src_channels, int nsrc, const void *packed,
+                                    const float *bias, void *const *outs, const int *out_channels, const int *out_strides,
+                                    int nout, int ksize, int relu, int B, int H, int W, void *stream)
+{
+    return conv_nhwc<f16>(srcs, src_channels, nsrc, packed, bias, outs, out_channels, out_strides, nout, ksize, relu, B, H, W, stream);
 }

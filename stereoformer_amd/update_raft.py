@@ -64,10 +64,14 @@ def _gru_step(h, x, conv_z, conv_r, conv_q, cz=None, cr=None, cq=None):
 
 
 def _split_ok(*ts):
-    """Inference on channels-last fp32 HIP activations outside autocast: the envelope of ``conv_split.conv_nhwc``."""
-    if torch.is_grad_enabled() or torch.is_autocast_enabled("cuda"):
+    """Inference on channels-last HIP activations -- fp32 outside autocast (the parity configuration: split-bf16 arithmetic), or
+    all-fp16 inside an fp16 autocast region (``mixed_precision``: native fp16 MFMA): the envelope of ``conv_split.conv_nhwc``."""
+    if torch.is_grad_enabled():
         return False
-    return all(t is None or (t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and not t.is_contiguous()
+    want = torch.float16 if _fp16_inference() else (None if torch.is_autocast_enabled("cuda") else torch.float32)
+    if want is None:
+        return False
+    return all(t is None or (t.is_cuda and t.dtype == want and t.dim() == 4 and not t.is_contiguous()
                              and t.is_contiguous(memory_format=torch.channels_last)) for t in ts)
 
 
@@ -94,11 +98,12 @@ class ConvGRU(nn.Module):
             setattr(self, "conv" + gate, _conv(hidden_dim + input_dim, hidden_dim, kernel_size))
 
     def forward(self, h, cz, cr, cq, *x_list):
+        if _fp16_inference():
+            h, cz, cr, cq = _to16(h), _to16(cz), _to16(cr), _to16(cq)
+            x_list = [_to16(t) for t in x_list]   # cast the small pieces, not their concatenation
         if (_split_ok(h, cz, cr, cq, *x_list) and conv_split.supported([h, *x_list], [self.convz])
                 and conv_split.supported([h, *x_list], [self.convr]) and conv_split.supported([h, *x_list], [self.convq])):
             return _gru_step_split(h, list(x_list), self.convz, self.convr, self.convq, cz, cr, cq)
-        if _fp16_inference():
-            x_list = [_to16(t) for t in x_list]   # cast the small pieces, not their concatenation
         return _gru_step(h, torch.cat(x_list, 1), self.convz, self.convr, self.convq, cz, cr, cq)
 
 
@@ -144,7 +149,7 @@ class BasicMotionEncoder_LZH(nn.Module):
 
     def forward(self, flow, corr):
         c1, f1 = F.relu(self.convc1(corr)), F.relu(self.convf1(flow))   # 1x1 over 36 and 7x7 over 2 channels: the library's
-        if (_split_ok(c1, f1, flow) and conv_split.supported([c1], [self.convc2]) and conv_split.supported([f1], [self.convf2])
+        if (_split_ok(c1, f1) and conv_split.supported([c1], [self.convc2]) and conv_split.supported([f1], [self.convf2])
                 and conv_split.supported([c1, f1], [self.conv])):
             (c,) = conv_split.conv_nhwc([c1], [self.convc2], relu=True)
             (f,) = conv_split.conv_nhwc([f1], [self.convf2], relu=True)

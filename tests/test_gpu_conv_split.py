@@ -145,3 +145,29 @@ def test_conv3x3_small_output_channels(S, case):
     r = F.conv2d(x.double().cpu(), m.weight.detach().double().cpu(), m.bias.detach().double().cpu(), padding=1)
     assert o.shape == r.shape and o.is_contiguous()
     assert float((o.double().cpu() - r).abs().max()) <= 5e-6 * float(r.abs().max()) + 2e-6   # sequential fp32 sums of 9 Cin terms
+
+
+@pytest.mark.parametrize("case", [(2, 11, 37, (16, 32), (128, 40), 3, True), (1, 17, 60, (128, 128, 128), (128, 128), 3, False),
+                                  (1, 6, 70, (32, 16, 16, 64), (24,), 1, False)])
+def test_conv_nhwc_fp16_activations(S, case):
+    """The mixed_precision form: fp16 channels-last activations, weights rounded to fp16, fp32 accumulation, one rounding of
+    the output -- against the fp64 convolution of the SAME rounded operands (error = the output's fp16 rounding) and against the
+    library's fp16 convolution under autocast."""
+    from stereoformer_amd import conv_split as C
+    B, H, W, cs, co, k, relu = case
+    torch.manual_seed(86)
+    srcs = [_cl(torch.randn(B, c, H, W, device="cuda").half()) for c in cs]
+    convs = [nn.Conv2d(sum(cs), c, k, padding=k // 2).cuda() for c in co]
+    with torch.no_grad():
+        assert C.supported(srcs, convs)
+        outs = C.conv_nhwc(srcs, convs, relu=relu)
+        with torch.autocast("cuda", dtype=torch.float16):
+            lib = [m(torch.cat(srcs, 1)) for m in convs]
+    x = torch.cat([s.double().cpu() for s in srcs], 1)
+    for o, l, m in zip(outs, lib, convs):
+        r = F.conv2d(x, m.weight.detach().half().double().cpu(), m.bias.detach().double().cpu(), padding=m.padding)
+        r = F.relu(r) if relu else r
+        assert o.dtype == torch.float16 and o.is_contiguous(memory_format=torch.channels_last)
+        scale = float(r.abs().max())
+        assert float((o.double().cpu() - r).abs().max()) <= 6e-4 * scale + 1e-4          # half an fp16 ulp at the output's scale
+        assert float((o.float() - (F.relu(l) if relu else l).float()).abs().max()) <= 2e-3 * scale + 1e-3
