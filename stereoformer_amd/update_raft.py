@@ -66,7 +66,7 @@ def _gru_step(h, x, conv_z, conv_r, conv_q, cz=None, cr=None, cq=None):
 def _split_ok(*ts):
     """Inference on channels-last HIP activations -- fp32 outside autocast (the parity configuration: split-bf16 arithmetic), or
     all-fp16 inside an fp16 autocast region (``mixed_precision``: native fp16 MFMA): the envelope of ``conv_split.conv_nhwc``."""
-    if torch.is_grad_enabled():
+    if torch.is_grad_enabled() or torch.compiler.is_compiling():   # (a traced graph keeps the library convolutions)
         return False
     want = torch.float16 if _fp16_inference() else (None if torch.is_autocast_enabled("cuda") else torch.float32)
     if want is None:
