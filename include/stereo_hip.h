@@ -343,6 +343,10 @@ int stereo_conv_nhwc_f16(const void *const *srcs, const int *src_channels, int n
  * [3][3][Cin][Cout]; bias [Cout] or NULL; out_nchw [B][Cout][H][W]. */
 int stereo_conv3x3_small_nhwc_f32(const float *x, const float *weight_tco, const float *bias, float *out_nchw, int B, int Cin,
                                   int Cout, int H, int W, void *stream);
+/* fp16 channels-last activations (mixed_precision), widened on the way into LDS; weights / bias / output fp32 as above (the
+ * caller rounds the weights to fp16 first if it wants the library's autocast numerics). */
+int stereo_conv3x3_small_nhwc_f16(const void *x, const float *weight_tco, const float *bias, float *out_nchw, int B, int Cin,
+                                  int Cout, int H, int W, void *stream);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,7 @@ SIGNATURES = {
     "stereo_instance_norm_relu_nhwc": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "stereo_relayout_nhwc_to_nchw": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_conv3x3_small_nhwc_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "stereo_conv3x3_small_nhwc_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_conv_packed_bytes": [_i, _i, _i],
     "stereo_conv_packed_bytes_f16": [_i, _i, _i],
     "stereo_conv_pack_weights": [_vp, _vp, _i, _i, _i, _vp],

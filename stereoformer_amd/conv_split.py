@@ -137,18 +137,22 @@ def small_supported(x, conv) -> bool:
         return False
     return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
             and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros" and conv.out_channels <= 4
-            and conv.weight.dtype == torch.float32 and x.is_cuda and x.dtype == torch.float32 and _is_cl(x)
+            and conv.weight.dtype == torch.float32 and x.is_cuda and x.dtype in (torch.float32, torch.float16) and _is_cl(x)
             and x.shape[1] == conv.in_channels and x.shape[1] % 32 == 0 and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 2 ** 31)
 
 
 def conv3x3_small(x, conv):
-    """``conv(x)`` for a 3x3 convolution with <= 4 output channels (``flow_head.conv2``): channels-last in, NCHW-contiguous out."""
+    """``conv(x)`` for a 3x3 convolution with <= 4 output channels (``flow_head.conv2``): channels-last fp32 / fp16 in,
+    NCHW-contiguous fp32 out."""
     if not small_supported(x, conv):
         raise ValueError("conv3x3_small: operands outside the kernel's envelope (see conv_split.small_supported)")
-    wt = _cached([conv], "tco", x.device, lambda: conv.weight.detach().permute(2, 3, 1, 0).contiguous())   # [3][3][Cin][Cout]
+    half = x.dtype == torch.float16   # mixed_precision: the weights rounded to fp16 as autocast hands them to the library
+    wt = _cached([conv], "tco16" if half else "tco", x.device,
+                 lambda: (conv.weight.detach().half().float() if half else conv.weight.detach()).permute(2, 3, 1, 0).contiguous())
     B, C, H, W = x.shape
     out = torch.empty((B, conv.out_channels, H, W), device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
-        N.call("stereo_conv3x3_small_nhwc_f32", N.ptr(x), N.ptr(wt), N.ptr(None if conv.bias is None else conv.bias.detach()),
+        N.call("stereo_conv3x3_small_nhwc_f16" if half else "stereo_conv3x3_small_nhwc_f32", N.ptr(x), N.ptr(wt),
+               N.ptr(None if conv.bias is None else conv.bias.detach()),
                N.ptr(out), B, C, conv.out_channels, H, W, N.stream_ptr(x.device))
     return out

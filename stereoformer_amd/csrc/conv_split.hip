@@ -300,13 +300,14 @@ __global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSr
 // thread owns one pixel of an 8 x 32 tile, the halo tile goes through LDS 32 input channels at a time ([pixel][32 + 4 pad]:
 // conflict-free 16-B reads), the weights are wave-uniform (scalar loads).  Channels-last in, NCHW out (the consumer adds the
 // result to the NCHW coordinate grid).
-template <int COUT>
-__global__ __launch_bounds__(256) void conv3x3_small_kernel(const float *__restrict__ x, const float *__restrict__ wt,
+template <int COUT, typename TIN>
+__global__ __launch_bounds__(256) void conv3x3_small_kernel(const TIN *__restrict__ x, const float *__restrict__ wt,
                                                             const float *__restrict__ bias, float *__restrict__ out, int Cin,
                                                             int H, int W, int tiles_x, int tiles_y)
 {
     constexpr int HC = 34, HR = 10, NPX = HC * HR, PXS = 36;   // halo tile, floats per pixel in LDS
-    constexpr int NQ = NPX * 8, NPASS = (NQ + 255) / 256;
+    constexpr int ES = (int)sizeof(TIN), QCH = 16 / ES, QPP = 32 / QCH;   // channels per 16-B quad, quads per pixel and chunk
+    constexpr int NQ = NPX * QPP, NPASS = (NQ + 255) / 256;
     __shared__ __attribute__((aligned(16))) float tile[NPX * PXS];
     const int tid = threadIdx.x, row = tid >> 5, col = tid & 31;
     int t = blockIdx.x;
@@ -314,29 +315,42 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const float *__restr
     t /= tiles_x;
     const int ty = t % tiles_y, b = t / tiles_y;
     const int x0 = 32 * tx, y0 = 8 * ty;
-    const __amdgpu_buffer_rsrc_t rs = buffer_rsrc(x + (size_t)b * H * W * Cin, (unsigned)H * (unsigned)W * (unsigned)Cin * 4u);
+    const __amdgpu_buffer_rsrc_t rs = buffer_rsrc(x + (size_t)b * H * W * Cin, (unsigned)H * (unsigned)W * (unsigned)Cin * (unsigned)ES);
     int voff[NPASS], lw[NPASS];
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
         const int q = tid + 256 * i;
-        const int px = q >> 3, cq = q & 7;
+        const int px = q / QPP, cq = q % QPP;
         const int hy = px / HC, hx = px - hy * HC;
         const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-        voff[i] = (q < NQ && yy >= 0 && yy < H && xx >= 0 && xx < W) ? ((yy * W + xx) * Cin + 4 * cq) * 4 : (int)0x80000000;
-        lw[i] = q < NQ ? px * PXS + 4 * cq : -1;
+        voff[i] = (q < NQ && yy >= 0 && yy < H && xx >= 0 && xx < W) ? ((yy * W + xx) * Cin + QCH * cq) * ES : (int)0x80000000;
+        lw[i] = q < NQ ? px * PXS + QCH * cq : -1;
     }
     float acc[COUT];
 #pragma unroll
     for (int o = 0; o < COUT; ++o) acc[o] = bias ? bias[o] : 0.0f;
     const float *tp = tile + (row * HC + col) * PXS;
     for (int c0 = 0; c0 < Cin; c0 += 32) {
-        f32x4 rk[NPASS];
-#pragma unroll
-        for (int i = 0; i < NPASS; ++i) rk[i] = BufLd<float>::quad(rs, voff[i], c0 * 4);   // (soffset is range-checked with voffset)
-        __syncthreads();   // the previous chunk has been consumed
+        u32x4_t rk[NPASS];
 #pragma unroll
         for (int i = 0; i < NPASS; ++i)
-            if (lw[i] >= 0) *reinterpret_cast<f32x4 *>(tile + lw[i]) = rk[i];
+            rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], c0 * ES, 0);   // (soffset is range-checked with voffset)
+        __syncthreads();   // the previous chunk has been consumed
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            if (lw[i] >= 0) {
+                if constexpr (ES == 4) {
+                    *reinterpret_cast<u32x4_t *>(tile + lw[i]) = rk[i];
+                } else {   // fp16 activations: widened on the way into LDS
+                    const f16x8 h = __builtin_bit_cast(f16x8, rk[i]);
+                    f32x4 lo, hi;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) lo[e] = (float)h[e], hi[e] = (float)h[4 + e];
+                    *reinterpret_cast<f32x4 *>(tile + lw[i]) = lo;
+                    *reinterpret_cast<f32x4 *>(tile + lw[i] + 4) = hi;
+                }
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -361,22 +375,24 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const float *__restr
 
 }  // namespace
 
-extern "C" int stereo_conv3x3_small_nhwc_f32(const float *x, const float *weight_tco, const float *bias, float *out_nchw, int B,
-                                             int Cin, int Cout, int H, int W, void *stream)
+namespace {
+template <typename TIN>
+int conv3x3_small(const TIN *x, const float *weight_tco, const float *bias, float *out_nchw, int B, int Cin, int Cout, int H, int W,
+                  void *stream)
 {
     if (B < 0 || Cin < 0 || Cout < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
     if (B == 0 || H == 0 || W == 0 || Cout == 0) return STEREO_OK;
     STEREO_REQUIRE_PTR(x);
     STEREO_REQUIRE_PTR(weight_tco);
     STEREO_REQUIRE_PTR(out_nchw);
-    if (Cin < 32 || Cin % 32 != 0 || Cout > 4 || !aligned16(x) || (long long)H * W * Cin * 4 >= (1LL << 31))
+    if (Cin < 32 || Cin % 32 != 0 || Cout > 4 || !aligned16(x) || (long long)H * W * Cin * (long long)sizeof(TIN) >= (1LL << 31))
         return STEREO_ERR_UNSUPPORTED;
     const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
     const long long nt = (long long)tiles_x * tiles_y * B;
     if (nt >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
-#define SMALL(CO) \
-    hipLaunchKernelGGL(conv3x3_small_kernel<CO>, dim3((unsigned)nt), dim3(256), 0, as_stream(stream), x, weight_tco, bias, out_nchw, \
-                       Cin, H, W, tiles_x, tiles_y)
+#define SMALL(CO)                                                                                                              \
+    hipLaunchKernelGGL((conv3x3_small_kernel<CO, TIN>), dim3((unsigned)nt), dim3(256), 0, as_stream(stream), x, weight_tco, bias, \
+                       out_nchw, Cin, H, W, tiles_x, tiles_y)
     if (Cout == 1) SMALL(1);
     else if (Cout == 2) SMALL(2);
     else if (Cout == 3) SMALL(3);
@@ -384,6 +400,18 @@ extern "C" int stereo_conv3x3_small_nhwc_f32(const float *x, const float *weight
 #undef SMALL
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
+}
+}  // namespace
+
+extern "C" int stereo_conv3x3_small_nhwc_f32(const float *x, const float *weight_tco, const float *bias, float *out_nchw, int B,
+                                             int Cin, int Cout, int H, int W, void *stream)
+{
+    return conv3x3_small<float>(x, weight_tco, bias, out_nchw, B, Cin, Cout, H, W, stream);
+}
+extern "C" int stereo_conv3x3_small_nhwc_f16(const void *x, const float *weight_tco, const float *bias, float *out_nchw, int B,
+                                             int Cin, int Cout, int H, int W, void *stream)
+{
+    return conv3x3_small<f16>(static_cast<const f16 *>(x), weight_tco, bias, out_nchw, B, Cin, Cout, H, W, stream);
 }
 
 namespace {

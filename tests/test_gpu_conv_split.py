@@ -171,3 +171,15 @@ def test_conv_nhwc_fp16_activations(S, case):
         scale = float(r.abs().max())
         assert float((o.double().cpu() - r).abs().max()) <= 6e-4 * scale + 1e-4          # half an fp16 ulp at the output's scale
         assert float((o.float() - (F.relu(l) if relu else l).float()).abs().max()) <= 2e-3 * scale + 1e-3
+
+
+def test_conv3x3_small_fp16_activations(S):
+    from stereoformer_amd import conv_split as C
+    torch.manual_seed(87)
+    x = _cl(torch.randn(2, 64, 9, 37, device="cuda").half())
+    m = nn.Conv2d(64, 2, 3, padding=1).cuda()
+    with torch.no_grad():
+        o = C.conv3x3_small(x, m)
+    r = F.conv2d(x.double().cpu(), m.weight.detach().half().double().cpu(), m.bias.detach().double().cpu(), padding=1)
+    assert o.dtype == torch.float32 and o.is_contiguous()
+    assert float((o.double().cpu() - r).abs().max()) <= 5e-6 * float(r.abs().max()) + 2e-6
