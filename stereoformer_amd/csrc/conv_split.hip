@@ -481,7 +481,9 @@ int conv_nhwc(const void *const *srcs, const int *src_channels, int nsrc, const 
     const int tiles_x = (W + CV_TW - 1) / CV_TW;
     // pixel tile: 4 rows x 32 columns, a wave = 4 rows x 32 output channels (an 8-row tile with 64 channels per wave measured equal
     // at the large shapes and 7-18 % behind at 1/8 and 1/16 scale: finer workgroups spread a launch more evenly over the chip)
-    constexpr int th = 4;
+    // (fp16 activations: one MFMA per fragment instead of six makes the 4-row shape LDS-bound -- every A fragment feeds a single
+    // MFMA; the 8-row shape, a wave = 4 rows x 64 channels, halves the fragment reads per MFMA)
+    constexpr int th = sizeof(TIN) == 4 ? 4 : 8;
     const int tiles_y = (H + th - 1) / th;
     const long long nt = (long long)tiles_x * tiles_y * B;
     if (nt * ntn >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
