@@ -282,7 +282,12 @@ def conv_split_roofline(B, Hq, Wq, dev):
             "achieved": round(tf, 1), "peak": round(2500.0 / 6, 1), "unit": "TFLOP/s", "frac": round(tf / (2500.0 / 6), 4),
             "traffic": None, "avg_launch_ms": round(ms, 4), "executed_bf16_tflops": round(6 * tf, 1),
             "frac_of_f32_mfma_peak": round(tf / MFMA_F32_PEAK, 4),
-            "note": "fp32-equivalent flops; MIOpen's fp32 implicit GEMM runs the same launch at ~128 TFLOP/s (0.81 of the f32 MFMA peak)"}
+            "sustained_bf16_mfma_tflops_random_operands": [1470, 1660],
+            "frac_of_sustained_rate": round(6 * tf / 1660.0, 3),
+            "note": "fp32-equivalent flops; MIOpen's fp32 implicit GEMM runs the same launch at ~128 TFLOP/s (0.81 of the f32 MFMA "
+                    "peak).  The 2.5 PFLOP/s bf16 figure is not reachable with real data on this part: a pure "
+                    "v_mfma_f32_32x32x16_bf16 loop sustains 2.43 PFLOP/s on CONSTANT operands but 1.47-1.66 PFLOP/s on random bits "
+                    "(power: the clock drops to 1.4-1.6 GHz; tools/mfma_rate_bf16.hip) -- frac_of_sustained_rate is against 1.66"}
 
 
 def cfg4(dev, rank, world, steps, warmup, cpu, mixed=False):
