@@ -478,6 +478,117 @@ extern "C" int stereo_corr_lookup_f32(const float *const *levels, const float *c
     return STEREO_OK;
 }
 
+// The same with one thread per (b, level, pixel) computing ALL 2 r + 1 taps in one pass over the channels: the taps of a pixel
+// sit on consecutive columns of the pooled feature row (px differs by exactly 1 between taps), so a channel costs the thread one
+// fmap1 value and 2 r + 2 consecutive fmap2 values per sampled row instead of 4 gathers and one fmap1 value PER TAP -- lanes are
+// consecutive pixels, so the column reads of a wave are contiguous wherever the disparity is locally smooth.  Every per-tap
+// coordinate / weight is computed with the reference's rounding sequence exactly as above; a thread whose taps are not on
+// consecutive columns (possible only through rounding at huge coordinates) takes the per-tap gathers.
+template <int R>
+__global__ __launch_bounds__(256) void alt_corr_lookup_taps_kernel(const float *__restrict__ f1, LevelPtrs lv,
+                                                                   const float *__restrict__ coords, float *__restrict__ out,
+                                                                   int C, int H, int W, int L, float sqrt_c, long long nitems)
+{
+    // workgroup = 64 (b, level, pixel) items x 4 channel slices (one wave per slice: lanes stay consecutive pixels); the four
+    // partial dot products of an item meet in LDS
+    constexpr int T = 2 * R + 1;
+    __shared__ float part[3][T][64];
+    const long long HW = (long long)H * W;
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    for (long long t0 = (long long)blockIdx.x * 64; t0 < nitems; t0 += (long long)gridDim.x * 64) {
+        const long long t = t0 + lane;
+        const bool live = t < nitems;
+        const long long tt = live ? t : nitems - 1;
+        const long long p = tt % HW;
+        long long q = tt / HW;
+        const int i = (int)(q % L);
+        const long long b = q / L;
+        const int Wl = lv.w[i];
+        const float x = coords[(size_t)b * 2 * HW + p], y = coords[(size_t)b * 2 * HW + HW + p];
+        const float yg = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, y), (float)(H - 1)), 1.0f);
+        const float iy = __fmul_rn(__fdiv_rn(__fadd_rn(yg, 1.0f), 2.0f), (float)(H - 1));
+        const float fy = floorf(iy), ay = iy - fy;
+        const int y0 = (int)fminf(fmaxf(fy, -4.0f), (float)H + 4.0f);
+        const bool vy0 = fy >= 0.0f && fy <= (float)(H - 1), vy1 = fy + 1.0f >= 0.0f && fy + 1.0f <= (float)(H - 1);
+        int x0[T];
+        float w00[T], w01[T], w10[T], w11[T];
+        bool consec = true;
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            const float px = __fadd_rn(x / (float)(1 << i), (float)(k - R));
+            const float xg = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, px), (float)(Wl - 1)), 1.0f);
+            const float ix = __fmul_rn(__fdiv_rn(__fadd_rn(xg, 1.0f), 2.0f), (float)(Wl - 1));
+            const float fx = floorf(ix), ax = ix - fx;
+            // clamp before the int conversion (coordinates far outside the row): such taps are invalid anyway
+            x0[k] = (int)fminf(fmaxf(fx, -4.0f), (float)Wl + 4.0f);
+            w00[k] = (1.0f - ax) * (1.0f - ay);
+            w01[k] = ax * (1.0f - ay);
+            w10[k] = (1.0f - ax) * ay;
+            w11[k] = ax * ay;
+            consec = consec && x0[k] == x0[0] + k;
+        }
+        const int cper = (C + 3) / 4, c_lo = slice * cper, c_hi = c_lo + cper < C ? c_lo + cper : C;
+        const size_t cstride = (size_t)H * (size_t)Wl;
+        const float *img = lv.p[i] + (size_t)b * C * cstride + (size_t)c_lo * cstride;
+        const float *q1 = f1 + (size_t)b * C * HW + (size_t)c_lo * HW + p;
+        float dot[T];
+#pragma unroll
+        for (int k = 0; k < T; ++k) dot[k] = 0.0f;
+        if (consec) {
+            const int xb = x0[0];
+            bool vcol[T + 1];
+#pragma unroll
+            for (int j = 0; j <= T; ++j) vcol[j] = xb + j >= 0 && xb + j <= Wl - 1;
+            const float *r0 = img + (size_t)(vy0 ? y0 : 0) * Wl, *r1 = img + (size_t)(vy1 ? y0 + 1 : 0) * Wl;
+#pragma unroll 2
+            for (int c = c_lo; c < c_hi; ++c) {
+                const float qv = *q1;
+                float a[T + 1], d[T + 1];
+#pragma unroll
+                for (int j = 0; j <= T; ++j) {
+                    a[j] = (vy0 && vcol[j]) ? r0[xb + j] : 0.0f;
+                    d[j] = (vy1 && vcol[j]) ? r1[xb + j] : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < T; ++k) {
+                    const float sv = a[k] * w00[k] + a[k + 1] * w01[k] + d[k] * w10[k] + d[k + 1] * w11[k];
+                    dot[k] = fmaf(sv, qv, dot[k]);
+                }
+                r0 += cstride;
+                r1 += cstride;
+                q1 += HW;
+            }
+        } else {
+            for (int c = c_lo; c < c_hi; ++c) {
+                const float *im = img + (size_t)(c - c_lo) * cstride;
+                const float qv = q1[(size_t)(c - c_lo) * HW];
+#pragma unroll
+                for (int k = 0; k < T; ++k) {
+                    const bool vx0 = x0[k] >= 0 && x0[k] <= Wl - 1, vx1 = x0[k] + 1 >= 0 && x0[k] + 1 <= Wl - 1;
+                    float sv = 0.0f;
+                    if (vy0 && vx0) sv += im[(size_t)y0 * Wl + x0[k]] * w00[k];
+                    if (vy0 && vx1) sv += im[(size_t)y0 * Wl + x0[k] + 1] * w01[k];
+                    if (vy1 && vx0) sv += im[(size_t)(y0 + 1) * Wl + x0[k]] * w10[k];
+                    if (vy1 && vx1) sv += im[(size_t)(y0 + 1) * Wl + x0[k] + 1] * w11[k];
+                    dot[k] = fmaf(sv, qv, dot[k]);
+                }
+            }
+        }
+        __syncthreads();   // (the previous item's partials have been consumed)
+        if (slice > 0) {
+#pragma unroll
+            for (int k = 0; k < T; ++k) part[slice - 1][k][lane] = dot[k];
+        }
+        __syncthreads();
+        if (slice == 0 && live) {
+            float *o = out + ((size_t)b * L * T + (size_t)i * T) * HW + p;
+#pragma unroll
+            for (int k = 0; k < T; ++k)
+                o[(size_t)k * HW] = (((dot[k] + part[0][k][lane]) + part[1][k][lane]) + part[2][k][lane]) / sqrt_c;
+        }
+    }
+}
+
 extern "C" long long stereo_alt_corr_workspace_floats(int B, int C, int H, int W, int num_levels)
 {
     long long total = 0;
@@ -521,9 +632,20 @@ extern "C" int stereo_alt_corr_lookup_f32(const float *fmap1, const float *fmap2
     }
     if (W < 2 || H < 2) return STEREO_ERR_UNSUPPORTED;  // corr.py:20-21 divides by (W-1),(H-1)
     const int T = 2 * radius + 1;
-    const long long nout = (long long)B * num_levels * T * H * W;
-    hipLaunchKernelGGL(alt_corr_lookup_kernel, dim3(grid_for(nout)), dim3(256), 0, st, fmap1, lv, coords, out, C, H, W,
-                       num_levels, radius, sqrtf((float)C), nout);
+    const long long nthr = (long long)B * num_levels * H * W;
+#define ALT_TAPS(RV)                                                                                                          \
+    hipLaunchKernelGGL(alt_corr_lookup_taps_kernel<RV>, dim3(grid_for(nthr * 4)), dim3(256), 0, st, fmap1, lv, coords, out, C, H, \
+                       W, num_levels, sqrtf((float)C), nthr)
+    if (radius == 4) ALT_TAPS(4);        // the reference's corr_radius (raft_stereo.py: corr_radius = 4)
+    else if (radius == 3) ALT_TAPS(3);
+    else if (radius == 2) ALT_TAPS(2);
+    else if (radius == 1) ALT_TAPS(1);
+    else {
+        const long long nout = nthr * T;
+        hipLaunchKernelGGL(alt_corr_lookup_kernel, dim3(grid_for(nout)), dim3(256), 0, st, fmap1, lv, coords, out, C, H, W,
+                           num_levels, radius, sqrtf((float)C), nout);
+    }
+#undef ALT_TAPS
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }

@@ -204,7 +204,15 @@ def main():
                 (Br * 36 * Hr * Wr * 4 * 3) / 1e9, note="out + ~2 taps gathered per output")
         if want("A10_alt"):
             alt = S.PytorchAlternateCorrBlock1D(f1[:1], f2[:1], 4, 4)
-            add("A10_alt_corr_lookup B=1", timeit(lambda: alt(coords[:1]), 3, 1), None,
+            add("A10_alt_corr_lookup B=1 [coords scattered up to 30 px in x AND y: every lane gathers from its own rows]",
+                timeit(lambda: alt(coords[:1]), 3, 1), None, 2 * 36 * Hr * Wr * Cr * 5 / 1e9, bound="valu")
+            # what the loop feeds it (raft_stereo.py:171-180): y is the row itself, x a smooth disparity field
+            xs = torch.linspace(0, 6.28, Wr, device=dev).view(1, 1, 1, Wr)
+            ys = torch.linspace(0, 3.14, Hr, device=dev).view(1, 1, Hr, 1)
+            smooth = S.coords_grid(1, Hr, Wr, device=dev).clone()
+            smooth[:, :1] -= 20.0 + 8.0 * torch.sin(xs) * torch.cos(ys)
+            smooth = smooth.contiguous()
+            add("A10_alt_corr_lookup B=1 [loop-like coords: y = row, smooth disparity]", timeit(lambda: alt(smooth), 3, 1), None,
                 2 * 36 * Hr * Wr * Cr * 5 / 1e9, bound="valu")
         if want("A13_upsample"):
             d8 = torch.rand(8, 1, 72, 120, device=dev)
