@@ -1,0 +1,24 @@
+"""Error audit of the update block on the split-bf16 convolution kernel against the same loop on the library's fp32 convolutions
+(dev tool): final low-resolution flow and upsampled disparity after 16 iterations at cfg-4 geometry, two pairs.
+    python tools/conv_audit.py > profiles/r02c_conv_error_audit.txt"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import stereoformer_amd as S
+from stereoformer_amd import conv_split as C
+from tools.bench_configs import raft_inputs
+dev = torch.device("cuda")
+f1, f2, nets, inps = raft_inputs(2, 136, 240, dev, 400)
+torch.manual_seed(4)
+loop = S.RAFTStereoLoop([128, 128, 128], channels_last=True).eval().to(dev)
+with torch.no_grad():
+    for iters in (1, 4, 16):
+        lo_a, up_a = loop(f1, f2, [n.clone() for n in nets], inps, iters=iters, test_mode=True)
+        real = C.supported, C.small_supported
+        C.supported = lambda *a, **k: False
+        C.small_supported = lambda *a, **k: False
+        lo_b, up_b = loop(f1, f2, [n.clone() for n in nets], inps, iters=iters, test_mode=True)
+        C.supported, C.small_supported = real
+        print(f"iterations {iters:2d}: max |flow_lo diff| {float((lo_a - lo_b).abs().max()):.2e} (|flow| max {float(lo_b.abs().max()):.2f}) px at 1/4 scale; "
+              f"max |disparity diff| {float((up_a - up_b).abs().max()):.2e}, mean {float((up_a - up_b).abs().mean()):.2e} px at full resolution "
+              f"(|disparity| max {float(up_b.abs().max()):.1f})", flush=True)
