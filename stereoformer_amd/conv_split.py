@@ -69,7 +69,7 @@ def _cached(convs, tag, device, build):
     """Per-module cache (it lives on the first module of the group and dies with it -- a global table keyed by storage
     addresses would hand a freed weight's packed copy to whatever tensor is allocated at the same address next)."""
     store = convs[0].__dict__.setdefault("_stereo_conv_cache", {})
-    key = (tag,) + tuple(id(m) for m in convs[1:])
+    key = (tag, device.index) + tuple(id(m) for m in convs[1:])   # (per device: nn.DataParallel replicas share this dict)
     sig = _signature(convs, device)
     hit = store.get(key)
     if hit is not None and hit[0] == sig:
