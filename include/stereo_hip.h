@@ -328,6 +328,15 @@ int stereo_conv_pack_weights(const float *weight, void *packed, int Cout, int Ci
 int stereo_conv_nhwc_f32(const float *const *srcs, const int *src_channels, int nsrc, const void *packed, const float *bias,
                          float *const *outs, const int *out_channels, const int *out_strides, int nout, int ksize, int relu,
                          int B, int H, int W, void *stream);
+/* A reduced-precision form for fp32 activations ("bf16x3", the counterpart of torch.set_float32_matmul_precision('high')): every
+ * operand as hi + mid bf16 pieces, the three leading piece products -- ~2^-16 relative error per product (100x finer than
+ * TF32, 250x coarser than the default form), half the matrix work.  NOT the parity configuration; opt-in on the host side
+ * (`conv_precision="high"`).  `packed` from stereo_conv_pack_weights_bf16x3 / stereo_conv_packed_bytes_bf16x3. */
+long long stereo_conv_packed_bytes_bf16x3(int Cout, int Cin, int ksize);
+int stereo_conv_pack_weights_bf16x3(const float *weight, void *packed, int Cout, int Cin, int ksize, void *stream);
+int stereo_conv_nhwc_f32_bf16x3(const float *const *srcs, const int *src_channels, int nsrc, const void *packed,
+                                const float *bias, float *const *outs, const int *out_channels, const int *out_strides, int nout,
+                                int ksize, int relu, int B, int H, int W, void *stream);
 /* The same for fp16 activations (the update block under the reference's mixed_precision flag, raft_stereo.py:176: fp16 autocast
  * around the block): sources and destinations fp16 channels-last, weights rounded to fp16 by stereo_conv_pack_weights_f16
  * (what autocast hands the library), v_mfma_f32_32x32x16_f16 with fp32 accumulation, bias (fp32) added before the one rounding

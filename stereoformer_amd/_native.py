@@ -66,6 +66,10 @@ SIGNATURES = {
     "stereo_conv3x3_small_nhwc_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_conv_packed_bytes": [_i, _i, _i],
     "stereo_conv_packed_bytes_f16": [_i, _i, _i],
+    "stereo_conv_packed_bytes_bf16x3": [_i, _i, _i],
+    "stereo_conv_pack_weights_bf16x3": [_vp, _vp, _i, _i, _i, _vp],
+    "stereo_conv_nhwc_f32_bf16x3": [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_i),
+                                    ctypes.POINTER(_i), _i, _i, _i, _i, _i, _i, _vp],
     "stereo_conv_pack_weights": [_vp, _vp, _i, _i, _i, _vp],
     "stereo_conv_pack_weights_f16": [_vp, _vp, _i, _i, _i, _vp],
     "stereo_conv_nhwc_f16": [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_i),
@@ -94,7 +98,7 @@ SIGNATURES = {
 }
 _RESTYPE = {"stereo_strerror": ctypes.c_char_p, "stereo_alt_corr_workspace_floats": _ll,
             "stereo_instance_norm_workspace_bytes": _ll, "stereo_conv_packed_bytes": _ll,
-            "stereo_conv_packed_bytes_f16": _ll}
+            "stereo_conv_packed_bytes_f16": _ll, "stereo_conv_packed_bytes_bf16x3": _ll}
 
 _lib = None
 

@@ -17,6 +17,21 @@ import torch
 
 from . import _native as N
 
+_PRECISION = "highest"
+
+
+def set_precision(precision):
+    """Arithmetic of ``conv_nhwc`` on fp32 activations: ``"highest"`` (default, the parity configuration: three bf16 pieces per
+    value, six piece products -- fp32-faithful) or ``"high"`` (two pieces, three products, "bf16x3": ~2^-16 relative error per
+    product -- the counterpart of ``torch.set_float32_matmul_precision('high')`` -- at half the matrix work).  Returns the
+    previous setting."""
+    global _PRECISION
+    if precision not in ("highest", "high"):
+        raise ValueError("conv_split.set_precision: 'highest' or 'high'")
+    prev, _PRECISION = _PRECISION, precision
+    return prev
+
+
 def _is_cl(t):
     return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
 
@@ -79,10 +94,9 @@ def _cached(convs, tag, device, build):
     return val
 
 
-def _packed(convs, device, half=False):
-    """Packed weights (split-bf16 pieces for fp32 activations, fp16 for fp16 ones; + the concatenated fp32 bias) of a group of
-    modules; rebuilt when a parameter is replaced or updated in place."""
-    sfx = "_f16" if half else ""
+def _packed(convs, device, sfx=""):
+    """Packed weights (split-bf16 pieces for fp32 activations -- three, or two with ``sfx="_bf16x3"`` --, fp16 for fp16 ones,
+    ``sfx="_f16"``; + the concatenated fp32 bias) of a group of modules; rebuilt when a parameter is replaced or updated in place."""
 
     def build():
         with torch.no_grad():
@@ -115,7 +129,8 @@ def conv_nhwc(srcs, convs, relu=False, out_channels_total=None):
         raise ValueError("conv_nhwc: out_channels_total applies to one module and must cover its output channels")
     dev = srcs[0].device
     half = srcs[0].dtype == torch.float16
-    packed, bias, k = _packed(convs, dev, half)
+    sfx = "_f16" if half else ("_bf16x3" if _PRECISION == "high" else "")
+    packed, bias, k = _packed(convs, dev, sfx)
     B, _, H, W = srcs[0].shape
     widths = [m.out_channels for m in convs] if out_channels_total is None else [int(out_channels_total)]
     outs = [torch.empty((B, c, H, W), device=dev, dtype=srcs[0].dtype, memory_format=torch.channels_last) for c in widths]
@@ -125,7 +140,7 @@ def conv_nhwc(srcs, convs, relu=False, out_channels_total=None):
     oc = (N._i * len(outs))(*[m.out_channels for m in convs])
     os_ = (N._i * len(outs))(*widths)
     with torch.cuda.device(dev):
-        N.call("stereo_conv_nhwc_f16" if half else "stereo_conv_nhwc_f32", sp, sc, len(srcs), N.ptr(packed), N.ptr(bias), op, oc, os_,
+        N.call("stereo_conv_nhwc_f16" if half else "stereo_conv_nhwc_f32" + sfx, sp, sc, len(srcs), N.ptr(packed), N.ptr(bias), op, oc, os_,
                len(outs), k,
                1 if relu else 0, B, H, W, N.stream_ptr(dev))
     return outs

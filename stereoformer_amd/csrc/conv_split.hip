@@ -50,14 +50,14 @@ template <typename TIN>
 struct ConvOp;
 template <>
 struct ConvOp<float> {
-    static constexpr int NP = 3, QCH = 4;   // pieces; channels per 16-B quad
+    static constexpr int QCH = 4;   // channels per 16-B quad (pieces per value: the kernels' NP parameter, 3 or 2)
     typedef bf16x8 frag;
     typedef __bf16 welem;
     static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 template <>
 struct ConvOp<f16> {
-    static constexpr int NP = 1, QCH = 8;
+    static constexpr int QCH = 8;   // (NP = 1)
     typedef f16x8 frag;
     typedef _Float16 welem;
     static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
@@ -66,11 +66,10 @@ struct ConvOp<f16> {
 // weights [Cout][Cin][KS][KS] fp32 -> packed[(((chunk * TAPS + tap) * NB + nb) * NP + piece) * 64 + lane][8], where lane l of
 // n block nb holds output channel 32 nb + (l & 31), input channels 16 chunk + 8 (l >> 5) + 0..7 (the MFMA's B fragment);
 // float activations: NP = 3 bf16 pieces; f16 activations: the weight rounded to fp16 (what autocast hands the library)
-template <typename TIN>
+template <typename TIN, int NP>
 __global__ void conv_pack_kernel(const float *__restrict__ w, typename ConvOp<TIN>::welem *__restrict__ packed, int Cout, int Cin,
                                  int taps, int NB)
 {
-    constexpr int NP = ConvOp<TIN>::NP;
     const long long total = (long long)(Cin / 16) * taps * NB * 64;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -86,11 +85,11 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, typename ConvOp<TI
         x[j] = n < Cout ? w[((size_t)n * Cin + c) * taps + tap] : 0.0f;
     }
     const size_t base = ((((size_t)chunk * taps + tap) * NB + nb) * NP) * 64 + lane;
-    if constexpr (NP == 3) {
-        bf16x8 pc[3];
-        split_oct<3>(x, pc);
+    if constexpr (NP >= 2) {
+        bf16x8 pc[NP];
+        split_oct<NP>(x, pc);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x8 *>(packed + (base + (size_t)p * 64) * 8) = pc[p];
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x8 *>(packed + (base + (size_t)p * 64) * 8) = pc[p];
     } else {
         f16x8 h;
 #pragma unroll
@@ -99,7 +98,7 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, typename ConvOp<TI
     }
 }
 
-template <int KS, int TH, typename TIN>
+template <int KS, int TH, typename TIN, int NP>
 __global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSrcs src,
                                                                            const typename ConvOp<TIN>::welem *__restrict__ packed,
                                                                            const float *__restrict__ bias, ConvDsts dst, int relu,
@@ -109,7 +108,7 @@ __global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSr
     typedef ConvOp<TIN> Op;
     typedef typename Op::frag frag;
     typedef typename Op::welem welem;
-    constexpr int NP = Op::NP, QCH = Op::QCH, QPP = 16 / QCH, ES = (int)sizeof(TIN);
+    constexpr int QCH = Op::QCH, QPP = 16 / QCH, ES = (int)sizeof(TIN);
     constexpr int HALO = KS / 2, TAPS = KS * KS;
     constexpr int WN = TH == 8 ? 2 : 4;          // waves along the output channels (the other 4 / WN along the rows)
     constexpr int NBW = 4 / WN;                  // 32-channel N blocks per wave
@@ -159,13 +158,13 @@ __global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSr
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             if (lw[i] >= 0) {
-                if constexpr (NP == 3) {
+                if constexpr (NP >= 2) {
                     const f32x4 v = __builtin_bit_cast(f32x4, rk[i]);
-                    bf16x2 a[3], c[3];
-                    split_pair<3>((f32x2){v[0], v[1]}, a);
-                    split_pair<3>((f32x2){v[2], v[3]}, c);
+                    bf16x2 a[NP], c[NP];
+                    split_pair<NP>((f32x2){v[0], v[1]}, a);
+                    split_pair<NP>((f32x2){v[2], v[3]}, c);
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4 *>(img + p * PS + lw[i]) = cat2(a[p], c[p]);
+                    for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4 *>(img + p * PS + lw[i]) = cat2(a[p], c[p]);
                 } else {
                     *reinterpret_cast<u32x4_t *>(img + lw[i]) = rk[i];
                 }
@@ -217,9 +216,11 @@ __global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSr
             af[p] = *reinterpret_cast<const frag *>(abase + p * PS + ((2 * (mb >> 1) + ky) * HCOLS + 16 * (mb & 1) + kx) * CV_PXB);
     };
     // piece products, smallest first: (a1 b1) (a0 b2) (a2 b0) (a0 b1) (a1 b0) (a0 b0)
-    constexpr int NPROD = NP == 3 ? 6 : 1;
-    constexpr int PA[6] = {NP == 3 ? 1 : 0, 0, NP == 3 ? 2 : 0, 0, NP == 3 ? 1 : 0, 0};
-    constexpr int PB[6] = {NP == 3 ? 1 : 0, NP == 3 ? 2 : 0, 0, NP == 3 ? 1 : 0, 0, 0};
+    // NP = 3: all six products above (fp32-faithful).  NP = 2 ("bf16x3": hi + mid pieces, the three leading products a0 b1, a1 b0,
+    // a0 b0 -- the last three entries): ~2^-16 relative error per product, half the matrix work.  NP = 1: a0 b0.
+    constexpr int NPROD = NP == 3 ? 6 : (NP == 2 ? 3 : 1);
+    constexpr int PA[6] = {NP == 3 ? 1 : 0, 0, NP == 3 ? 2 : 0, 0, NP >= 2 ? 1 : 0, 0};
+    constexpr int PB[6] = {NP == 3 ? 1 : 0, NP == 3 ? 2 : 0, 0, NP >= 2 ? 1 : 0, 0, 0};
     auto single = [&](int m0, int ky, int kx, const frag (&bf)[NBW][NP]) {
         frag a0[NP];
         load_a(a0, m0, ky, kx);
@@ -416,30 +417,30 @@ extern "C" int stereo_conv3x3_small_nhwc_f16(const void *x, const float *weight_
 
 namespace {
 
-template <typename TIN>
+template <typename TIN, int NP>
 long long packed_bytes(int Cout, int Cin, int ksize)
 {
     if (Cout < 1 || Cin < 16 || Cin % 16 != 0 || (ksize != 1 && ksize != 3)) return 0;
     const long long NB = 4LL * ((Cout + 127) / 128);
-    return (long long)(Cin / 16) * ksize * ksize * NB * ConvOp<TIN>::NP * 64 * 8 * 2;
+    return (long long)(Cin / 16) * ksize * ksize * NB * NP * 64 * 8 * 2;
 }
 
-template <typename TIN>
+template <typename TIN, int NP>
 int pack_weights(const float *weight, void *packed, int Cout, int Cin, int ksize, void *stream)
 {
-    if (packed_bytes<TIN>(Cout, Cin, ksize) == 0) return STEREO_ERR_BAD_SHAPE;
+    if (packed_bytes<TIN, NP>(Cout, Cin, ksize) == 0) return STEREO_ERR_BAD_SHAPE;
     STEREO_REQUIRE_PTR(weight);
     STEREO_REQUIRE_PTR(packed);
     if (!aligned16(packed)) return STEREO_ERR_UNSUPPORTED;
     const int NB = 4 * ((Cout + 127) / 128), taps = ksize * ksize;
     const long long total = (long long)(Cin / 16) * taps * NB * 64;
-    hipLaunchKernelGGL(conv_pack_kernel<TIN>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), weight,
+    hipLaunchKernelGGL((conv_pack_kernel<TIN, NP>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), weight,
                        static_cast<typename ConvOp<TIN>::welem *>(packed), Cout, Cin, taps, NB);
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }
 
-template <typename TIN>
+template <typename TIN, int NP>
 int conv_nhwc(const void *const *srcs, const int *src_channels, int nsrc, const void *packed, const float *bias,
               void *const *outs, const int *out_channels, const int *out_strides, int nout, int ksize, int relu, int B, int H,
               int W, void *stream)
@@ -490,7 +491,7 @@ int conv_nhwc(const void *const *srcs, const int *src_channels, int nsrc, const 
     dim3 grid((unsigned)(nt * ntn));
     typedef typename ConvOp<TIN>::welem welem;
 #define CONV_LAUNCH(KSV)                                                                                                        \
-    hipLaunchKernelGGL((conv_split_kernel<KSV, th, TIN>), grid, dim3(256), 0, as_stream(stream), s, static_cast<const welem *>(packed), \
+    hipLaunchKernelGGL((conv_split_kernel<KSV, th, TIN, NP>), grid, dim3(256), 0, as_stream(stream), s, static_cast<const welem *>(packed), \
                        bias, d, relu, H, W, tiles_x, tiles_y, NB, Cout, ntn)
     if (ksize == 3) CONV_LAUNCH(3);
     else CONV_LAUNCH(1);
@@ -501,26 +502,38 @@ int conv_nhwc(const void *const *srcs, const int *src_channels, int nsrc, const 
 
 }  // namespace
 
-extern "C" long long stereo_conv_packed_bytes(int Cout, int Cin, int ksize) { return packed_bytes<float>(Cout, Cin, ksize); }
-extern "C" long long stereo_conv_packed_bytes_f16(int Cout, int Cin, int ksize) { return packed_bytes<f16>(Cout, Cin, ksize); }
+extern "C" long long stereo_conv_packed_bytes(int Cout, int Cin, int ksize) { return packed_bytes<float, 3>(Cout, Cin, ksize); }
+extern "C" long long stereo_conv_packed_bytes_bf16x3(int Cout, int Cin, int ksize) { return packed_bytes<float, 2>(Cout, Cin, ksize); }
+extern "C" long long stereo_conv_packed_bytes_f16(int Cout, int Cin, int ksize) { return packed_bytes<f16, 1>(Cout, Cin, ksize); }
 extern "C" int stereo_conv_pack_weights(const float *weight, void *packed, int Cout, int Cin, int ksize, void *stream)
 {
-    return pack_weights<float>(weight, packed, Cout, Cin, ksize, stream);
+    return pack_weights<float, 3>(weight, packed, Cout, Cin, ksize, stream);
+}
+extern "C" int stereo_conv_pack_weights_bf16x3(const float *weight, void *packed, int Cout, int Cin, int ksize, void *stream)
+{
+    return pack_weights<float, 2>(weight, packed, Cout, Cin, ksize, stream);
 }
 extern "C" int stereo_conv_pack_weights_f16(const float *weight, void *packed, int Cout, int Cin, int ksize, void *stream)
 {
-    return pack_weights<f16>(weight, packed, Cout, Cin, ksize, stream);
+    return pack_weights<f16, 1>(weight, packed, Cout, Cin, ksize, stream);
 }
 extern "C" int stereo_conv_nhwc_f32(const float *const *srcs, const int *src_channels, int nsrc, const void *packed,
                                     const float *bias, float *const *outs, const int *out_channels, const int *out_strides,
                                     int nout, int ksize, int relu, int B, int H, int W, void *stream)
 {
-    return conv_nhwc<float>(reinterpret_cast<const void *const *>(srcs), src_channels, nsrc, packed, bias,
-                            reinterpret_cast<void *const *>(outs), out_channels, out_strides, nout, ksize, relu, B, H, W, stream);
+    return conv_nhwc<float, 3>(reinterpret_cast<const void *const *>(srcs), src_channels, nsrc, packed, bias,
+                               reinterpret_cast<void *const *>(outs), out_channels, out_strides, nout, ksize, relu, B, H, W, stream);
+}
+extern "C" int stereo_conv_nhwc_f32_bf16x3(const float *const *srcs, const int *src_channels, int nsrc, const void *packed,
+                                           const float *bias, float *const *outs, const int *out_channels, const int *out_strides,
+                                           int nout, int ksize, int relu, int B, int H, int W, void *stream)
+{
+    return conv_nhwc<float, 2>(reinterpret_cast<const void *const *>(srcs), src_channels, nsrc, packed, bias,
+                               reinterpret_cast<void *const *>(outs), out_channels, out_strides, nout, ksize, relu, B, H, W, stream);
 }
 extern "C" int stereo_conv_nhwc_f16(const void *const *srcs, const int *src_channels, int nsrc, const void *packed,
                                     const float *bias, void *const *outs, const int *out_channels, const int *out_strides,
                                     int nout, int ksize, int relu, int B, int H, int W, void *stream)
 {
-    return conv_nhwc<f16>(srcs, src_channels, nsrc, packed, bias, outs, out_channels, out_strides, nout, ksize, relu, B, H, W, stream);
+    return conv_nhwc<f16, 1>(srcs, src_channels, nsrc, packed, bias, outs, out_channels, out_strides, nout, ksize, relu, B, H, W, stream);
 }

@@ -55,14 +55,20 @@ class _GraphCache:
 
 class RAFTStereoLoop(nn.Module):
     def __init__(self, hidden_dims=(128, 128, 128), downsample=2, corr_levels=4, corr_radius=4, n_gru_layers=3,
-                 mixed_precision=False, channels_last=False):
+                 mixed_precision=False, channels_last=False, conv_precision="highest"):
         """``channels_last``: keep the update block's weights and activations in NHWC (MIOpen's convolutions are
         17 % (fp32) to 2x (fp16) faster there and need no layout transposes); the pointwise HIP kernels take either
         dense layout, lookups / upsampling convert their small inputs.  Same arithmetic, off by default.
         ``mixed_precision``: the reference's flag of the same name (``raft_stereo.py:176``): the update block's
         convolutions run under fp16 ``autocast``; correlation, lookup, gate math, coordinates and the convex
-        upsampling stay fp32.  Off by default -- fp32 is the parity configuration."""
+        upsampling stay fp32.  Off by default -- fp32 is the parity configuration.
+        ``conv_precision`` (inference with ``channels_last``, where the block's convolutions run on ``conv_split``): ``"highest"``
+        = fp32-faithful split-bf16 arithmetic (default, parity); ``"high"`` = two bf16 pieces / three products per fp32 product
+        (like ``torch.set_float32_matmul_precision('high')``): ~2^-16 relative error per product at half the matrix work."""
         super().__init__()
+        if conv_precision not in ("highest", "high"):
+            raise ValueError("RAFTStereoLoop: conv_precision is 'highest' (fp32-faithful, the parity configuration) or 'high'")
+        self.conv_precision = conv_precision
         self.mixed_precision = bool(mixed_precision)
         self.channels_last = bool(channels_last)
         self.hidden_dims = list(hidden_dims)
@@ -111,11 +117,20 @@ class RAFTStereoLoop(nn.Module):
                                       test_mode)
             return list(out)
 
-        key = (tuple(tuple(t.shape) for t in flat), iters, bool(test_mode), flat[0].device.index, self.mixed_precision, self.channels_last)
+        key = (tuple(tuple(t.shape) for t in flat), iters, bool(test_mode), flat[0].device.index, self.mixed_precision,
+               self.channels_last, self.conv_precision)
         out = self._graphs.run(key, fn, flat)
         return tuple(out) if test_mode else out
 
     def _forward_eager(self, fmap1, fmap2, net_list, inp_list, iters, flow_init, test_mode):
+        from . import conv_split
+        prev = conv_split.set_precision(self.conv_precision)
+        try:
+            return self._forward_eager_impl(fmap1, fmap2, net_list, inp_list, iters, flow_init, test_mode)
+        finally:
+            conv_split.set_precision(prev)
+
+    def _forward_eager_impl(self, fmap1, fmap2, net_list, inp_list, iters, flow_init, test_mode):
         # raft_stereo.py:155-156 widens the feature maps with `.float()`; fp16 maps are handed over as they are -- the
         # all-pairs kernel widens them on the way into LDS (same numbers, half the read bytes)
         keep = (torch.float16, torch.float32)

@@ -183,3 +183,28 @@ def test_conv3x3_small_fp16_activations(S):
     r = F.conv2d(x.double().cpu(), m.weight.detach().half().double().cpu(), m.bias.detach().double().cpu(), padding=1)
     assert o.dtype == torch.float32 and o.is_contiguous()
     assert float((o.double().cpu() - r).abs().max()) <= 5e-6 * float(r.abs().max()) + 2e-6
+
+
+def test_conv_nhwc_high_precision_option(S):
+    """conv_precision='high' (bf16x3: two pieces, three products): error ~2^-16 relative per product -- far inside TF32's, outside
+    the default form's; opt-in and restored."""
+    from stereoformer_amd import conv_split as C
+    torch.manual_seed(88)
+    srcs = [_cl(torch.randn(1, 128, 17, 60, device="cuda")) for _ in range(3)]
+    convs = [nn.Conv2d(384, 128, 3, padding=1).cuda() for _ in range(2)]
+    ref = _ref64(srcs, convs, False)
+    with torch.no_grad():
+        hi = C.conv_nhwc(srcs, convs)
+        prev = C.set_precision("high")
+        try:
+            assert prev == "highest"
+            lo = C.conv_nhwc(srcs, convs)
+        finally:
+            C.set_precision(prev)
+        again = C.conv_nhwc(srcs, convs)
+    for a, b, c, r in zip(hi, lo, again, ref):
+        scale = float(r.abs().max())
+        e_hi, e_lo = float((a.double().cpu() - r).abs().max()), float((b.double().cpu() - r).abs().max())
+        assert e_hi <= 4e-6 * scale + 1e-6
+        assert e_hi < e_lo <= 2e-4 * scale           # coarser than the default, ~30x finer than TF32 would be
+        assert torch.equal(a, c)

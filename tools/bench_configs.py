@@ -296,23 +296,29 @@ def cfg4(dev, rank, world, steps, warmup, cpu, mixed=False):
     roof = conv_split_roofline(B, Hq, Wq, dev) if rank == 0 else None
     torch.manual_seed(4)
     out = []
-    for mp in ((False, True) if mixed else (False,)):
-        loop = S.RAFTStereoLoop([128, 128, 128], mixed_precision=mp, channels_last=True).eval().to(dev)
+    for mp in ((False, True, "high") if mixed else (False,)):
+        hp = mp == "high"     # fp32 activations, bf16x3 convolution arithmetic (conv_precision='high')
+        mp = mp is True
+        loop = S.RAFTStereoLoop([128, 128, 128], mixed_precision=mp, channels_last=True,
+                                conv_precision="high" if hp else "highest").eval().to(dev)
         fn = lambda: loop(f1, f2, [n.clone() for n in nets], inps, iters=16, test_mode=True, use_graph=True)
         sec, per_rank = timed(fn, steps, warmup, world, dev)
         cb = None
-        if cpu and rank == 0 and not mp:
+        if cpu and rank == 0 and not mp and not hp:
             def leg():
                 s, d = cpu_raft_loop(Hq, Wq, 16)
                 return _cpu_entry(s, "1 pair: all-pairs + pyramid once, 2 measured iterations scaled to 16, upsampling once; C oracle "
                                      "+ torch-CPU convolutions", d)
             cb = _guard(leg)
-        out.append(entry("cfg-4" + (" (fp16 autocast convs)" if mp else ""),
+        out.append(entry("cfg-4" + (" (fp16 autocast convs)" if mp else (" (bf16x3 convs)" if hp else "")),
                          "SceneFlow 960x540 (padded 544) IterativeLocalCostVolume loop (RAFT-style update operator at 1/4 "
                          "resolution, NHWC through the update block): all-pairs pyramid + 16 x (lookup + update block + coords) + "
                          "convex upsampling, batch=8 per GPU (64 pairs over 8 GPUs)"
                          + (", update-block convolutions under fp16 autocast (the reference's mixed_precision flag; NOT the "
-                            "parity configuration)" if mp else ", fp32"), B, world, sec, per_rank, steps, warmup, roof, cb,
+                            "parity configuration)" if mp else
+                            (", fp32 activations with conv_precision='high': two bf16 pieces / three products per fp32 product "
+                             "(~2^-16 relative per product; NOT the parity configuration)" if hp else ", fp32")),
+                         B, world, sec, per_rank, steps, warmup, roof, cb,
                          {"bounded_by": ("MIOpen fp16 convolutions of the update block" if mp else
                                          "the update block's convolutions (1.2 TFLOP fp32-equivalent per iteration for 8 pairs) on "
                                          "the split-bf16 matrix-core kernel"),
