@@ -11,16 +11,19 @@
 // the ReLU and scatters its output channels to several destination tensors (convz | convr in one launch).
 //
 //   GEMM view      M = pixels (A operand, from LDS), N = output channels (B operand, pre-packed weights), K = (tap, channel)
-//   workgroup      4 waves, tile = 8 rows x 32 columns of pixels x 128 output channels; wave (wm, wn) owns rows 4 wm .. 4 wm + 3
-//                  (four M blocks of 2 rows x 16 columns) x channels 64 wn .. + 63 (two N blocks): 8 accumulator blocks = 128 registers
-//   K loop         sources in concatenation order, 16 input channels at a time: the (8 + 2) x (32 + 2) halo tile of the chunk is
+//   workgroup      4 waves, tile = 4 rows x 32 columns of pixels x 128 output channels; wave wn owns all four M blocks (2 rows x
+//                  16 columns each) x channels 32 wn .. + 31 (one N block): 4 accumulator blocks = 64 registers, four waves per
+//                  SIMD.  (fp16 activations: 8 rows, wave (wm, wn) = rows 4 wm .. x 64 channels, so an A fragment feeds two MFMAs.)
+//   K loop         sources in concatenation order, 16 input channels at a time: the (4 + 2) x (32 + 2) halo tile of the chunk is
 //                  fetched into registers (16-B quads through one buffer resource per source image: pixels outside the image read
-//                  0 = the zero padding), split into its three bf16 pieces and written to LDS as [piece][pixel][16 ch + pad]
+//                  0 = the zero padding), split into its bf16 pieces and written to LDS as [piece][pixel][16 ch + pad]
 //                  (48-B pixel stride: the A fragments are conflict-free ds_read_b128 at compile-time offsets per tap); the next
-//                  chunk's quads are in flight while the 9 taps x 48 MFMAs of the current one run
+//                  chunk's quads are in flight while the 9 taps x 24 MFMAs of the current one run
 //   weights        packed once per module by conv_pack_kernel into the B-fragment order [k-step][n block][piece][lane][8]: a
 //                  fragment is one 16-B load per lane, 1 KB contiguous per wave, served by L2 (2.6 MB for 384 -> 128 channels)
 //   epilogue       + bias, optional ReLU, every accumulator register is a 128-B row of 32 consecutive output channels of one pixel
+//   ceiling        power: the bf16 matrix pipe sustains 1.47-1.66 PFLOP/s on operands with random bits on this part (2.4 on
+//                  constant ones; tools/mfma_rate_bf16.hip), and the kernel issues 87-98 % of that MFMA rate
 #include "common.h"
 #include <type_traits>
 
