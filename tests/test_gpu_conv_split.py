@@ -208,3 +208,23 @@ def test_conv_nhwc_high_precision_option(S):
         assert e_hi <= 4e-6 * scale + 1e-6
         assert e_hi < e_lo <= 2e-4 * scale           # coarser than the default, ~30x finer than TF32 would be
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 3), (3, 1, 1), (1, 4, 16), (2, 3, 17), (0, 4, 8)])
+def test_conv_nhwc_tiny_and_empty_images(S, shape):
+    """Images smaller than one M block, a single pixel, an empty batch: every edge mode of the tile loop."""
+    from stereoformer_amd import conv_split as C
+    B, H, W = shape
+    torch.manual_seed(89)
+    x = torch.randn(B, 32, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    if not x.is_contiguous(memory_format=torch.channels_last) or x.is_contiguous():
+        x = torch.empty_strided((B, 32, H, W), (32 * H * W, 1, 32 * W, 32), device="cuda").copy_(torch.randn(B, 32, H, W, device="cuda"))
+    m = nn.Conv2d(32, 48, 3, padding=1).cuda()
+    with torch.no_grad():
+        if not C.supported([x], [m]):      # (1x1 images are both NCHW- and NHWC-contiguous: torch cannot tell them apart)
+            pytest.skip("layout-ambiguous shape")
+        (o,) = C.conv_nhwc([x], [m])
+        r = m(x)
+    assert o.shape == r.shape
+    if B:
+        assert float((o - r).abs().max()) <= 2e-5 * max(1.0, float(r.abs().max()))
