@@ -1,6 +1,7 @@
-"""Error audit of the split-bf16 cross-attention kernels against the CPU oracle (dev tool; the oracle is test infrastructure):
+"""Error audit of the split-bf16 cross-attention kernels against the CPU oracle (a script, not a collected test; it lives under
+tests/ because only tests may use the oracle):
 per config, max / mean |disparity error| and max |output error| for fp32 and fp16 features, both mask modes.
-    python tools/a7_audit.py > profiles/r02c_a7_error_audit.txt"""
+    python tests/audit_a7.py > profiles/r02c_a7_error_audit.txt"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

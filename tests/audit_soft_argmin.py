@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Error of the soft-argmin family against an fp64 ground truth (numpy), next to the fp32 C oracle's
+"""(A script, not a collected test; under tests/ because only tests may use the oracle.)
+Error of the soft-argmin family against an fp64 ground truth (numpy), next to the fp32 C oracle's
 own error: tells summation-order noise from exp() approximation error."""
 import os, sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))

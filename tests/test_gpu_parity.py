@@ -442,7 +442,7 @@ def _cross_attention(S, oracle, cfg):
             oo, od = oracle.cross_attention(L, R, V, D, mask, scale)
             close(o, oo, rtol=1e-4, atol=5e-5)
             # fp32 logit-accumulation noise is amplified by the spread of d: the mean-error budget grows
-            # with D (tools/accuracy_probe.py: the oracle itself sits 5e-5 from fp64 truth at D=352)
+            # with D (tests/audit_soft_argmin.py: the oracle itself sits 5e-5 from fp64 truth at D=352)
             close(d, od, rtol=0, atol=1e-3, mean_atol=2.5e-4 * max(1.0, D / 192.0))
     # value defaults to the right features (one staged tile serves as K and V when C <= 32)
     o, d = S.CrossAttentionCostVolume(D, "neginf", "sqrt_c")(dev(L), dev(R))
