@@ -62,6 +62,11 @@ def test_product_never_imports_the_oracle():
                 assert "libstereo_oracle" not in txt, f
     code = "import sys; import stereoformer_amd; assert 'oracle' not in sys.modules"
     subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+    # dev tools: only bench.py's cpu_baseline leg (tools/bench_configs.py) may reach the oracle; audit scripts live under tests/
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith(".py") and f != "bench_configs.py":
+            txt = open(os.path.join(ROOT, "tools", f)).read()
+            assert not re.search(r"^\s*(import|from)\s+oracle|import oracle", txt, flags=re.M), f
 
 
 def test_host_helpers_cpu():
