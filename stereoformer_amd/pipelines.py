@@ -167,10 +167,15 @@ class RAFTStereoLoop(nn.Module):
         return preds
 
 class LowCNNGRULoop(nn.Module):
-    def __init__(self, input_channels=24, hidden_dim=32, sample_points=20):
+    def __init__(self, input_channels=24, hidden_dim=32, sample_points=20, channels_last=False):
+        """``channels_last``: keep the updater's weights and activations in NHWC; for inference its 3x3 convolutions (GRU gates,
+        offset head, mask head) then run on the library's own convolution kernels (``conv_split``), the two encoder convolutions
+        (24 and 3 input channels) and the 1x1 mask projection stay with MIOpen.  Same arithmetic to fp32 rounding; off by
+        default."""
         super().__init__()
         self.update = DisparityUpdateDLCWithMask(input_channels=input_channels, hidden_dim=hidden_dim,
                                                  sample_points=sample_points)
+        self.channels_last = bool(channels_last)
         self._graphs = _GraphCache()
 
     def forward(self, cost_volume, disp, left_image, right_image, iters=12, use_graph=False, graph_all_iterates=False):
@@ -180,12 +185,15 @@ class LowCNNGRULoop(nn.Module):
         graph replay is inference-only."""
         B, D, h, w = cost_volume.shape
         hidden = torch.zeros(B, 2 * self.update.hidden_dim, h, w, device=cost_volume.device)
+        if self.channels_last:
+            self.update.to(memory_format=torch.channels_last)   # no-op once converted
+            hidden = hidden.contiguous(memory_format=torch.channels_last)
         if use_graph:
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
                 raise RuntimeError("LowCNNGRULoop: use_graph=True is an inference path; call it under torch.no_grad()")
 
             def fn(ts):
-                d, hid = ts[1], torch.zeros_like(hidden)
+                d, hid = ts[1], torch.zeros_like(hidden)   # (preserves the channels-last layout)
                 outs = []
                 for it in range(iters):   # unless every iterate is wanted, only the last one is upsampled: the
                     last = it == iters - 1  # earlier mask heads are skipped
@@ -195,7 +203,7 @@ class LowCNNGRULoop(nn.Module):
                 return outs
 
             key = (tuple(cost_volume.shape), tuple(left_image.shape), iters, cost_volume.device.index,
-                   bool(graph_all_iterates))
+                   bool(graph_all_iterates), self.channels_last)
             return self._graphs.run(key, fn, [cost_volume, disp, left_image, right_image])
         outs = []
         for _ in range(iters):

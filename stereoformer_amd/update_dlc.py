@@ -132,6 +132,15 @@ def gru_blend(h, zc, qc, cz=None, cq=None, softsign=False):
     return out
 
 
+def _split_convs_ok(*ts):
+    """Inference on channels-last fp32 HIP activations outside autocast / tracing: where the 3x3 convolutions go to
+    ``conv_split`` (see ``update_raft._split_ok``)."""
+    if torch.is_grad_enabled() or torch.is_autocast_enabled("cuda") or torch.compiler.is_compiling():
+        return False
+    return all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 for t in ts) and \
+        ts[0].is_contiguous(memory_format=torch.channels_last) and not ts[0].is_contiguous()
+
+
 class ConvGRU(nn.Module):
     """``ConvGRU(nb_channel, softsign)`` (Attempts/update.py:17-49)."""
 
@@ -157,6 +166,21 @@ class ConvGRU(nn.Module):
         if prev_h is None:  # the reference hard-codes .cuda() here (:38-39)
             prev_h = torch.zeros(input.size(0), self.nb_channel, input.size(2), input.size(3), device=input.device,
                                  dtype=input.dtype)
+        if _split_convs_ok(input, prev_h):
+            from . import conv_split as C
+            if prev_h.is_contiguous() and not prev_h.is_contiguous(memory_format=torch.channels_last):
+                prev_h = prev_h.contiguous(memory_format=torch.channels_last)
+            srcs = [input, prev_h]                                    # the reference's cat order (:40)
+            if (prev_h.is_contiguous(memory_format=torch.channels_last) and C.supported(srcs, [self.conv_z])
+                    and C.supported(srcs, [self.conv_b]) and C.supported([prev_h, input], [self.conv_g])):
+                # inference in torch.channels_last: the three gate convolutions on conv_split (no concatenation is materialised)
+                if C.supported(srcs, [self.conv_z, self.conv_b]):
+                    zc, bc = C.conv_nhwc(srcs, [self.conv_z, self.conv_b])
+                else:
+                    (zc,), (bc,) = C.conv_nhwc(srcs, [self.conv_z]), C.conv_nhwc(srcs, [self.conv_b])
+                s = gru_reset(prev_h, bc)
+                (gc,) = C.conv_nhwc([s, input], [self.conv_g])
+                return gru_blend(prev_h, zc, gc, softsign=self.softsign)
         x1 = torch.cat((input, prev_h), 1)
         zc = self.conv_z(x1)
         bc = self.conv_b(x1)
@@ -205,6 +229,13 @@ class OffsetPredictionHead(nn.Module):
         self.relu2 = nn.ReLU(inplace=True)
 
     def forward(self, x):
+        if _split_convs_ok(x):
+            from . import conv_split as C
+            if C.supported([x], [self.conv1]):
+                (y,) = C.conv_nhwc([x], [self.conv1], relu=True)
+                if C.small_supported(y, self.conv2):
+                    return self.relu2(C.conv3x3_small(y, self.conv2))     # (64 -> 2: fp32 vector kernel, NCHW out)
+                return self.relu2(self.conv2(y))
         return self.relu2(self.conv2(self.relu1(self.conv1(x))))
 
 
@@ -250,7 +281,14 @@ class DisparityUpdateDLCWithMask(nn.Module):
         inference loop that only upsamples its last iterate does not need the earlier masks."""
         offset_features = self.encoder(old_cost_volume, cur_disp, left_image, right_image)
         hidden_state = self.gru(offset_features, hidden_state)
-        mask = .25 * self.mask(hidden_state) if need_mask else None
+        mask = None
+        if need_mask:
+            m0 = None
+            if _split_convs_ok(hidden_state):
+                from . import conv_split as C
+                if C.supported([hidden_state], [self.mask[0]]):
+                    (m0,) = C.conv_nhwc([hidden_state], [self.mask[0]], relu=True)
+            mask = .25 * (self.mask[2](m0) if m0 is not None else self.mask(hidden_state))
         bounds = self.offset(hidden_state)          # [B,2,h,w]: (lower offset, upper offset)
         disp = bounds_lookup(old_cost_volume, cur_disp, bounds, self.sample_points, consider_valid)
         return disp, hidden_state, mask

@@ -307,3 +307,31 @@ def test_cfg5_attention_flow_init_loop_chain(S, oracle):
     init = torch.cat([-d.unsqueeze(1), torch.zeros_like(d.unsqueeze(1))], 1)
     lo, _ = _check_final_iterate(S, oracle, loop, f1, f2, nets, inps, 16, flow_init=init)
     assert (lo[:, :1] + d.unsqueeze(1)).abs().mean().item() < 50   # the loop moved from, not ignored, its start
+
+
+def test_lowcnn_gru_loop_channels_last_takes_the_split_convolutions(S, monkeypatch):
+    """LowCNNGRULoop(channels_last=True): the updater's 3x3 convolutions (GRU gates, offset head, mask head) run on conv_split
+    (asserted); same disparities as the default (library-convolution) loop to fp32 rounding, eager and graph."""
+    import copy
+    from stereoformer_amd import conv_split as C
+    B, D, h, w = 2, 24, 36, 60
+    torch.manual_seed(2)
+    ref = S.LowCNNGRULoop(D, 32, 20).eval().cuda()
+    cl = S.LowCNNGRULoop(D, 32, 20, channels_last=True).eval().cuda()
+    cl.load_state_dict(copy.deepcopy(ref.state_dict()))
+    vol = torch.randn(B, D, h, w, device="cuda")
+    left = torch.randn(B, 3, 8 * h, 8 * w, device="cuda")
+    right = torch.randn(B, 3, 8 * h, 8 * w, device="cuda")
+    disp = S.DisparityEstimation(D)(vol).unsqueeze(1)
+    calls = []
+    real = C.conv_nhwc
+    monkeypatch.setattr(C, "conv_nhwc", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    with torch.no_grad():
+        a = ref(vol, disp, left, right, iters=5)
+        assert not calls
+        b = cl(vol, disp, left, right, iters=5)
+        assert len(calls) == 5 * 5                      # per iteration: z, b, g gates + offset.conv1 + mask[0]
+        g = cl(vol, disp, left, right, iters=5, use_graph=True, graph_all_iterates=True)
+    for x, y, z in zip(a, b, g):
+        assert x.shape == y.shape and float((x - y).abs().max()) < 2e-3 * max(1.0, float(x.abs().max()) / 50), float((x - y).abs().max())
+        assert float((y - z).abs().max()) < 1e-4

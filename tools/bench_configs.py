@@ -330,7 +330,7 @@ def cfg4(dev, rank, world, steps, warmup, cpu, mixed=False):
     disp = torch.rand(B, 1, 72, 120, device=dev, generator=g) * 20
     li = torch.randn(B, 3, 576, 960, device=dev, generator=g)
     ri = torch.randn(B, 3, 576, 960, device=dev, generator=g)
-    lp = S.LowCNNGRULoop(24, 32, 20).eval().to(dev)
+    lp = S.LowCNNGRULoop(24, 32, 20, channels_last=True).eval().to(dev)
     n = max(steps, 10)
     sec, per_rank = timed(lambda: lp(vol, disp, li, ri, iters=16, use_graph=True), n, warmup, world, dev)
     roof2 = None
@@ -347,7 +347,8 @@ def cfg4(dev, rank, world, steps, warmup, cpu, mixed=False):
         cb = _guard(leg2)
     out.append(entry("cfg-4 (LowCNN GRU updater)", "16 x DisparityUpdateDLCWithMask (baseline_dynamic_gru) at 1/8 resolution "
                      "[8,24,72,120] + convex upsampling x8 of the last iterate, batch=8 per GPU, fp32", B, world, sec, per_rank, n,
-                     warmup, roof2, cb, {"bounded_by": "MIOpen convolutions (Winograd / GEMM) of the updater"}))
+                     warmup, roof2, cb, {"bounded_by": "the updater's convolutions (3x3: csrc/conv_split.hip; encoder and 1x1 mask projection: MIOpen) "
+                                      "and ~30 small launches per iteration"}))
     return out
 
 

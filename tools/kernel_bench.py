@@ -363,6 +363,10 @@ def main():
             ms = timeit(lambda: lp(v, dsp, li, ri, iters=16, use_graph=True, graph_all_iterates=True), 3, 1)
             add("cfg-4 LowCNN-GRU loop 16 iters B=8 graph (all iterates)", ms, None, None,
                 note=f"{8 / ms * 1e3:.1f} pairs/s per GPU")
+            lpc = S.LowCNNGRULoop(24, 32, 20, channels_last=True).eval().cuda()
+            ms = timeit(lambda: lpc(v, dsp, li, ri, iters=16, use_graph=True), 3, 1)
+            add("cfg-4 LowCNN-GRU loop 16 iters B=8 channels_last graph (last iterate) [3x3 convolutions on conv_split]", ms, None, None,
+                note=f"{8 / ms * 1e3:.1f} pairs/s per GPU")
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "kernel_bench.json"), "w"), indent=1)
 
