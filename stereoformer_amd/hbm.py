@@ -60,10 +60,12 @@ def _event_ms(fn, reps):
     return best
 
 
-def place_volume_stage_outputs(left, right, maxdisp, num_groups, max_tries=6, probe_reps=2, good_enough_tbs=6.0):
+def place_volume_stage_outputs(left, right, maxdisp, num_groups, max_tries=6, probe_reps=2, good_enough_tbs=6.3):
     """Output buffers ``(vol [B,G,D,H,W], disp [B,H,W], mean [B,D,H,W])`` for ``build_gwc_volume_with_disparity(..., out=...)``
     placed by timing that very launch on each candidate (``left`` / ``right`` are only read).  ``good_enough_tbs``: stop at the
-    first candidate that streams the algorithmic bytes faster than this (TB/s)."""
+    first candidate that streams the algorithmic bytes faster than this (TB/s): 6.3 is the fast level itself (4.64-4.72 ms at
+    cfg-2); probe times taken while the other candidates are still held run a few percent above the steady state, so a looser
+    threshold would stop at a middling arena."""
     from .cost_volume import build_gwc_volume_with_disparity
     B, C, H, W = left.shape
     D, G = int(maxdisp), int(num_groups)
