@@ -255,7 +255,7 @@ def main():
     # the fastest is kept -- the launch's speed is a stable property of the physical memory behind its outputs.
     placed, placement = None, None
     if not args.no_placement and not args.reread:
-        tries = 2 if args.rehearse_on_one_gpu else 6
+        tries = 2 if args.rehearse_on_one_gpu else 8
         placed, placement = S.hbm.place_volume_stage_outputs(L, R, D, G, max_tries=tries)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
