@@ -243,3 +243,23 @@ def test_hbm_place_keeps_the_fastest_candidate_and_frees_the_rest():
     made.clear(), alive.clear()
     best, rep = hbm.place(alloc, lambda b: times[b.i], max_tries=5, good_enough_ms=4.8)
     assert best.i == 2 and len(rep["probe_ms"]) == 3          # stopped at the first good-enough candidate
+
+
+def test_conv_split_is_never_taken_on_cpu_tensors():
+    """The update blocks run on CPU tensors in bench.py's cpu_baseline leg (custom ops routed to the oracle there): the HIP
+    convolution kernels must not be selected for them, and asking for them directly fails loudly."""
+    import torch
+    import torch.nn as nn
+    from stereoformer_amd import conv_split as C
+    from stereoformer_amd.update_raft import _split_ok
+    x = torch.randn(1, 16, 8, 32).contiguous(memory_format=torch.channels_last)
+    m = nn.Conv2d(16, 32, 3, padding=1)
+    with torch.no_grad():
+        assert not C.supported([x], [m]) and not C.small_supported(x, nn.Conv2d(16, 2, 3, padding=1)) and not _split_ok(x)
+        try:
+            C.conv_nhwc([x], [m])
+        except ValueError as e:
+            assert "envelope" in str(e)
+        else:
+            raise AssertionError("conv_nhwc accepted a CPU tensor")
+    assert C.set_precision("high") == "highest" and C.set_precision("highest") == "high"
