@@ -228,3 +228,31 @@ def test_conv_nhwc_tiny_and_empty_images(S, shape):
     assert o.shape == r.shape
     if B:
         assert float((o - r).abs().max()) <= 2e-5 * max(1.0, float(r.abs().max()))
+
+
+def test_conv_nhwc_random_shapes_sweep(S):
+    """40 random (batch, size, source split, output split, kernel, ReLU, bias) combinations against the library's fp32 result."""
+    from stereoformer_amd import conv_split as C
+    g = torch.Generator().manual_seed(90)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    for case in range(40):
+        B, H, W = ri(1, 3), ri(1, 21), ri(1, 75)
+        cs = tuple(16 * ri(1, 4) for _ in range(ri(1, 4)))
+        nout = ri(1, 3)
+        co = tuple([128 * ri(1, 2 if nout < 3 else 1) for _ in range(nout - 1)] + [ri(1, 160)])
+        if sum(co) > 512:
+            co = co[-1:]
+        k = 3 if ri(0, 3) else 1
+        relu, bias = bool(ri(0, 1)), bool(ri(0, 1))
+        srcs = [torch.empty_strided((B, c, H, W), (c * H * W, 1, c * W, c), device="cuda").copy_(torch.randn(B, c, H, W, device="cuda"))
+                for c in cs]
+        convs = [nn.Conv2d(sum(cs), c, k, padding=k // 2, bias=bias).cuda() for c in co]
+        with torch.no_grad():
+            if not C.supported(srcs, convs):
+                continue                      # (layout-ambiguous 1 x 1 images)
+            outs = C.conv_nhwc(srcs, convs, relu=relu)
+            x = torch.cat(srcs, 1)
+            for o, m in zip(outs, convs):
+                r = F.relu(m(x)) if relu else m(x)
+                assert o.shape == r.shape, (case, B, H, W, cs, co, k)
+                assert float((o - r).abs().max()) <= 3e-5 * max(1.0, float(r.abs().max())), (case, B, H, W, cs, co, k, relu, bias)
