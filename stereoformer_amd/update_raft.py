@@ -75,6 +75,18 @@ def _split_ok(*ts):
                              and t.is_contiguous(memory_format=torch.channels_last)) for t in ts)
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+    """One side stream per device for the motion encoder (see ``BasicMultiUpdateBlock_LZH.forward``)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SIDE.get(idx)
+    if st is None:
+        st = _SIDE[idx] = torch.cuda.Stream(device=idx)
+    return st
+
+
 def _gru_step_split(h, xs, conv_z, conv_r, conv_q, cz, cr, cq):
     """The ConvGRU update with its convolutions on ``conv_split`` (inference, channels-last fp32): ``convz`` and ``convr`` are
     ONE launch over the sources ``[h | x...]`` (no concatenation is materialised), ``convq`` a second one over
@@ -189,6 +201,16 @@ class BasicMultiUpdateBlock_LZH(nn.Module):
         """``need_mask=False`` (not in the reference) skips the upsampling-mask head and returns ``None`` for it: in
         ``test_mode`` the reference computes the mask in every iteration but only reads the last one
         (``raft_stereo.py:184-185``) -- 13 % of the block's FLOPs."""
+        # The motion encoder depends on (flow, corr) only, the coarse GRUs on the hidden states only -- and the coarse GRUs'
+        # launches are small (1/16 scale: 288 workgroups for 1024 slots): for inference the encoder runs on a side stream
+        # under them (fork / join by events: capturable in a HIP graph).
+        motion, side = None, None
+        if iter08 and (iter16 or iter32) and _split_ok(net[0]) and flow is not None and flow.is_cuda:
+            cur = torch.cuda.current_stream(flow.device)
+            side = _side_stream(flow.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                motion = self.encoder(self._like(flow, net[0]), self._like(corr, net[0]))
         if iter32:
             net[2] = self.gru32(net[2], *inp[2], pool2x(net[1]))
         if iter16:
@@ -196,7 +218,12 @@ class BasicMultiUpdateBlock_LZH(nn.Module):
             net[1] = self.gru16(net[1], *inp[1], pool2x(net[0]), *extra)
         if iter08:
             extra = (self._like(interp(_f32(net[1]), net[0]), net[0]),) if self.n_gru_layers > 1 else ()
-            net[0] = self.gru08(net[0], *inp[0], self.encoder(self._like(flow, net[0]), self._like(corr, net[0])), *extra)
+            if side is not None:
+                cur.wait_stream(side)
+                motion.record_stream(cur)     # allocated on the side stream, consumed (and freed) on this one
+            else:
+                motion = self.encoder(self._like(flow, net[0]), self._like(corr, net[0]))
+            net[0] = self.gru08(net[0], *inp[0], motion, *extra)
         if not update:
             return net
         h0 = net[0]
