@@ -347,6 +347,45 @@ int stereo_conv_nhwc_f16(const void *const *srcs, const int *src_channels, int n
                          void *const *outs, const int *out_channels, const int *out_strides, int nout, int ksize, int relu,
                          int B, int H, int W, void *stream);
 
+/* The general form of the three entry points above: arithmetic form selected by `arith`, and a per-destination EPILOGUE that
+ * replaces the pointwise launches around the ConvGRU's convolutions (update/update.py:28-32: z = sigmoid(convz(hx) + cz),
+ * r = sigmoid(convr(hx) + cr), q = tanh(convq([r h, x]) + cq), h' = (1 - z) h + z q).
+ *   arith   STEREO_CONV_F32_F16X3   fp32 activations, every operand as two fp16 pieces x = hi + 2^-11 lo' (22-23 significant
+ *                                   bits), the three leading piece products (each exact in fp32) into two fp32 accumulators:
+ *                                   fp32-faithful for |x| < 65 504 (inf / NaN beyond, never silently wrong), HALF the matrix
+ *                                   work of the bf16 form.  The host layer's default for fp32 activations.
+ *           STEREO_CONV_F32_BF16X6  = stereo_conv_nhwc_f32 (three bf16 pieces, six products: fp32's full exponent range)
+ *           STEREO_CONV_F32_BF16X3  = stereo_conv_nhwc_f32_bf16x3        STEREO_CONV_F16  = stereo_conv_nhwc_f16
+ *           (`packed` must come from stereo_conv_pack_weights_ex with the same `arith`.)
+ *   epilogue[j] (NULL: all linear), with t = conv + bias + addend[j] (addend[j], aux0[j], aux1[j]: tensors of destination j's
+ *   geometry [B][H][W][out_strides[j]] and element type, or NULL; `relu` only with linear epilogues):
+ *           STEREO_EPI_LINEAR       out = t (ReLU if `relu`)
+ *           STEREO_EPI_SIGMOID      out = sigmoid(t)                                  (z; addend = cz)
+ *           STEREO_EPI_SIGMOID_MUL  out = sigmoid(t) * aux0                           (r h; addend = cr, aux0 = h)
+ *           STEREO_EPI_GRU_BLEND    out = (1 - aux1) * aux0 + aux1 * tanh(t)          (h'; addend = cq, aux0 = h, aux1 = z)
+ *           STEREO_EPI_GRU_BLEND_SOFTSIGN   the same with t / (1 + |t|) in place of tanh(t)   (Attempts/update.py:33-34)
+ *   out may alias aux0 / aux1 / addend element for element (every output element is read and written by the same thread). */
+#define STEREO_CONV_F32_BF16X6 0
+#define STEREO_CONV_F32_BF16X3 1
+#define STEREO_CONV_F16 2
+#define STEREO_CONV_F32_F16X3 3
+#define STEREO_EPI_LINEAR 0
+#define STEREO_EPI_SIGMOID 1
+#define STEREO_EPI_SIGMOID_MUL 2
+#define STEREO_EPI_GRU_BLEND 3
+#define STEREO_EPI_GRU_BLEND_SOFTSIGN 4
+long long stereo_conv_packed_bytes_ex(int arith, int Cout, int Cin, int ksize);
+int stereo_conv_pack_weights_ex(int arith, const float *weight, void *packed, int Cout, int Cin, int ksize, void *stream);
+int stereo_conv_nhwc_ex(int arith, const void *const *srcs, const int *src_channels, int nsrc, const void *packed,
+                        const float *bias, void *const *outs, const int *out_channels, const int *out_strides, int nout,
+                        const int *epilogue, const void *const *addend, const void *const *aux0, const void *const *aux1,
+                        int ksize, int relu, int B, int H, int W, void *stream);
+
+/* Content fingerprints of `n` device tensors (fp32 parameters: nbytes[k] % 4 == 0) in one launch: out[k] (device, n x 64 bit)
+ * = a position-dependent 64-bit hash sum of tensor k's words.  The host layer compares them once per forward of a loop to
+ * rebuild packed weights after an in-place update through `tensor.data`, which leaves no host-visible trace. */
+int stereo_fingerprint(const void *const *tensors, const long long *nbytes, int n, unsigned long long *out, void *stream);
+
 /* 3x3 stride-1 "same" convolution with 1..4 output channels (flow_head.conv2, update.py:11-14: 256 -> 2) on the fp32 vector
  * units: x [B][H][W][Cin] channels-last (Cin % 32 == 0), weight_tco = weight.permute(2, 3, 1, 0) contiguous, i.e.
  * [3][3][Cin][Cout]; bias [Cout] or NULL; out_nchw [B][Cout][H][W]. */

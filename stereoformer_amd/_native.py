@@ -76,6 +76,12 @@ SIGNATURES = {
                              ctypes.POINTER(_i), _i, _i, _i, _i, _i, _i, _vp],
     "stereo_conv_nhwc_f32": [ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_i),
                              ctypes.POINTER(_i), _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_conv_packed_bytes_ex": [_i, _i, _i, _i],
+    "stereo_conv_pack_weights_ex": [_i, _vp, _vp, _i, _i, _i, _vp],
+    "stereo_conv_nhwc_ex": [_i, ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_i),
+                            ctypes.POINTER(_i), _i, ctypes.POINTER(_i), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                            ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _vp],
+    "stereo_fingerprint": [ctypes.POINTER(_vp), ctypes.POINTER(_ll), _i, _vp, _vp],
     "stereo_soft_argmin_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_gwc_volume_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_local_lookup_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
@@ -98,7 +104,8 @@ SIGNATURES = {
 }
 _RESTYPE = {"stereo_strerror": ctypes.c_char_p, "stereo_alt_corr_workspace_floats": _ll,
             "stereo_instance_norm_workspace_bytes": _ll, "stereo_conv_packed_bytes": _ll,
-            "stereo_conv_packed_bytes_f16": _ll, "stereo_conv_packed_bytes_bf16x3": _ll}
+            "stereo_conv_packed_bytes_f16": _ll, "stereo_conv_packed_bytes_bf16x3": _ll,
+            "stereo_conv_packed_bytes_ex": _ll}
 
 _lib = None
 

@@ -4,31 +4,64 @@
 kernel, stride 1, padding k // 2, the same input) for channels-last fp32 activations, as ONE launch of
 ``csrc/conv_split.hip``: the concatenation is never materialised (the kernel's K loop walks the sources), the bias and an
 optional ReLU ride in the epilogue, and several modules that read the same input (``convz`` | ``convr``; ``flow_head.conv1`` |
-``mask[0]``) run as one convolution whose output channels are scattered to one tensor per module.  Arithmetic: fp32-faithful
-split-bf16 on ``v_mfma_f32_32x32x16_bf16`` (see the kernel's header).
+``mask[0]``) run as one convolution whose output channels are scattered to one tensor per module.  ``epilogue=`` puts the
+ConvGRU's gate math (``update.py:28-32``) into the same launch: ``sigmoid(conv + c)``, ``sigmoid(conv + c) * h`` and
+``(1 - z) * h + z * tanh(conv + c)`` instead of separate pointwise kernels over materialised pre-activations.
+
+Arithmetic on fp32 activations (``precision``):
+
+* ``"highest"`` (default, the parity configuration) -- every operand as two fp16 pieces ``x = hi + 2^-11 lo'`` (22-23 significant
+  bits), the three leading piece products (each exact in fp32) into two fp32 accumulators on ``v_mfma_f32_32x32x16_f16``:
+  fp32-faithful for ``|x| < 65504`` -- the range the reference's own ``mixed_precision`` flag assumes for this block; beyond it
+  the result is inf / NaN, never silently wrong.
+* ``"bf16x6"`` -- three bf16 pieces, six piece products: the same fidelity over fp32's whole exponent range at twice the matrix
+  work (round 2's default).
+* ``"high"`` -- two bf16 pieces, three products ("bf16x3", ~2^-16 relative error per product: the counterpart of
+  ``torch.set_float32_matmul_precision('high')``).  NOT a parity configuration.
+
+fp16 activations (the block under ``mixed_precision``) are the operands of the fp16 MFMA as they are.
 
 Inference only (no autograd formula: the training path keeps the library convolutions); ``supported(...)`` tells a caller whether
-its tensors are inside the kernel's envelope."""
+its tensors are inside the kernel's envelope.
+
+Packed weights are cached per module and keyed by what the host can see of a parameter (identity, storage address, version
+counter, shape).  An in-place update through ``param.data`` (``m.weight.data.copy_(w)``, EMA swaps ...) changes none of those:
+``refresh(root)`` compares CONTENT fingerprints computed on the device (one launch + one 8-byte-per-tensor read-back for a whole
+module tree; the loops in ``pipelines.py`` call it once per forward) and drops what went stale; ``invalidate(root)`` drops
+everything unconditionally."""
 from __future__ import annotations
 
 import ctypes
+import threading
 
 import torch
 
 from . import _native as N
 
-_PRECISION = "highest"
+ARITH = {"bf16x6": 0, "bf16x3": 1, "f16": 2, "f16x3": 3}
+_ALIAS = {"highest": "f16x3", "high": "bf16x3"}
+EPILOGUES = {"linear": 0, "sigmoid": 1, "sigmoid_mul": 2, "gru_blend": 3, "gru_blend_softsign": 4}
+_N_OPERANDS = {"linear": 0, "sigmoid": 1, "sigmoid_mul": 2, "gru_blend": 3, "gru_blend_softsign": 3}   # (addend, aux0, aux1) taken by each
+_tls = threading.local()
+
+
+def _form(precision):
+    name = _ALIAS.get(precision, precision)
+    if name not in ("f16x3", "bf16x6", "bf16x3"):
+        raise ValueError("conv_split: precision is 'highest' (= 'f16x3'), 'bf16x6' or 'high' (= 'bf16x3')")
+    return name
+
+
+def get_precision():
+    return getattr(_tls, "precision", "highest")
 
 
 def set_precision(precision):
-    """Arithmetic of ``conv_nhwc`` on fp32 activations: ``"highest"`` (default, the parity configuration: three bf16 pieces per
-    value, six piece products -- fp32-faithful) or ``"high"`` (two pieces, three products, "bf16x3": ~2^-16 relative error per
-    product -- the counterpart of ``torch.set_float32_matmul_precision('high')`` -- at half the matrix work).  Returns the
-    previous setting."""
-    global _PRECISION
-    if precision not in ("highest", "high"):
-        raise ValueError("conv_split.set_precision: 'highest' or 'high'")
-    prev, _PRECISION = _PRECISION, precision
+    """Default arithmetic of ``conv_nhwc`` on fp32 activations FOR THE CALLING THREAD (see the module docstring); an explicit
+    ``precision=`` argument wins.  Returns the previous setting."""
+    _form(precision)
+    prev = get_precision()
+    _tls.precision = precision
     return prev
 
 
@@ -71,13 +104,43 @@ def supported(srcs, convs) -> bool:
     return total <= 512
 
 
+# ---------------------------------------------------------------------------------------------- packed-weight cache
+def _version(p):
+    try:
+        return p._version
+    except RuntimeError:      # inference tensors carry no version counter
+        return -1
+
+
+def _params(convs):
+    return [p for m in convs for p in (m.weight, m.bias) if p is not None]
+
+
 def _signature(convs, device):
-    """What a packed copy depends on: the identity, storage address and in-place version of every parameter involved."""
+    """What the host can see of the parameters a packed copy depends on."""
     sig = [device.index]
     for m in convs:
         for p in (m.weight, m.bias):
-            sig.append(None if p is None else (id(p), p.data_ptr(), p._version, tuple(p.shape)))
+            sig.append(None if p is None else (id(p), p.data_ptr(), _version(p), tuple(p.shape)))
     return tuple(sig)
+
+
+def fingerprints(tensors):
+    """Content fingerprints (python ints) of fp32 HIP tensors: one launch (``stereo_fingerprint``) and one small read-back."""
+    tensors = [t.detach() for t in tensors]
+    if not tensors:
+        return []
+    dev = tensors[0].device
+    for t in tensors:
+        dense = t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+        if not (t.is_cuda and t.device == dev and t.dtype == torch.float32 and dense):
+            raise ValueError("fingerprints: dense fp32 tensors on one HIP device")
+    out = torch.empty(len(tensors), device=dev, dtype=torch.int64)
+    tp = (N._vp * len(tensors))(*[t.data_ptr() for t in tensors])
+    nb = (N._ll * len(tensors))(*[t.numel() * 4 for t in tensors])
+    with torch.cuda.device(dev):
+        N.call("stereo_fingerprint", tp, nb, len(tensors), N.ptr(out), N.stream_ptr(dev))
+    return [int(v) for v in out.tolist()]
 
 
 def _cached(convs, tag, device, build):
@@ -90,13 +153,57 @@ def _cached(convs, tag, device, build):
     if hit is not None and hit[0] == sig:
         return hit[1]
     val = build()
-    store[key] = (sig, val)
+    # [signature, value, the modules of the group, content fingerprints at build time (filled in by the first refresh() that
+    # sees the entry BEFORE it is trusted across a forward -- see refresh)]
+    store[key] = [sig, val, list(convs), fingerprints(_params(convs))
+                  if not torch.cuda.is_current_stream_capturing() else None]
     return val
 
 
-def _packed(convs, device, sfx=""):
-    """Packed weights (split-bf16 pieces for fp32 activations -- three, or two with ``sfx="_bf16x3"`` --, fp16 for fp16 ones,
-    ``sfx="_f16"``; + the concatenated fp32 bias) of a group of modules; rebuilt when a parameter is replaced or updated in place."""
+def invalidate(root):
+    """Drop every packed copy cached on ``root`` (an ``nn.Module`` tree or an iterable of modules)."""
+    mods = root.modules() if isinstance(root, torch.nn.Module) else root
+    for m in mods:
+        m.__dict__.pop("_stereo_conv_cache", None)
+
+
+def refresh(root):
+    """Re-validate the packed copies cached under ``root`` by CONTENT: fingerprints of all parameters involved are computed on
+    the device in one launch and compared with those taken when each copy was built; stale copies are dropped (and rebuilt by
+    the next call that needs them).  Catches in-place updates through ``param.data``, which bump no version counter.  Costs one
+    small launch and one read-back per call -- made once per forward by the loops, outside any graph capture."""
+    entries = []
+    for m in (root.modules() if isinstance(root, torch.nn.Module) else root):
+        store = m.__dict__.get("_stereo_conv_cache")
+        if store:
+            entries += [(store, k, e) for k, e in store.items()]
+    if not entries or torch.cuda.is_current_stream_capturing():
+        return 0
+    by_dev = {}
+    for store, k, e in entries:
+        ps = _params(e[2])
+        if ps and ps[0].is_cuda:
+            by_dev.setdefault(ps[0].device, []).append((store, k, e, ps))
+        else:
+            store.pop(k, None)       # parameters moved off the device: the copy is dead
+    dropped = 0
+    for dev, items in by_dev.items():
+        flat = [p for it in items for p in it[3]]
+        fps = fingerprints(flat)
+        pos = 0
+        for store, k, e, ps in items:
+            cur = fps[pos:pos + len(ps)]
+            pos += len(ps)
+            if e[3] is None or e[3] != cur:
+                store.pop(k, None)
+                dropped += 1
+    return dropped
+
+
+def _packed(convs, device, form):
+    """Packed weights of a group of modules in the operand form ``form`` (+ the concatenated fp32 bias); rebuilt when a parameter
+    is replaced or updated in place."""
+    arith = ARITH[form]
 
     def build():
         with torch.no_grad():
@@ -106,21 +213,25 @@ def _packed(convs, device, sfx=""):
                 bias = torch.cat([m.bias.detach() if m.bias is not None else torch.zeros(m.out_channels, device=device)
                                   for m in convs]).contiguous()
             cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
-            nbytes = getattr(N.load(), "stereo_conv_packed_bytes" + sfx)(cout, cin, k)
+            nbytes = N.load().stereo_conv_packed_bytes_ex(arith, cout, cin, k)
             if nbytes <= 0:
                 raise ValueError(f"conv_nhwc: unsupported weight shape {tuple(w.shape)}")
             packed = torch.empty(nbytes, device=device, dtype=torch.uint8)
             with torch.cuda.device(device):
-                N.call("stereo_conv_pack_weights" + sfx, N.ptr(w), N.ptr(packed), cout, cin, k, N.stream_ptr(device))
+                N.call("stereo_conv_pack_weights_ex", arith, N.ptr(w), N.ptr(packed), cout, cin, k, N.stream_ptr(device))
         return packed, bias, k
-    return _cached(convs, "split" + sfx, device, build)
+    return _cached(convs, "split_" + form, device, build)
 
 
-def conv_nhwc(srcs, convs, relu=False, out_channels_total=None):
+def conv_nhwc(srcs, convs, relu=False, out_channels_total=None, epilogue=None, precision=None):
     """``[m(torch.cat(srcs, 1)) for m in convs]`` (optionally followed by ReLU), channels-last fp32 (or fp16: what the modules give
     under fp16 autocast) in and out, one launch.
     ``out_channels_total`` (single module only): allocate the output with that many channels and fill the first
-    ``out_channels`` of them -- the caller owns the rest (the motion encoder appends the 2 flow channels, update.py:89-91)."""
+    ``out_channels`` of them -- the caller owns the rest (the motion encoder appends the 2 flow channels, update.py:89-91).
+    ``epilogue``: one entry per module, ``None`` (linear) or a tuple -- with ``t = m(cat(srcs)) + c`` (``c`` may be ``None``):
+    ``("sigmoid", c)`` -> ``sigmoid(t)``; ``("sigmoid_mul", c, h)`` -> ``sigmoid(t) * h``; ``("gru_blend", c, h, z)`` ->
+    ``(1 - z) * h + z * tanh(t)`` (``"gru_blend_softsign"``: ``t / (1 + |t|)`` for the tanh); ``("linear", c)`` -> ``t``.  The operand tensors have the output's shape, layout and dtype.
+    ``precision``: see the module docstring (default: the calling thread's ``set_precision`` value)."""
     srcs = list(srcs)
     convs = list(convs)
     if not supported(srcs, convs):
@@ -129,20 +240,45 @@ def conv_nhwc(srcs, convs, relu=False, out_channels_total=None):
         raise ValueError("conv_nhwc: out_channels_total applies to one module and must cover its output channels")
     dev = srcs[0].device
     half = srcs[0].dtype == torch.float16
-    sfx = "_f16" if half else ("_bf16x3" if _PRECISION == "high" else "")
-    packed, bias, k = _packed(convs, dev, sfx)
+    form = "f16" if half else _form(get_precision() if precision is None else precision)
+    packed, bias, k = _packed(convs, dev, form)
     B, _, H, W = srcs[0].shape
     widths = [m.out_channels for m in convs] if out_channels_total is None else [int(out_channels_total)]
     outs = [torch.empty((B, c, H, W), device=dev, dtype=srcs[0].dtype, memory_format=torch.channels_last) for c in widths]
+    n = len(outs)
+    epi = (N._i * n)(*([0] * n))
+    operands = [[None] * n for _ in range(3)]
+    if epilogue is not None:
+        if len(epilogue) != n:
+            raise ValueError("conv_nhwc: one epilogue entry per module")
+        for j, e in enumerate(epilogue):
+            if e is None:
+                continue
+            kind, ops = e[0], list(e[1:])
+            if kind not in EPILOGUES or len(ops) != _N_OPERANDS[kind] + (kind == "linear"):
+                raise ValueError(f"conv_nhwc: bad epilogue {e[0]!r} / operand count")
+            if kind != "linear" and relu:
+                raise ValueError("conv_nhwc: relu applies to linear epilogues only")
+            for i, t in enumerate(ops):
+                if t is None:
+                    if i > 0:
+                        raise ValueError(f"conv_nhwc: epilogue {kind!r} needs its tensor operands")
+                    continue
+                if not (isinstance(t, torch.Tensor) and t.is_cuda and t.device == dev and t.dtype == outs[j].dtype
+                        and t.shape == outs[j].shape and _is_cl(t)):
+                    raise ValueError(f"conv_nhwc: epilogue operands must match the output ({tuple(outs[j].shape)}, "
+                                     f"{outs[j].dtype}, channels-last)")
+                operands[i][j] = t
+            epi[j] = EPILOGUES[kind]
     sp = (N._vp * len(srcs))(*[t.data_ptr() for t in srcs])
     sc = (N._i * len(srcs))(*[t.shape[1] for t in srcs])
-    op = (N._vp * len(outs))(*[t.data_ptr() for t in outs])
-    oc = (N._i * len(outs))(*[m.out_channels for m in convs])
-    os_ = (N._i * len(outs))(*widths)
+    op = (N._vp * n)(*[t.data_ptr() for t in outs])
+    oc = (N._i * n)(*[m.out_channels for m in convs])
+    os_ = (N._i * n)(*widths)
+    aux = [(N._vp * n)(*[None if t is None else t.data_ptr() for t in row]) for row in operands]
     with torch.cuda.device(dev):
-        N.call("stereo_conv_nhwc_f16" if half else "stereo_conv_nhwc_f32" + sfx, sp, sc, len(srcs), N.ptr(packed), N.ptr(bias), op, oc, os_,
-               len(outs), k,
-               1 if relu else 0, B, H, W, N.stream_ptr(dev))
+        N.call("stereo_conv_nhwc_ex", ARITH[form], sp, sc, len(srcs), N.ptr(packed), N.ptr(bias), op, oc, os_, n, epi, aux[0],
+               aux[1], aux[2], k, 1 if relu else 0, B, H, W, N.stream_ptr(dev))
     return outs
 
 
@@ -167,7 +303,7 @@ def conv3x3_small(x, conv):
     B, C, H, W = x.shape
     out = torch.empty((B, conv.out_channels, H, W), device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
-        N.call("stereo_conv3x3_small_nhwc_f16" if half else "stereo_conv3x3_small_nhwc_f32", N.ptr(x), N.ptr(wt),
+        N.call("stereo_conv3x3_small_nhwc_f32" if not half else "stereo_conv3x3_small_nhwc_f16", N.ptr(x), N.ptr(wt),
                N.ptr(None if conv.bias is None else conv.bias.detach()),
                N.ptr(out), B, C, conv.out_channels, H, W, N.stream_ptr(x.device))
     return out

@@ -163,6 +163,23 @@ static inline bool aligned_quad(const void *p) { return (reinterpret_cast<uintpt
 // v_exp_f32 based exp: |rel err| ~1e-6 on the softmax range; far inside the 1e-3 disparity bar
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
+// ConvGRU gate functions (update.py:28-32): shared by the pointwise kernels and the convolution epilogues so that the fused
+// and the separate forms agree bit for bit.  Hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each): |error| <= 3e-7
+// absolute on both -- fp32 rounding level for values in (0, 1) / (-1, 1) -- at 4-5 instructions instead of the ~30-40 of
+// expf + IEEE division / tanhf, which matters inside a convolution epilogue (64 gate values per lane).
+__device__ __forceinline__ float gate_sigmoid(float x)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float gate_tanh(float x)
+{
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
+// (1 - z) h + z q with the contraction spelled out (the compiler's own choice differs from kernel to kernel)
+__device__ __forceinline__ float gate_blend(float z, float h, float q) { return fmaf(z, q, (1.0f - z) * h); }
+__device__ __forceinline__ float gate_softsign(float x) { return x / (1.0f + fabsf(x)); }
+
 // ste_ceil / ste_floor forward values (fixed_local_cost_volume.py:5-9):
 // ceil(x) - x + x evaluated left to right in fp32 (no contraction: these are
 // plain adds, and the library is built without fast-math).

@@ -30,7 +30,7 @@
 namespace {
 
 constexpr int CV_TW = 32;               // output pixel tile: TH (8 or 4) rows x 32 columns
-constexpr int CV_PXB = 48;             // LDS bytes per pixel and piece: 16 channels x bf16 + 16 B pad (conflict-free b128 reads)
+constexpr int CV_PXB = 48;             // LDS bytes per pixel and piece: 16 channels x 2 B + 16 B pad (conflict-free b128 reads)
 constexpr int CV_MAXSRC = 4, CV_MAXNT = 4;
 
 struct ConvSrcs {
@@ -40,39 +40,119 @@ struct ConvSrcs {
 };
 struct ConvDsts {          // one entry per N tile of 128 output channels
     void *p[CV_MAXNT];
+    const void *add[CV_MAXNT];   // per-element addend (a ConvGRU context tensor) or null; geometry of the destination
+    const void *aux0[CV_MAXNT];  // epilogue operands (hidden state / update gate), geometry of the destination
+    const void *aux1[CV_MAXNT];
     int stride[CV_MAXNT];  // channels of the destination tensor (pixel stride)
     int coff[CV_MAXNT];    // first channel of this tile inside it
     int nvalid[CV_MAXNT];  // output channels of this tile that exist (<= 128)
+    int epi[CV_MAXNT];     // STEREO_EPI_*
 };
 
-// Operand formulation by activation type.  float: three bf16 pieces per value, six piece products (fp32-faithful).  f16 (the
-// update block under the reference's mixed_precision flag, raft_stereo.py:176: fp16 autocast): the values ARE the operands of
-// v_mfma_f32_32x32x16_f16 -- one product, fp32 accumulation, fp16 output, what the library's fp16 convolution computes.
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-template <typename TIN>
-struct ConvOp;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+// Arithmetic forms (STEREO_CONV_* of include/stereo_hip.h).  A form says how an activation / weight value becomes NP matrix-core
+// operands ("pieces"), which piece products are executed (PA[q] x PB[q]) and into which of NACC fp32 accumulators (PC[q]).
+//   F32_F16X3 (default for fp32 activations): x = hi + 2^-11 lo', hi = fp16(x), lo' = fp16(2^11 (x - hi)) -- 22-23 significant
+//       bits; the products hi hi -> accumulator 0, hi lo' and lo' hi -> accumulator 1, result = acc0 + 2^-11 acc1 (the dropped
+//       lo lo term is <= 2^-22 of the product).  Every piece product is exact in fp32 (11 x 11 bits), so the error is that of
+//       the fp32 accumulation plus <= 2^-22 relative per operand: fp32-faithful for |x| < 65 504 (the fp16 range -- the range
+//       the reference's own mixed_precision flag assumes for this block; beyond it the result is inf / NaN, never silently
+//       wrong; below fp16's normal range, |x| < 2^-14, the error becomes absolute, <= 2^-36 per operand).  Three MFMAs per fp32
+//       product block instead of six.
+//   F32_BF16X6: x = hi + mid + lo exactly (three bf16 pieces, fp32's exponent range), the six leading piece products.
+//   F32_BF16X3 ("high"): two bf16 pieces, three products, ~2^-16 relative.   F16: fp16 activations, one product.
+template <int AR>
+struct ConvAr;
 template <>
-struct ConvOp<float> {
-    static constexpr int QCH = 4;   // channels per 16-B quad (pieces per value: the kernels' NP parameter, 3 or 2)
+struct ConvAr<STEREO_CONV_F32_BF16X6> {
+    typedef float tin;
     typedef bf16x8 frag;
     typedef __bf16 welem;
+    static constexpr int NP = 3, NPROD = 6, NACC = 1;
+    // smallest first: (a1 b1) (a0 b2) (a2 b0) (a0 b1) (a1 b0) (a0 b0)
+    static constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0}, PC[6] = {0, 0, 0, 0, 0, 0};
     static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 template <>
-struct ConvOp<f16> {
-    static constexpr int QCH = 8;   // (NP = 1)
+struct ConvAr<STEREO_CONV_F32_BF16X3> {
+    typedef float tin;
+    typedef bf16x8 frag;
+    typedef __bf16 welem;
+    static constexpr int NP = 2, NPROD = 3, NACC = 1;
+    static constexpr int PA[6] = {0, 1, 0, 0, 0, 0}, PB[6] = {1, 0, 0, 0, 0, 0}, PC[6] = {0, 0, 0, 0, 0, 0};
+    static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct ConvAr<STEREO_CONV_F16> {
+    typedef f16 tin;
     typedef f16x8 frag;
     typedef _Float16 welem;
+    static constexpr int NP = 1, NPROD = 1, NACC = 1;
+    static constexpr int PA[6] = {0, 0, 0, 0, 0, 0}, PB[6] = {0, 0, 0, 0, 0, 0}, PC[6] = {0, 0, 0, 0, 0, 0};
     static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
+template <>
+struct ConvAr<STEREO_CONV_F32_F16X3> {
+    typedef float tin;
+    typedef f16x8 frag;
+    typedef _Float16 welem;
+    static constexpr int NP = 2, NPROD = 3, NACC = 2;
+    // the two products of accumulator 1 are separated by the one of accumulator 0 (no back-to-back dependent MFMAs)
+    static constexpr int PA[6] = {0, 0, 1, 0, 0, 0}, PB[6] = {1, 0, 0, 0, 0, 0}, PC[6] = {1, 0, 1, 0, 0, 0};
+    static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+// compile-time loop: the body sees its index as a constant expression (a `#pragma unroll` loop this long is only partially
+// unrolled and then indexes the fragment buffers dynamically)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+constexpr float CV_LO_SCALE = 2048.0f, CV_LO_UNSCALE = 1.0f / 2048.0f;
+
+// x = hi + 2^-11 lo' (two fp16 pieces), two values at a time: v_cvt_pk_f16_f32, two widenings, v_pk_add_f32, v_pk_mul_f32,
+// v_cvt_pk_f16_f32
+__device__ __forceinline__ void split_pair_f16(f32x2 x, f16x2 *p)
+{
+    p[0] = __builtin_convertvector(x, f16x2);
+    const f32x2 r = (x - __builtin_convertvector(p[0], f32x2)) * CV_LO_SCALE;
+    p[1] = __builtin_convertvector(r, f16x2);
+}
+
+// eight fp32 values -> the form's NP operands
+template <int AR>
+__device__ __forceinline__ void conv_split_oct(const float *x, typename ConvAr<AR>::frag *p)
+{
+    if constexpr (AR == STEREO_CONV_F32_BF16X6 || AR == STEREO_CONV_F32_BF16X3) {
+        split_oct<ConvAr<AR>::NP>(x, p);
+    } else if constexpr (AR == STEREO_CONV_F16) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[0][j] = (_Float16)x[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f16x2 t[2];
+            split_pair_f16((f32x2){x[2 * j], x[2 * j + 1]}, t);
+            p[0][2 * j] = t[0][0], p[0][2 * j + 1] = t[0][1];
+            p[1][2 * j] = t[1][0], p[1][2 * j + 1] = t[1][1];
+        }
+    }
+}
 
 // weights [Cout][Cin][KS][KS] fp32 -> packed[(((chunk * TAPS + tap) * NB + nb) * NP + piece) * 64 + lane][8], where lane l of
 // n block nb holds output channel 32 nb + (l & 31), input channels 16 chunk + 8 (l >> 5) + 0..7 (the MFMA's B fragment);
-// float activations: NP = 3 bf16 pieces; f16 activations: the weight rounded to fp16 (what autocast hands the library)
-template <typename TIN, int NP>
-__global__ void conv_pack_kernel(const float *__restrict__ w, typename ConvOp<TIN>::welem *__restrict__ packed, int Cout, int Cin,
+// the pieces of the form (F16: the weight rounded to fp16, what autocast hands the library)
+template <int AR>
+__global__ void conv_pack_kernel(const float *__restrict__ w, typename ConvAr<AR>::welem *__restrict__ packed, int Cout, int Cin,
                                  int taps, int NB)
 {
+    typedef ConvAr<AR> Ar;
+    constexpr int NP = Ar::NP;
     const long long total = (long long)(Cin / 16) * taps * NB * 64;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -88,37 +168,43 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, typename ConvOp<TI
         x[j] = n < Cout ? w[((size_t)n * Cin + c) * taps + tap] : 0.0f;
     }
     const size_t base = ((((size_t)chunk * taps + tap) * NB + nb) * NP) * 64 + lane;
-    if constexpr (NP >= 2) {
-        bf16x8 pc[NP];
-        split_oct<NP>(x, pc);
+    typename Ar::frag pc[NP];
+    conv_split_oct<AR>(x, pc);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x8 *>(packed + (base + (size_t)p * 64) * 8) = pc[p];
-    } else {
-        f16x8 h;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) h[j] = (_Float16)x[j];
-        *reinterpret_cast<f16x8 *>(packed + base * 8) = h;
-    }
+    for (int p = 0; p < NP; ++p) *reinterpret_cast<typename Ar::frag *>(packed + (base + (size_t)p * 64) * 8) = pc[p];
 }
 
-template <int KS, int TH, typename TIN, int NP>
-__global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSrcs src,
-                                                                           const typename ConvOp<TIN>::welem *__restrict__ packed,
-                                                                           const float *__restrict__ bias, ConvDsts dst, int relu,
-                                                                           int H, int W, int tiles_x, int tiles_y, int NB, int Cout,
-                                                                           int ntn)
+template <int AR>
+constexpr int conv_min_wg_per_cu()
 {
-    typedef ConvOp<TIN> Op;
-    typedef typename Op::frag frag;
-    typedef typename Op::welem welem;
-    constexpr int QCH = Op::QCH, QPP = 16 / QCH, ES = (int)sizeof(TIN);
+    return AR == STEREO_CONV_F16 ? 2 : (AR == STEREO_CONV_F32_F16X3 ? 2 : 4);
+}
+
+template <int KS, int TH, int AR>
+__global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kernel(ConvSrcs src,
+                                                                                    const typename ConvAr<AR>::welem *__restrict__ packed,
+                                                                                    const float *__restrict__ bias, ConvDsts dst, int relu,
+                                                                                    int H, int W, int tiles_x, int tiles_y, int NB, int Cout,
+                                                                                    int ntn)
+{
+    typedef ConvAr<AR> Ar;
+    typedef typename Ar::tin TIN;
+    typedef typename Ar::frag frag;
+    typedef typename Ar::welem welem;
+    constexpr int NP = Ar::NP, NPROD = Ar::NPROD, NACC = Ar::NACC;
+    constexpr int ES = (int)sizeof(TIN), QCH = 16 / ES, QPP = 16 / QCH;   // channels per 16-B quad, quads per pixel and chunk
     constexpr int HALO = KS / 2, TAPS = KS * KS;
     constexpr int WN = TH == 8 ? 2 : 4;          // waves along the output channels (the other 4 / WN along the rows)
     constexpr int NBW = 4 / WN;                  // 32-channel N blocks per wave
     constexpr int HCOLS = CV_TW + 2 * HALO, HROWS = TH + 2 * HALO, NPX = HROWS * HCOLS;
     constexpr int PS = NPX * CV_PXB;             // piece stride (bytes)
     constexpr int NQ = NPX * QPP, NPASS = (NQ + 255) / 256;   // 16-B quads of the halo tile's chunk
-    __shared__ __attribute__((aligned(16))) char img[NP * PS];
+    // PIPE (the split-fp16 form: three MFMAs per fragment pair, two waves per SIMD -- too little of either to hide an LDS
+    // round trip behind): two chunk images in LDS, ONE barrier per chunk, A fragments fetched a block ahead and B fragments a
+    // tap ahead of the MFMAs that use them
+    constexpr bool PIPE = AR == STEREO_CONV_F32_F16X3;
+    constexpr int IMG = NP * PS;                 // one chunk image
+    __shared__ __attribute__((aligned(16))) char img[(PIPE ? 2 : 1) * IMG];
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l31 = lane & 31, half = lane >> 5;
@@ -157,19 +243,28 @@ __global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSr
         is_c += 16;
         if (is_c >= Cs) is_c = 0, ++is_s;
     };
-    auto commit = [&]() {
+    auto commit = [&](int buf) {
+        char *const im = img + buf * IMG;
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
             if (lw[i] >= 0) {
-                if constexpr (NP >= 2) {
+                if constexpr (AR == STEREO_CONV_F32_BF16X6 || AR == STEREO_CONV_F32_BF16X3) {
                     const f32x4 v = __builtin_bit_cast(f32x4, rk[i]);
                     bf16x2 a[NP], c[NP];
                     split_pair<NP>((f32x2){v[0], v[1]}, a);
                     split_pair<NP>((f32x2){v[2], v[3]}, c);
 #pragma unroll
-                    for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4 *>(img + p * PS + lw[i]) = cat2(a[p], c[p]);
+                    for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4 *>(im + p * PS + lw[i]) = cat2(a[p], c[p]);
+                } else if constexpr (AR == STEREO_CONV_F32_F16X3) {
+                    const f32x4 v = __builtin_bit_cast(f32x4, rk[i]);
+                    f16x2 a[2], c[2];
+                    split_pair_f16((f32x2){v[0], v[1]}, a);
+                    split_pair_f16((f32x2){v[2], v[3]}, c);
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        *reinterpret_cast<f16x4 *>(im + p * PS + lw[i]) = __builtin_shufflevector(a[p], c[p], 0, 1, 2, 3);
                 } else {
-                    *reinterpret_cast<u32x4_t *>(img + lw[i]) = rk[i];
+                    *reinterpret_cast<u32x4_t *>(im + lw[i]) = rk[i];
                 }
             }
         }
@@ -180,13 +275,15 @@ __global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSr
     for (int s = 0; s < CV_MAXSRC; ++s)
         if (s < src.n) nchunks += src.c[s] / 16;
 
-    f32x16 acc[4][NBW];
+    f32x16 acc[4][NBW][NACC];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.0f;
+            for (int a = 0; a < NACC; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mb][nb][a][r] = 0.0f;
 
     // M block mb = (row pair rp = mb >> 1, column half ch = mb & 1) is 2 rows x 16 columns of pixels: MFMA row i of the block is
     // pixel (4 wm + 2 rp + (i >> 4), 16 ch + (i & 15)) of the tile, so an image whose width is a multiple of 16 (240, 120 ...)
@@ -198,39 +295,46 @@ __global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSr
     const size_t kstep = (size_t)NB * NP * 64 * 8;   // elements per k-step (one tap of one chunk)
 
     // which of this wave's four M blocks lie inside the image (wave-uniform): all of them (the common case), the left column
-    // half only (last tile of a row whose width is 16 mod 32), or some other subset (bottom edge)
+    // half only (last tile of a row whose width is 16 mod 32), or some other subset (bottom edge).  The K loop -- and with it
+    // the barrier sequence -- is chosen for the WORKGROUP: the waves of an 8-row tile (wm = 0, 1) can see different subsets at
+    // the bottom edge, and then all of them take the generic loop with their own predicates.
     bool mbv[4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) mbv[mb] = y0 + 4 * wm + 2 * (mb >> 1) < H && x0 + 16 * (mb & 1) < W;
-    const int mode = (mbv[0] && mbv[1] && mbv[2] && mbv[3]) ? 0 : ((mbv[0] && mbv[2] && !mbv[1] && !mbv[3]) ? 1 : 2);
+    int mode = -1;
+#pragma unroll
+    for (int w = 0; w < 4 / WN; ++w) {
+        bool v[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) v[mb] = y0 + 4 * w + 2 * (mb >> 1) < H && x0 + 16 * (mb & 1) < W;
+        const int m = (v[0] && v[1] && v[2] && v[3]) ? 0 : ((v[0] && v[2] && !v[1] && !v[3]) ? 1 : 2);
+        mode = (w == 0 || m == mode) ? m : 2;
+    }
 
-    // one chunk's 9 taps; MODE selects the M blocks.  (Four waves per SIMD hide the dependent six-MFMA chain of a block; a
-    // variant that alternated two blocks' chains and fetched the B fragments a tap ahead needed 142 registers -- three waves per
-    // SIMD -- and measured 4 % slower.)
+    // one chunk's 9 taps; MODE selects the M blocks.
     auto load_b = [&](frag (&bf)[NBW][NP], const welem *wt) {
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
             for (int p = 0; p < NP; ++p) bf[nb][p] = *reinterpret_cast<const frag *>(wt + ((size_t)nb * NP + p) * 64 * 8);
     };
-    auto load_a = [&](frag (&af)[NP], int mb, int ky, int kx) {
+    auto load_a = [&](frag (&af)[NP], int buf, int mb, int ky, int kx) {
 #pragma unroll
         for (int p = 0; p < NP; ++p)
-            af[p] = *reinterpret_cast<const frag *>(abase + p * PS + ((2 * (mb >> 1) + ky) * HCOLS + 16 * (mb & 1) + kx) * CV_PXB);
+            af[p] = *reinterpret_cast<const frag *>(abase + buf * IMG + p * PS +
+                                                    ((2 * (mb >> 1) + ky) * HCOLS + 16 * (mb & 1) + kx) * CV_PXB);
     };
-    // piece products, smallest first: (a1 b1) (a0 b2) (a2 b0) (a0 b1) (a1 b0) (a0 b0)
-    // NP = 3: all six products above (fp32-faithful).  NP = 2 ("bf16x3": hi + mid pieces, the three leading products a0 b1, a1 b0,
-    // a0 b0 -- the last three entries): ~2^-16 relative error per product, half the matrix work.  NP = 1: a0 b0.
-    constexpr int NPROD = NP == 3 ? 6 : (NP == 2 ? 3 : 1);
-    constexpr int PA[6] = {NP == 3 ? 1 : 0, 0, NP == 3 ? 2 : 0, 0, NP >= 2 ? 1 : 0, 0};
-    constexpr int PB[6] = {NP == 3 ? 1 : 0, NP == 3 ? 2 : 0, 0, NP >= 2 ? 1 : 0, 0, 0};
+    auto products = [&](int m0, const frag (&a0)[NP], const frag (&bf)[NBW][NP]) {
+#pragma unroll
+        for (int q = 0; q < NPROD; ++q)
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+                acc[m0][nb][Ar::PC[q]] = Ar::mma(a0[Ar::PA[q]], bf[nb][Ar::PB[q]], acc[m0][nb][Ar::PC[q]]);
+    };
     auto single = [&](int m0, int ky, int kx, const frag (&bf)[NBW][NP]) {
         frag a0[NP];
-        load_a(a0, m0, ky, kx);
-#pragma unroll
-        for (int q = 6 - NPROD; q < 6; ++q)     // (one piece: the last entry, a0 b0)
-#pragma unroll
-            for (int nb = 0; nb < NBW; ++nb) acc[m0][nb] = Op::mma(a0[PA[q]], bf[nb][PB[q]], acc[m0][nb]);
+        load_a(a0, 0, m0, ky, kx);
+        products(m0, a0, bf);
     };
     auto chunk = [&](auto mode_tag, const welem *wk) {
         constexpr int MODE = decltype(mode_tag)::value;
@@ -263,40 +367,137 @@ __global__ __launch_bounds__(256, TH == 8 ? 2 : 4) void conv_split_kernel(ConvSr
     auto run = [&](auto mode_tag) {
         issue();
         for (int g = 0; g < nchunks; ++g) {
-            commit();
+            commit(0);
             __syncthreads();   // the chunk's pieces are visible
             if (g + 1 < nchunks) issue();
             chunk(mode_tag, wbase + (size_t)g * TAPS * kstep);
             __syncthreads();   // every wave is done with the chunk before the next commit overwrites it
         }
     };
-    if (mode == 0) run(std::integral_constant<int, 0>{});
-    else if (mode == 1) run(std::integral_constant<int, 1>{});
-    else run(std::integral_constant<int, 2>{});
+    // PIPE: chunk g is computed out of image g & 1 while chunk g + 1 is committed (half-way through, when its loads have long
+    // landed) into the other one and chunk g + 2's loads are issued: one barrier per chunk.  The (tap, block) steps of a chunk
+    // are one unrolled sequence: step s issues the A fragments of step s + 1 and, on the first block of a tap, the B fragments
+    // of the NEXT tap (of the next chunk after the last tap), then its own MFMAs.
+    auto run_pipe = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;   // 0: all four M blocks; 1: blocks 0 and 2
+        constexpr int NBLK = MODE == 0 ? 4 : 2, BSTEP = MODE == 0 ? 1 : 2, NSTEP = TAPS * NBLK;
+        frag bq[2][NBW][NP], aq[2][NP];
+        issue();
+        load_b(bq[0], wbase);
+        commit(0);
+        if (nchunks > 1) issue();
+        __syncthreads();
+        for (int g = 0; g < nchunks; ++g) {
+            const int cur = g & 1;
+            const welem *wk = wbase + (size_t)g * TAPS * kstep;
+            load_a(aq[0], cur, 0, 0, 0);
+            static_for<0, NSTEP>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                constexpr int tap = s / NBLK, mb = (s % NBLK) * BSTEP;
+                if constexpr (s % NBLK == 0) {
+                    if (tap + 1 < TAPS || g + 1 < nchunks) load_b(bq[(tap + 1) & 1], wk + (size_t)(tap + 1) * kstep);
+                }
+                if constexpr (s + 1 < NSTEP) {
+                    constexpr int ntap = (s + 1) / NBLK, nmb = ((s + 1) % NBLK) * BSTEP;
+                    load_a(aq[(s + 1) & 1], cur, nmb, ntap / KS, ntap % KS);
+                }
+                if constexpr (s == NSTEP / 2) {
+                    if (g + 1 < nchunks) {
+                        commit(cur ^ 1);
+                        if (g + 2 < nchunks) issue();
+                    }
+                }
+                // (pin the issue order: the machine scheduler otherwise sinks every load to just in front of its first use)
+                __builtin_amdgcn_sched_barrier(0);
+                products(mb, aq[s & 1], bq[tap & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if constexpr ((TAPS & 1) != 0) {   // the next chunk's first tap landed in bq[1]
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) bq[0][nb][p] = bq[1][nb][p];
+            }
+            __syncthreads();   // every wave is done with image `cur`; the commits into the other one are visible
+        }
+    };
+    if constexpr (PIPE) {
+        // (an edge tile with some other subset of blocks inside the image computes all four: pixels outside the image read as
+        // zeros and are never stored)
+        if (mode == 1) run_pipe(std::integral_constant<int, 1>{});
+        else run_pipe(std::integral_constant<int, 0>{});
+    } else {
+        if (mode == 0) run(std::integral_constant<int, 0>{});
+        else if (mode == 1) run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 2>{});
+    }
 
     // ---- epilogue: register r of lane (l31, half) holds MFMA row i = (r & 3) + 8 (r >> 2) + 4 half of its M block, i.e. pixel
-    // (row + (r >> 3), 16 ch + (r & 3) + 8 ((r >> 2) & 1) + 4 half), output channel 32 (NBW wn + nb) + l31: a 128-B row per store
-    TIN *ob = static_cast<TIN *>(dst.p[nt]);
+    // (row + (r >> 3), 16 ch + (r & 3) + 8 ((r >> 2) & 1) + 4 half), output channel 32 (NBW wn + nb) + l31: a 128-B row per
+    // access.  STEREO_EPI_*: bias (+ per-element addend), then ReLU / the ConvGRU gate math (update.py:28-32) in place of the
+    // separate pointwise launches: sigmoid -> z; sigmoid x h -> r h (convq's first source); tanh and the (1 - z) h + z q blend.
     const int ostride = dst.stride[nt], coff = dst.coff[nt], nvalid = dst.nvalid[nt];
+    const size_t obase = (size_t)b * H * W * ostride;      // this batch image inside the destination-shaped tensors
+    TIN *ob = static_cast<TIN *>(dst.p[nt]) + obase;
+    const TIN *addp = dst.add[nt] ? static_cast<const TIN *>(dst.add[nt]) + obase : nullptr;
+    const TIN *a0p = dst.aux0[nt] ? static_cast<const TIN *>(dst.aux0[nt]) + obase : nullptr;
+    const TIN *a1p = dst.aux1[nt] ? static_cast<const TIN *>(dst.aux1[nt]) + obase : nullptr;
+    auto epilogue = [&](auto epi_tag) {
+        constexpr int EPI = decltype(epi_tag)::value;
 #pragma unroll
-    for (int nb = 0; nb < NBW; ++nb) {
-        const int cl = 32 * (NBW * wn + nb) + l31;
-        const int cg = 128 * nt + cl;
-        const float bv = (bias != nullptr && cg < Cout) ? bias[cg] : 0.0f;
-        if (cl < nvalid) {
+        for (int nb = 0; nb < NBW; ++nb) {
+            const int cl = 32 * (NBW * wn + nb) + l31;
+            const int cg = 128 * nt + cl;
+            const float bv = (bias != nullptr && cg < Cout) ? bias[cg] : 0.0f;
+            if (cl < nvalid) {
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
+                for (int mb = 0; mb < 4; ++mb) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int y = y0 + 4 * wm + 2 * (mb >> 1) + (r >> 3);
-                    const int x = x0 + 16 * (mb & 1) + (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
-                    float v = acc[mb][nb][r] + bv;
-                    if (relu) v = fmaxf(v, 0.0f);
-                    if (y < H && x < W) ob[(((size_t)b * H + y) * W + x) * ostride + coff + cl] = (TIN)v;
+                    for (int rh = 0; rh < 16; rh += 8) {   // (one row of the block: 8 registers)
+                        // the operand rows of 8 outputs are requested together, then the math, then the stores
+                        int o[8];                          // element offsets inside this batch image (< 2^31: launcher)
+                        bool in[8];
+                        float ad[8], u0[8], u1[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int r = rh + j;
+                            const int y = y0 + 4 * wm + 2 * (mb >> 1) + (r >> 3);
+                            const int x = x0 + 16 * (mb & 1) + (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
+                            in[j] = y < H && x < W;
+                            o[j] = (y * W + x) * ostride + coff + cl;
+                            ad[j] = (in[j] && addp != nullptr) ? (float)addp[o[j]] : 0.0f;
+                            if constexpr (EPI >= STEREO_EPI_SIGMOID_MUL) u0[j] = in[j] ? (float)a0p[o[j]] : 0.0f;
+                            if constexpr (EPI >= STEREO_EPI_GRU_BLEND) u1[j] = in[j] ? (float)a1p[o[j]] : 0.0f;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int r = rh + j;
+                            float v = acc[mb][nb][0][r];
+                            if constexpr (NACC == 2) v = fmaf(acc[mb][nb][1][r], CV_LO_UNSCALE, v);
+                            v = (v + bv) + ad[j];
+                            if constexpr (EPI == STEREO_EPI_LINEAR) {
+                                if (relu) v = fmaxf(v, 0.0f);
+                            } else if constexpr (EPI == STEREO_EPI_SIGMOID) {
+                                v = gate_sigmoid(v);
+                            } else if constexpr (EPI == STEREO_EPI_SIGMOID_MUL) {
+                                v = gate_sigmoid(v) * u0[j];
+                            } else {
+                                const float q = EPI == STEREO_EPI_GRU_BLEND_SOFTSIGN ? gate_softsign(v) : gate_tanh(v);
+                                v = gate_blend(u1[j], u0[j], q);
+                            }
+                            if (in[j]) ob[o[j]] = (TIN)v;
+                        }
+                    }
                 }
             }
         }
-    }
+    };
+    const int epi = dst.epi[nt];
+    if (epi == STEREO_EPI_LINEAR) epilogue(std::integral_constant<int, STEREO_EPI_LINEAR>{});
+    else if (epi == STEREO_EPI_SIGMOID) epilogue(std::integral_constant<int, STEREO_EPI_SIGMOID>{});
+    else if (epi == STEREO_EPI_SIGMOID_MUL) epilogue(std::integral_constant<int, STEREO_EPI_SIGMOID_MUL>{});
+    else if (epi == STEREO_EPI_GRU_BLEND) epilogue(std::integral_constant<int, STEREO_EPI_GRU_BLEND>{});
+    else epilogue(std::integral_constant<int, STEREO_EPI_GRU_BLEND_SOFTSIGN>{});
 }
 
 // ---- 3x3 convolutions with a handful of output channels (flow_head.conv2: 256 -> 2, update.py:11-14): a 32-channel MFMA N
@@ -420,34 +621,36 @@ extern "C" int stereo_conv3x3_small_nhwc_f16(const void *x, const float *weight_
 
 namespace {
 
-template <typename TIN, int NP>
+template <int AR>
 long long packed_bytes(int Cout, int Cin, int ksize)
 {
     if (Cout < 1 || Cin < 16 || Cin % 16 != 0 || (ksize != 1 && ksize != 3)) return 0;
     const long long NB = 4LL * ((Cout + 127) / 128);
-    return (long long)(Cin / 16) * ksize * ksize * NB * NP * 64 * 8 * 2;
+    return (long long)(Cin / 16) * ksize * ksize * NB * ConvAr<AR>::NP * 64 * 8 * 2;
 }
 
-template <typename TIN, int NP>
+template <int AR>
 int pack_weights(const float *weight, void *packed, int Cout, int Cin, int ksize, void *stream)
 {
-    if (packed_bytes<TIN, NP>(Cout, Cin, ksize) == 0) return STEREO_ERR_BAD_SHAPE;
+    if (packed_bytes<AR>(Cout, Cin, ksize) == 0) return STEREO_ERR_BAD_SHAPE;
     STEREO_REQUIRE_PTR(weight);
     STEREO_REQUIRE_PTR(packed);
     if (!aligned16(packed)) return STEREO_ERR_UNSUPPORTED;
     const int NB = 4 * ((Cout + 127) / 128), taps = ksize * ksize;
     const long long total = (long long)(Cin / 16) * taps * NB * 64;
-    hipLaunchKernelGGL((conv_pack_kernel<TIN, NP>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), weight,
-                       static_cast<typename ConvOp<TIN>::welem *>(packed), Cout, Cin, taps, NB);
+    hipLaunchKernelGGL((conv_pack_kernel<AR>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), weight,
+                       static_cast<typename ConvAr<AR>::welem *>(packed), Cout, Cin, taps, NB);
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }
 
-template <typename TIN, int NP>
+template <int AR>
 int conv_nhwc(const void *const *srcs, const int *src_channels, int nsrc, const void *packed, const float *bias,
-              void *const *outs, const int *out_channels, const int *out_strides, int nout, int ksize, int relu, int B, int H,
+              void *const *outs, const int *out_channels, const int *out_strides, int nout, const int *epilogue,
+              const void *const *addend, const void *const *aux0, const void *const *aux1, int ksize, int relu, int B, int H,
               int W, void *stream)
 {
+    typedef typename ConvAr<AR>::tin TIN;
     if (nsrc < 1 || nsrc > CV_MAXSRC || nout < 1 || nout > CV_MAXNT || (ksize != 1 && ksize != 3) || B < 0 || H < 0 || W < 0)
         return STEREO_ERR_BAD_SHAPE;
     if (srcs == nullptr || src_channels == nullptr || outs == nullptr || out_channels == nullptr) return STEREO_ERR_NULL_POINTER;
@@ -471,12 +674,23 @@ int conv_nhwc(const void *const *srcs, const int *src_channels, int nsrc, const 
         const int c = out_channels[i];
         const int cs = out_strides ? out_strides[i] : c;   // channels of the destination tensor (>= c: the rest is the caller's)
         if (c < 1 || cs < c || (i + 1 < nout && c % 128 != 0)) return STEREO_ERR_UNSUPPORTED;
+        if ((long long)H * W * cs >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;     // 32-bit element offsets in the epilogue
+        const int epi = epilogue ? epilogue[i] : STEREO_EPI_LINEAR;
+        if (epi < STEREO_EPI_LINEAR || epi > STEREO_EPI_GRU_BLEND_SOFTSIGN) return STEREO_ERR_BAD_SHAPE;
+        if (epi != STEREO_EPI_LINEAR && relu) return STEREO_ERR_BAD_SHAPE;
+        const void *ad = addend ? addend[i] : nullptr, *x0 = aux0 ? aux0[i] : nullptr, *x1 = aux1 ? aux1[i] : nullptr;
+        if (epi >= STEREO_EPI_SIGMOID_MUL && x0 == nullptr) return STEREO_ERR_NULL_POINTER;
+        if (epi >= STEREO_EPI_GRU_BLEND && x1 == nullptr) return STEREO_ERR_NULL_POINTER;
         for (int o = 0; o < c; o += 128) {
             if (ntn >= CV_MAXNT) return STEREO_ERR_UNSUPPORTED;
             d.p[ntn] = outs[i];
+            d.add[ntn] = ad;
+            d.aux0[ntn] = x0;
+            d.aux1[ntn] = x1;
             d.stride[ntn] = cs;
             d.coff[ntn] = o;
             d.nvalid[ntn] = c - o < 128 ? c - o : 128;
+            d.epi[ntn] = epi;
             ++ntn;
         }
         Cout += c;
@@ -492,9 +706,9 @@ int conv_nhwc(const void *const *srcs, const int *src_channels, int nsrc, const 
     const long long nt = (long long)tiles_x * tiles_y * B;
     if (nt * ntn >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
     dim3 grid((unsigned)(nt * ntn));
-    typedef typename ConvOp<TIN>::welem welem;
+    typedef typename ConvAr<AR>::welem welem;
 #define CONV_LAUNCH(KSV)                                                                                                        \
-    hipLaunchKernelGGL((conv_split_kernel<KSV, th, TIN, NP>), grid, dim3(256), 0, as_stream(stream), s, static_cast<const welem *>(packed), \
+    hipLaunchKernelGGL((conv_split_kernel<KSV, th, AR>), grid, dim3(256), 0, as_stream(stream), s, static_cast<const welem *>(packed), \
                        bias, d, relu, H, W, tiles_x, tiles_y, NB, Cout, ntn)
     if (ksize == 3) CONV_LAUNCH(3);
     else CONV_LAUNCH(1);
@@ -505,38 +719,77 @@ int conv_nhwc(const void *const *srcs, const int *src_channels, int nsrc, const 
 
 }  // namespace
 
-extern "C" long long stereo_conv_packed_bytes(int Cout, int Cin, int ksize) { return packed_bytes<float, 3>(Cout, Cin, ksize); }
-extern "C" long long stereo_conv_packed_bytes_bf16x3(int Cout, int Cin, int ksize) { return packed_bytes<float, 2>(Cout, Cin, ksize); }
-extern "C" long long stereo_conv_packed_bytes_f16(int Cout, int Cin, int ksize) { return packed_bytes<f16, 1>(Cout, Cin, ksize); }
+#define CONV_FORMS(CALL)                                       \
+    switch (arith) {                                           \
+    case STEREO_CONV_F32_BF16X6: return CALL(STEREO_CONV_F32_BF16X6); \
+    case STEREO_CONV_F32_BF16X3: return CALL(STEREO_CONV_F32_BF16X3); \
+    case STEREO_CONV_F16: return CALL(STEREO_CONV_F16);       \
+    case STEREO_CONV_F32_F16X3: return CALL(STEREO_CONV_F32_F16X3); \
+    default: break;                                            \
+    }
+
+extern "C" long long stereo_conv_packed_bytes_ex(int arith, int Cout, int Cin, int ksize)
+{
+#define CALL(A) packed_bytes<A>(Cout, Cin, ksize)
+    CONV_FORMS(CALL)
+#undef CALL
+    return 0;
+}
+extern "C" int stereo_conv_pack_weights_ex(int arith, const float *weight, void *packed, int Cout, int Cin, int ksize, void *stream)
+{
+#define CALL(A) pack_weights<A>(weight, packed, Cout, Cin, ksize, stream)
+    CONV_FORMS(CALL)
+#undef CALL
+    return STEREO_ERR_BAD_SHAPE;
+}
+extern "C" int stereo_conv_nhwc_ex(int arith, const void *const *srcs, const int *src_channels, int nsrc, const void *packed,
+                                   const float *bias, void *const *outs, const int *out_channels, const int *out_strides, int nout,
+                                   const int *epilogue, const void *const *addend, const void *const *aux0, const void *const *aux1,
+                                   int ksize, int relu, int B, int H, int W, void *stream)
+{
+#define CALL(A) \
+    conv_nhwc<A>(srcs, src_channels, nsrc, packed, bias, outs, out_channels, out_strides, nout, epilogue, addend, aux0, aux1, ksize, relu, B, H, W, stream)
+    CONV_FORMS(CALL)
+#undef CALL
+    return STEREO_ERR_BAD_SHAPE;
+}
+
+// the round-2 entry points: fixed arithmetic form, linear epilogue
+extern "C" long long stereo_conv_packed_bytes(int Cout, int Cin, int ksize) { return packed_bytes<STEREO_CONV_F32_BF16X6>(Cout, Cin, ksize); }
+extern "C" long long stereo_conv_packed_bytes_bf16x3(int Cout, int Cin, int ksize) { return packed_bytes<STEREO_CONV_F32_BF16X3>(Cout, Cin, ksize); }
+extern "C" long long stereo_conv_packed_bytes_f16(int Cout, int Cin, int ksize) { return packed_bytes<STEREO_CONV_F16>(Cout, Cin, ksize); }
 extern "C" int stereo_conv_pack_weights(const float *weight, void *packed, int Cout, int Cin, int ksize, void *stream)
 {
-    return pack_weights<float, 3>(weight, packed, Cout, Cin, ksize, stream);
+    return pack_weights<STEREO_CONV_F32_BF16X6>(weight, packed, Cout, Cin, ksize, stream);
 }
 extern "C" int stereo_conv_pack_weights_bf16x3(const float *weight, void *packed, int Cout, int Cin, int ksize, void *stream)
 {
-    return pack_weights<float, 2>(weight, packed, Cout, Cin, ksize, stream);
+    return pack_weights<STEREO_CONV_F32_BF16X3>(weight, packed, Cout, Cin, ksize, stream);
 }
 extern "C" int stereo_conv_pack_weights_f16(const float *weight, void *packed, int Cout, int Cin, int ksize, void *stream)
 {
-    return pack_weights<f16, 1>(weight, packed, Cout, Cin, ksize, stream);
+    return pack_weights<STEREO_CONV_F16>(weight, packed, Cout, Cin, ksize, stream);
 }
 extern "C" int stereo_conv_nhwc_f32(const float *const *srcs, const int *src_channels, int nsrc, const void *packed,
                                     const float *bias, float *const *outs, const int *out_channels, const int *out_strides,
                                     int nout, int ksize, int relu, int B, int H, int W, void *stream)
 {
-    return conv_nhwc<float, 3>(reinterpret_cast<const void *const *>(srcs), src_channels, nsrc, packed, bias,
-                               reinterpret_cast<void *const *>(outs), out_channels, out_strides, nout, ksize, relu, B, H, W, stream);
+    return conv_nhwc<STEREO_CONV_F32_BF16X6>(reinterpret_cast<const void *const *>(srcs), src_channels, nsrc, packed, bias,
+                                             reinterpret_cast<void *const *>(outs), out_channels, out_strides, nout, nullptr, nullptr,
+                                             nullptr, nullptr, ksize, relu, B, H, W, stream);
 }
 extern "C" int stereo_conv_nhwc_f32_bf16x3(const float *const *srcs, const int *src_channels, int nsrc, const void *packed,
                                            const float *bias, float *const *outs, const int *out_channels, const int *out_strides,
                                            int nout, int ksize, int relu, int B, int H, int W, void *stream)
 {
-    return conv_nhwc<float, 2>(reinterpret_cast<const void *const *>(srcs), src_channels, nsrc, packed, bias,
-                               reinterpret_cast<void *const *>(outs), out_channels, out_strides, nout, ksize, relu, B, H, W, stream);
+    return conv_nhwc<STEREO_CONV_F32_BF16X3>(reinterpret_cast<const void *const *>(srcs), src_channels, nsrc, packed, bias,
+                                             reinterpret_cast<void *const *>(outs), out_channels, out_strides, nout, nullptr, nullptr,
+                                             nullptr, nullptr, ksize, relu, B, H, W, stream);
 }
 extern "C" int stereo_conv_nhwc_f16(const void *const *srcs, const int *src_channels, int nsrc, const void *packed,
                                     const float *bias, void *const *outs, const int *out_channels, const int *out_strides,
                                     int nout, int ksize, int relu, int B, int H, int W, void *stream)
 {
-    return conv_nhwc<f16, 1>(srcs, src_channels, nsrc, packed, bias, outs, out_channels, out_strides, nout, ksize, relu, B, H, W, stream);
+    return conv_nhwc<STEREO_CONV_F16>(srcs, src_channels, nsrc, packed, bias, outs, out_channels, out_strides, nout, nullptr, nullptr,
+                                      nullptr, nullptr, ksize, relu, B, H, W, stream);
 }

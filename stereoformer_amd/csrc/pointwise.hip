@@ -5,7 +5,7 @@
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return gate_sigmoid(x); }
 
 template <int V>
 __global__ __launch_bounds__(256) void gru_reset_kernel(const float *__restrict__ h, const float *__restrict__ rc,
@@ -45,15 +45,15 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict_
             for (int i = 0; i < 4; ++i) {
                 const float z = sigmoidf_(zv[i] + bz[i]);
                 const float qx = qv[i] + bq[i];
-                const float q = SOFTSIGN ? qx / (1.0f + fabsf(qx)) : tanhf(qx);
-                o[i] = (1.0f - z) * hv[i] + z * q;
+                const float q = SOFTSIGN ? gate_softsign(qx) : gate_tanh(qx);
+                o[i] = gate_blend(z, hv[i], q);
             }
             st4(out + t * 4, o);
         } else {
             const float z = sigmoidf_(zc[t] + (cz ? cz[t] : 0.0f));
             const float qx = qc[t] + (cq ? cq[t] : 0.0f);
-            const float q = SOFTSIGN ? qx / (1.0f + fabsf(qx)) : tanhf(qx);
-            out[t] = (1.0f - z) * h[t] + z * q;
+            const float q = SOFTSIGN ? gate_softsign(qx) : gate_tanh(qx);
+            out[t] = gate_blend(z, h[t], q);
         }
     }
 }
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256) void gru_blend_f16_kernel(const _Float16 *__re
 {
     auto one = [](float hv, float zv, float qv) {
         const float z = sigmoidf_(zv);
-        const float q = SOFTSIGN ? qv / (1.0f + fabsf(qv)) : tanhf(qv);
-        return (1.0f - z) * hv + z * q;
+        const float q = SOFTSIGN ? gate_softsign(qv) : gate_tanh(qv);
+        return gate_blend(z, hv, q);
     };
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nvec;
          t += (long long)gridDim.x * blockDim.x) {

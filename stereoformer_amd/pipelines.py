@@ -31,6 +31,10 @@ class _GraphCache:
     def __init__(self):
         self._entries = {}
 
+    def clear(self):
+        """Forget every captured graph (their launches read packed weight copies that have been rebuilt)."""
+        self._entries.clear()
+
     def run(self, key, fn, tensors):
         ent = self._entries.get(key)
         if ent is None:
@@ -55,22 +59,24 @@ class _GraphCache:
 
 class RAFTStereoLoop(nn.Module):
     def __init__(self, hidden_dims=(128, 128, 128), downsample=2, corr_levels=4, corr_radius=4, n_gru_layers=3,
-                 mixed_precision=False, channels_last=False, conv_precision="highest"):
-        """``channels_last``: keep the update block's weights and activations in NHWC (MIOpen's convolutions are
-        17 % (fp32) to 2x (fp16) faster there and need no layout transposes); the pointwise HIP kernels take either
-        dense layout, lookups / upsampling convert their small inputs.  Same arithmetic, off by default.
+                 mixed_precision=False, channels_last=None, conv_precision="highest"):
+        """``channels_last``: keep the update block's weights and activations in NHWC, where the block's convolutions run on the
+        library's own kernels (``conv_split``: gate math in the epilogues, no concatenations) for inference.  ``None`` (default):
+        NHWC whenever the forward runs without gradients -- the drop-in inference path IS the HIP path --, the reference's
+        NCHW + library convolutions under autograd; ``True`` / ``False`` force one layout for both.
         ``mixed_precision``: the reference's flag of the same name (``raft_stereo.py:176``): the update block's
         convolutions run under fp16 ``autocast``; correlation, lookup, gate math, coordinates and the convex
         upsampling stay fp32.  Off by default -- fp32 is the parity configuration.
-        ``conv_precision`` (inference with ``channels_last``, where the block's convolutions run on ``conv_split``): ``"highest"``
-        = fp32-faithful split-bf16 arithmetic (default, parity); ``"high"`` = two bf16 pieces / three products per fp32 product
-        (like ``torch.set_float32_matmul_precision('high')``): ~2^-16 relative error per product at half the matrix work."""
+        ``conv_precision`` (inference in NHWC): ``"highest"`` = fp32-faithful split-fp16 arithmetic (default, parity;
+        ``conv_split``'s docstring), ``"bf16x6"`` = the split-bf16 form with fp32's whole exponent range (twice the matrix work),
+        ``"high"`` = two bf16 pieces / three products per fp32 product (like ``torch.set_float32_matmul_precision('high')``):
+        ~2^-16 relative error per product."""
         super().__init__()
-        if conv_precision not in ("highest", "high"):
-            raise ValueError("RAFTStereoLoop: conv_precision is 'highest' (fp32-faithful, the parity configuration) or 'high'")
+        if conv_precision not in ("highest", "f16x3", "bf16x6", "high", "bf16x3"):
+            raise ValueError("RAFTStereoLoop: conv_precision is 'highest' (fp32-faithful, the parity configuration), 'bf16x6' or 'high'")
         self.conv_precision = conv_precision
         self.mixed_precision = bool(mixed_precision)
-        self.channels_last = bool(channels_last)
+        self.channels_last = None if channels_last is None else bool(channels_last)
         self.hidden_dims = list(hidden_dims)
         self.downsample = downsample
         self.corr_levels = corr_levels
@@ -118,12 +124,20 @@ class RAFTStereoLoop(nn.Module):
             return list(out)
 
         key = (tuple(tuple(t.shape) for t in flat), iters, bool(test_mode), flat[0].device.index, self.mixed_precision,
-               self.channels_last, self.conv_precision)
+               self._nhwc(), self.conv_precision)
+        from . import conv_split
+        if conv_split.refresh(self.update_block):
+            self._graphs.clear()
         out = self._graphs.run(key, fn, flat)
         return tuple(out) if test_mode else out
 
+    def _nhwc(self):
+        return (not torch.is_grad_enabled()) if self.channels_last is None else self.channels_last
+
     def _forward_eager(self, fmap1, fmap2, net_list, inp_list, iters, flow_init, test_mode):
         from . import conv_split
+        if not torch.cuda.is_current_stream_capturing() and conv_split.refresh(self.update_block):
+            self._graphs.clear()     # weights changed under a packed copy: captured launches point at the old one
         prev = conv_split.set_precision(self.conv_precision)
         try:
             return self._forward_eager_impl(fmap1, fmap2, net_list, inp_list, iters, flow_init, test_mode)
@@ -144,11 +158,13 @@ class RAFTStereoLoop(nn.Module):
         net_list = [n.contiguous() for n in net_list]   # a private list: the update block writes into it
         if self.mixed_precision and not torch.is_grad_enabled():
             inp_list = [[t.half() for t in lvl] for lvl in inp_list]   # context biases: cast once, not per iteration
-        if self.channels_last:
+        if self._nhwc():
             cl = torch.channels_last
             self.update_block.to(memory_format=cl)   # no-op once converted
             net_list = [n.contiguous(memory_format=cl) for n in net_list]
             inp_list = [[t.contiguous(memory_format=cl) for t in lvl] for lvl in inp_list]
+        elif self.channels_last is None:
+            self.update_block.to(memory_format=torch.contiguous_format)   # back from an earlier inference call (no-op otherwise)
         preds = []
         up_mask = None
         for itr in range(iters):
@@ -167,16 +183,20 @@ class RAFTStereoLoop(nn.Module):
         return preds
 
 class LowCNNGRULoop(nn.Module):
-    def __init__(self, input_channels=24, hidden_dim=32, sample_points=20, channels_last=False):
-        """``channels_last``: keep the updater's weights and activations in NHWC; for inference its 3x3 convolutions (GRU gates,
-        offset head, mask head) then run on the library's own convolution kernels (``conv_split``), the two encoder convolutions
-        (24 and 3 input channels) and the 1x1 mask projection stay with MIOpen.  Same arithmetic to fp32 rounding; off by
-        default."""
+    def __init__(self, input_channels=24, hidden_dim=32, sample_points=20, channels_last=None):
+        """``channels_last``: keep the updater's weights and activations in NHWC; for inference its 3x3 convolutions (GRU gates
+        with the gate math in their epilogues, offset head, mask head) then run on the library's own convolution kernels
+        (``conv_split``), the two encoder convolutions (24 and 3 input channels) and the 1x1 mask projection stay with MIOpen.
+        Same arithmetic to fp32 rounding.  ``None`` (default): NHWC whenever the forward runs without gradients, NCHW + library
+        convolutions under autograd."""
         super().__init__()
         self.update = DisparityUpdateDLCWithMask(input_channels=input_channels, hidden_dim=hidden_dim,
                                                  sample_points=sample_points)
-        self.channels_last = bool(channels_last)
+        self.channels_last = None if channels_last is None else bool(channels_last)
         self._graphs = _GraphCache()
+
+    def _nhwc(self):
+        return (not torch.is_grad_enabled()) if self.channels_last is None else self.channels_last
 
     def forward(self, cost_volume, disp, left_image, right_image, iters=12, use_graph=False, graph_all_iterates=False):
         """cost_volume [B,D,h,w] (1/8 scale), disp [B,1,h,w] -> list of full-resolution disparities
@@ -185,9 +205,14 @@ class LowCNNGRULoop(nn.Module):
         graph replay is inference-only."""
         B, D, h, w = cost_volume.shape
         hidden = torch.zeros(B, 2 * self.update.hidden_dim, h, w, device=cost_volume.device)
-        if self.channels_last:
+        from . import conv_split
+        if not torch.cuda.is_current_stream_capturing() and conv_split.refresh(self.update):
+            self._graphs.clear()
+        if self._nhwc():
             self.update.to(memory_format=torch.channels_last)   # no-op once converted
             hidden = hidden.contiguous(memory_format=torch.channels_last)
+        elif self.channels_last is None:
+            self.update.to(memory_format=torch.contiguous_format)         # back from an earlier inference call
         if use_graph:
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
                 raise RuntimeError("LowCNNGRULoop: use_graph=True is an inference path; call it under torch.no_grad()")
@@ -203,7 +228,7 @@ class LowCNNGRULoop(nn.Module):
                 return outs
 
             key = (tuple(cost_volume.shape), tuple(left_image.shape), iters, cost_volume.device.index,
-                   bool(graph_all_iterates), self.channels_last)
+                   bool(graph_all_iterates), self._nhwc())
             return self._graphs.run(key, fn, [cost_volume, disp, left_image, right_image])
         outs = []
         for _ in range(iters):

@@ -173,14 +173,15 @@ class ConvGRU(nn.Module):
             srcs = [input, prev_h]                                    # the reference's cat order (:40)
             if (prev_h.is_contiguous(memory_format=torch.channels_last) and C.supported(srcs, [self.conv_z])
                     and C.supported(srcs, [self.conv_b]) and C.supported([prev_h, input], [self.conv_g])):
-                # inference in torch.channels_last: the three gate convolutions on conv_split (no concatenation is materialised)
+                # inference in torch.channels_last: the three gate convolutions on conv_split (no concatenation is
+                # materialised) with the gate math in their epilogues (:41-48): two launches per GRU step
                 if C.supported(srcs, [self.conv_z, self.conv_b]):
-                    zc, bc = C.conv_nhwc(srcs, [self.conv_z, self.conv_b])
+                    z, s = C.conv_nhwc(srcs, [self.conv_z, self.conv_b], epilogue=[("sigmoid", None), ("sigmoid_mul", None, prev_h)])
                 else:
-                    (zc,), (bc,) = C.conv_nhwc(srcs, [self.conv_z]), C.conv_nhwc(srcs, [self.conv_b])
-                s = gru_reset(prev_h, bc)
-                (gc,) = C.conv_nhwc([s, input], [self.conv_g])
-                return gru_blend(prev_h, zc, gc, softsign=self.softsign)
+                    (z,) = C.conv_nhwc(srcs, [self.conv_z], epilogue=[("sigmoid", None)])
+                    (s,) = C.conv_nhwc(srcs, [self.conv_b], epilogue=[("sigmoid_mul", None, prev_h)])
+                blend = "gru_blend_softsign" if self.softsign else "gru_blend"
+                return C.conv_nhwc([s, input], [self.conv_g], epilogue=[(blend, None, prev_h, z)])[0]
         x1 = torch.cat((input, prev_h), 1)
         zc = self.conv_z(x1)
         bc = self.conv_b(x1)

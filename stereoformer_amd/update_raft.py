@@ -88,16 +88,16 @@ def _side_stream(device):
 
 
 def _gru_step_split(h, xs, conv_z, conv_r, conv_q, cz, cr, cq):
-    """The ConvGRU update with its convolutions on ``conv_split`` (inference, channels-last fp32): ``convz`` and ``convr`` are
-    ONE launch over the sources ``[h | x...]`` (no concatenation is materialised), ``convq`` a second one over
-    ``[r * h | x...]``; same gate kernels as ``_gru_step``."""
+    """The ConvGRU update as TWO launches of ``conv_split`` (inference, channels-last): ``convz | convr`` over the sources
+    ``[h | x...]`` (no concatenation is materialised) with the gate math in the epilogue -- ``z = sigmoid(. + cz)`` and
+    ``r h = sigmoid(. + cr) * h`` leave the kernel, the pre-activations never exist in memory --, then ``convq`` over
+    ``[r h | x...]`` whose epilogue is ``tanh(. + cq)`` and the ``(1 - z) h + z q`` blend (update.py:28-32)."""
     if conv_split.supported([h, *xs], [conv_z, conv_r]):
-        z_pre, r_pre = conv_split.conv_nhwc([h, *xs], [conv_z, conv_r])
+        z, gated = conv_split.conv_nhwc([h, *xs], [conv_z, conv_r], epilogue=[("sigmoid", cz), ("sigmoid_mul", cr, h)])
     else:   # hidden sizes that do not fill whole 128-channel output tiles: one launch per gate
-        (z_pre,), (r_pre,) = conv_split.conv_nhwc([h, *xs], [conv_z]), conv_split.conv_nhwc([h, *xs], [conv_r])
-    gated = gru_reset(h, r_pre, cr)
-    (q_pre,) = conv_split.conv_nhwc([gated, *xs], [conv_q])
-    return gru_blend(h, z_pre, q_pre, cz, cq)
+        (z,) = conv_split.conv_nhwc([h, *xs], [conv_z], epilogue=[("sigmoid", cz)])
+        (gated,) = conv_split.conv_nhwc([h, *xs], [conv_r], epilogue=[("sigmoid_mul", cr, h)])
+    return conv_split.conv_nhwc([gated, *xs], [conv_q], epilogue=[("gru_blend", cq, h, z)])[0]
 
 
 class ConvGRU(nn.Module):
@@ -220,7 +220,11 @@ class BasicMultiUpdateBlock_LZH(nn.Module):
             extra = (self._like(interp(_f32(net[1]), net[0]), net[0]),) if self.n_gru_layers > 1 else ()
             if side is not None:
                 cur.wait_stream(side)
-                motion.record_stream(cur)     # allocated on the side stream, consumed (and freed) on this one
+                if not torch.cuda.is_current_stream_capturing():
+                    # allocated on the side stream, consumed (and freed) on this one.  (Inside a capture the fork / join above
+                    # already orders the block's reuse on the side stream after its last consumer, and record_stream would
+                    # defer every iteration's free to the end of the capture: one motion buffer per iteration in the pool.)
+                    motion.record_stream(cur)
             else:
                 motion = self.encoder(self._like(flow, net[0]), self._like(corr, net[0]))
             net[0] = self.gru08(net[0], *inp[0], motion, *extra)

@@ -1,4 +1,4 @@
-"""GPU parity of the update block's convolutions on the split-bf16 matrix-core kernel (csrc/conv_split.hip) against the fp64
+"""GPU parity of the update block's convolutions on the split-operand matrix-core kernel (csrc/conv_split.hip) against the fp64
 CPU convolution of the same operands (the oracle for a library op is the framework's own CPU kernel in double precision) and
 against MIOpen's fp32 result on the device."""
 import numpy as np
@@ -42,7 +42,8 @@ def _ref64(srcs, convs, relu):
     (1, 6, 70, (32, 16, 16, 64), (24,), 1, False, True),              # 1x1
     (1, 34, 60, (128, 128), (128,), 3, False, True),
 ])
-def test_conv_nhwc_matches_fp64_and_miopen(S, case):
+@pytest.mark.parametrize("precision", ["highest", "bf16x6"])
+def test_conv_nhwc_matches_fp64_and_miopen(S, case, precision):
     from stereoformer_amd import conv_split as C
     B, H, W, cs, co, k, relu, bias = case
     torch.manual_seed(81)
@@ -51,7 +52,7 @@ def test_conv_nhwc_matches_fp64_and_miopen(S, case):
     assert not C.supported(srcs, convs)          # grad mode with trainable weights: the library path
     with torch.no_grad():
         assert C.supported(srcs, convs)
-        outs = C.conv_nhwc(srcs, convs, relu=relu)
+        outs = C.conv_nhwc(srcs, convs, relu=relu, precision=precision)
         lib = [m(torch.cat(srcs, 1)) for m in convs]
     ref = _ref64(srcs, convs, relu)
     for o, r, l, m in zip(outs, ref, lib, convs):
@@ -59,8 +60,8 @@ def test_conv_nhwc_matches_fp64_and_miopen(S, case):
         scale = float(r.abs().max())
         err = float((o.double().cpu() - r).abs().max())
         err_lib = float(((F.relu(l) if relu else l).double().cpu() - r).abs().max())
-        # fp32-faithful: within a few ulps of the fp64 result at the output's scale (six fp32 accumulations per 16 input
-        # channels instead of the f32 instruction's eight: the same order of rounding error as the library's own result)
+        # fp32-faithful: within a few ulps of the fp64 result at the output's scale (split-fp16: two fp32 accumulators, three
+        # accumulations per 16 input channels; split-bf16: six into one -- the same order of rounding error as the library's)
         assert err <= 4e-6 * scale + 1e-6, (err, scale)
         assert err <= 10 * err_lib + 1e-6, (err, err_lib)
 
@@ -208,6 +209,162 @@ def test_conv_nhwc_high_precision_option(S):
         assert e_hi <= 4e-6 * scale + 1e-6
         assert e_hi < e_lo <= 2e-4 * scale           # coarser than the default, ~30x finer than TF32 would be
         assert torch.equal(a, c)
+
+
+def _gru_ref64(h, xs, cz, cr, cq, convz, convr, convq, softsign=False):
+    """update.py:28-32 in fp64 on the CPU."""
+    d = lambda t: t.double().cpu()
+    conv = lambda m, x: F.conv2d(x, d(m.weight.detach()), d(m.bias.detach()), padding=m.padding)
+    hx = torch.cat([d(h), *[d(x) for x in xs]], 1)
+    z = torch.sigmoid(conv(convz, hx) + (0 if cz is None else d(cz)))
+    r = torch.sigmoid(conv(convr, hx) + (0 if cr is None else d(cr)))
+    t = conv(convq, torch.cat([r * d(h), *[d(x) for x in xs]], 1)) + (0 if cq is None else d(cq))
+    q = t / (1 + t.abs()) if softsign else torch.tanh(t)
+    return z, r * d(h), (1 - z) * d(h) + z * q
+
+
+@pytest.mark.parametrize("case", [(2, 13, 40, 128, (128, 128), True, False), (1, 9, 33, 128, (128,), True, False),
+                                  (1, 7, 20, 64, (32,), False, True), (2, 6, 18, 64, (32,), False, False)])
+@pytest.mark.parametrize("precision", ["highest", "bf16x6"])
+def test_conv_nhwc_gru_epilogues(S, case, precision):
+    """The ConvGRU as two launches with the gate math in the epilogues (sigmoid -> z, sigmoid x h -> r h, tanh / softsign + blend)
+    against the fp64 statement of update.py:28-32, and bit-for-bit against the unfused form (linear epilogue + the pointwise
+    gate kernels): both evaluate the same device functions on the same accumulator values."""
+    from stereoformer_amd import conv_split as C
+    from stereoformer_amd.update_dlc import gru_blend, gru_reset
+    B, H, W, hd, xcs, ctx, softsign = case
+    torch.manual_seed(91)
+    h = _cl(torch.tanh(torch.randn(B, hd, H, W, device="cuda")))
+    xs = [_cl(torch.randn(B, c, H, W, device="cuda")) for c in xcs]
+    cz, cr, cq = [(_cl(torch.randn(B, hd, H, W, device="cuda")) if ctx else None) for _ in range(3)]
+    cin = hd + sum(xcs)
+    convz, convr, convq = [nn.Conv2d(cin, hd, 3, padding=1).cuda() for _ in range(3)]
+    blend = "gru_blend_softsign" if softsign else "gru_blend"
+    with torch.no_grad():
+        if C.supported([h, *xs], [convz, convr]):
+            z, gated = C.conv_nhwc([h, *xs], [convz, convr], epilogue=[("sigmoid", cz), ("sigmoid_mul", cr, h)], precision=precision)
+        else:
+            (z,) = C.conv_nhwc([h, *xs], [convz], epilogue=[("sigmoid", cz)], precision=precision)
+            (gated,) = C.conv_nhwc([h, *xs], [convr], epilogue=[("sigmoid_mul", cr, h)], precision=precision)
+        (hn,) = C.conv_nhwc([gated, *xs], [convq], epilogue=[(blend, cq, h, z)], precision=precision)
+        # unfused: the same convolutions with linear epilogues, then the pointwise kernels
+        (zp,), (rp,) = C.conv_nhwc([h, *xs], [convz], precision=precision), C.conv_nhwc([h, *xs], [convr], precision=precision)
+        gated_u = gru_reset(h, rp, cr)
+        (qp,) = C.conv_nhwc([gated_u, *xs], [convq], precision=precision)
+        hn_u = gru_blend(h, zp, qp, cz, cq, softsign=softsign)
+    assert torch.equal(gated, gated_u) and torch.equal(hn, hn_u)
+    for t in (z, gated, hn):
+        assert t.is_contiguous(memory_format=torch.channels_last) and t.shape == h.shape
+    rz, rg, rh = _gru_ref64(h, xs, cz, cr, cq, convz, convr, convq, softsign)
+    for got, ref in ((z, rz), (gated, rg), (hn, rh)):
+        assert float((got.double().cpu() - ref).abs().max()) <= 3e-6, float((got.double().cpu() - ref).abs().max())
+
+
+def test_conv_nhwc_epilogue_argument_checks(S):
+    from stereoformer_amd import conv_split as C
+    torch.manual_seed(92)
+    x = _cl(torch.randn(1, 16, 8, 32, device="cuda"))
+    m = nn.Conv2d(16, 32, 3, padding=1).cuda()
+    h = _cl(torch.randn(1, 32, 8, 32, device="cuda"))
+    with torch.no_grad():
+        with pytest.raises(ValueError):
+            C.conv_nhwc([x], [m], epilogue=[("sigmoid_mul", None, None)])          # missing operand
+        with pytest.raises(ValueError):
+            C.conv_nhwc([x], [m], epilogue=[("sigmoid", h.contiguous())])         # NCHW operand
+        with pytest.raises(ValueError):
+            C.conv_nhwc([x], [m], epilogue=[("sigmoid", h[:, :16])])              # wrong shape
+        with pytest.raises(ValueError):
+            C.conv_nhwc([x], [m], relu=True, epilogue=[("sigmoid", None)])        # ReLU with a gate epilogue
+        with pytest.raises(ValueError):
+            C.conv_nhwc([x], [m], epilogue=[("swish", None)])
+        with pytest.raises(ValueError):
+            C.conv_nhwc([x], [m], precision="fp8")
+        (a,) = C.conv_nhwc([x], [m], epilogue=[("linear", h)])
+        assert torch.allclose(a, m(x) + h, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("scale", [2.0 ** -12, 2.0 ** -6, 1.0, 2.0 ** 9])
+def test_conv_nhwc_split_fp16_is_scale_invariant_inside_the_fp16_range(S, scale):
+    """The default arithmetic splits every operand into two fp16 pieces with the low piece scaled by 2^11: its RELATIVE error
+    must not depend on the magnitude of the data inside fp16's normal range, 2^-14 <= |x| < 65504 (activations x 2^-12 .. 2^9,
+    weights x 2^-3.6 .. 2^2.7); below it the error is absolute, <= 2^-36 per operand."""
+    from stereoformer_amd import conv_split as C
+    torch.manual_seed(93)
+    srcs = [_cl(torch.randn(1, 64, 12, 40, device="cuda") * scale) for _ in range(2)]
+    m = nn.Conv2d(128, 64, 3, padding=1).cuda()
+    with torch.no_grad():
+        m.weight.mul_(scale ** 0.3)
+        m.bias.zero_()
+        (o,) = C.conv_nhwc(srcs, [m], precision="highest")
+    (r,) = _ref64(srcs, [m], False)
+    err, mag = float((o.double().cpu() - r).abs().max()), float(r.abs().max())
+    assert err <= 4e-6 * mag, (err, mag)
+
+
+def test_conv_nhwc_split_fp16_overflow_is_loud(S):
+    """Beyond the fp16 range the default form's result is non-finite -- never silently wrong; 'bf16x6' covers fp32's range."""
+    from stereoformer_amd import conv_split as C
+    torch.manual_seed(94)
+    x = _cl(torch.randn(1, 16, 8, 32, device="cuda"))
+    x[0, 3, 4, 5] = 7.0e4                       # beyond fp16's largest finite value
+    m = nn.Conv2d(16, 32, 3, padding=1).cuda()
+    with torch.no_grad():
+        (o,) = C.conv_nhwc([x], [m], precision="highest")
+        (b,) = C.conv_nhwc([x], [m], precision="bf16x6")
+        assert not bool(torch.isfinite(o[0, :, 3:6, 4:7]).any())          # every output that saw the value
+        assert bool(torch.isfinite(o[0, :, :2]).all())
+        assert torch.allclose(b, m(x), rtol=1e-5, atol=1e-2)             # the split-bf16 form covers fp32's range
+
+
+def test_packed_weights_follow_updates_through_dot_data(S):
+    """`param.data.copy_()` / `.data.mul_()` leave id, address, version counter and shape unchanged: refresh() finds the change
+    by content (device fingerprints); RAFTStereoLoop / LowCNNGRULoop call it once per forward."""
+    from stereoformer_amd import conv_split as C
+    torch.manual_seed(95)
+    x = _cl(torch.randn(1, 16, 8, 32, device="cuda"))
+    m = nn.Conv2d(16, 32, 3, padding=1).cuda()
+    with torch.no_grad():
+        a = C.conv_nhwc([x], [m])[0]
+        v = m.weight._version
+        m.weight.data.mul_(2.0)
+        assert m.weight._version == v                                   # invisible to the host-side key
+        assert C.refresh([m]) == 1
+        b = C.conv_nhwc([x], [m])[0]
+        assert torch.allclose(b, m(x), rtol=1e-5, atol=1e-5) and not torch.allclose(a, b)
+        assert C.refresh([m]) == 0                                      # nothing changed: nothing dropped
+        c = C.conv_nhwc([x], [m])[0]
+        assert torch.equal(b, c)
+        m.bias.data.copy_(torch.randn_like(m.bias))
+        assert C.refresh(nn.Sequential(m)) == 1
+        assert torch.allclose(C.conv_nhwc([x], [m])[0], m(x), rtol=1e-5, atol=1e-5)
+        C.invalidate([m])
+        assert "_stereo_conv_cache" not in m.__dict__
+        fa, fb = C.fingerprints([m.weight, m.bias]), C.fingerprints([m.weight.flip(0).contiguous(), m.bias])
+        assert fa[1] == fb[1] and fa[0] != fb[0]                        # position-dependent
+
+
+def test_loop_follows_dot_data_weight_updates_with_and_without_graph(S):
+    from stereoformer_amd import conv_split as C
+    torch.manual_seed(96)
+    dev = torch.device("cuda")
+    loop = S.RAFTStereoLoop([128, 128, 128]).eval().to(dev)
+    B, Hq, Wq = 1, 16, 32
+    f1, f2 = torch.randn(B, 256, Hq, Wq, device=dev), torch.randn(B, 256, Hq, Wq, device=dev)
+    nets = [torch.tanh(torch.randn(B, 128, Hq >> i, Wq >> i, device=dev)) for i in range(3)]
+    inps = [[torch.randn(B, 128, Hq >> i, Wq >> i, device=dev) for _ in range(3)] for i in range(3)]
+    with torch.no_grad():
+        for use_graph in (False, True):
+            a = loop(f1, f2, [n.clone() for n in nets], inps, iters=2, test_mode=True, use_graph=use_graph)[1]
+            loop.update_block.gru08.convq.weight.data.mul_(0.5)
+            b = loop(f1, f2, [n.clone() for n in nets], inps, iters=2, test_mode=True, use_graph=use_graph)[1]
+            real = C.supported, C.small_supported
+            C.supported = C.small_supported = lambda *a, **k: False
+            try:
+                r = loop(f1, f2, [n.clone() for n in nets], inps, iters=2, test_mode=True)[1]
+            finally:
+                C.supported, C.small_supported = real
+            assert not torch.allclose(a, b, atol=1e-4)
+            assert float((b - r).abs().max()) <= 1e-3, float((b - r).abs().max())
 
 
 @pytest.mark.parametrize("shape", [(1, 2, 3), (3, 1, 1), (1, 4, 16), (2, 3, 17), (0, 4, 8)])

@@ -266,28 +266,43 @@ def cfg3(dev, rank, world, steps, warmup, cpu):
 
 def conv_split_roofline(B, Hq, Wq, dev):
     """The launch that dominates a RAFT-loop iteration: convz | convr of the 1/4-scale GRU over [h | motion | interp] (384 -> 256
-    channels, 3x3) on the split-bf16 kernel.  `achieved` counts fp32-equivalent flops; the matrix cores execute 6 bf16 piece
-    products per fp32 product, so the dense bf16 peak / 6 is the peak of this formulation."""
+    channels, 3x3, gate math in the epilogue) on the split-fp16 kernel.  `achieved` counts fp32-equivalent flops; the matrix
+    cores execute 3 fp16 piece products per fp32 product, so the dense fp16 peak / 3 is the peak of this formulation."""
     import torch.nn as nn
     from stereoformer_amd import conv_split as C
     cl = torch.channels_last
     srcs = [torch.randn(B, 128, Hq, Wq, device=dev).contiguous(memory_format=cl) for _ in range(3)]
+    ctx = [torch.randn(B, 128, Hq, Wq, device=dev).contiguous(memory_format=cl) for _ in range(2)]
     convs = [nn.Conv2d(384, 128, 3, padding=1).to(dev) for _ in range(2)]
+    epi = [("sigmoid", ctx[0]), ("sigmoid_mul", ctx[1], srcs[0])]
     with torch.no_grad():
-        ms = event_ms(lambda: C.conv_nhwc(srcs, convs))
+        ms = event_ms(lambda: C.conv_nhwc(srcs, convs, epilogue=epi))
+        ms6 = event_ms(lambda: C.conv_nhwc(srcs, convs, epilogue=epi, precision="bf16x6"))
     gf = 2 * B * Hq * Wq * 384 * 256 * 9 / 1e9
     tf = gf / ms
-    return {"bound": "mfma", "kernel": "conv_split_kernel<3,4> (A14: convz | convr of the 1/4-scale ConvGRU, 384 -> 256 channels, "
-                                       "fp32-faithful split-bf16 on v_mfma_f32_32x32x16_bf16; ~84 % of the loop's time is this kernel)",
-            "achieved": round(tf, 1), "peak": round(2500.0 / 6, 1), "unit": "TFLOP/s", "frac": round(tf / (2500.0 / 6), 4),
-            "traffic": None, "avg_launch_ms": round(ms, 4), "executed_bf16_tflops": round(6 * tf, 1),
+    traffic = None
+    try:   # HBM bytes per launch from the committed counter passes of this kernel (tools/refresh_profiles.sh), not this run
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "pmc_conv_latest.json")) as f:
+            traffic = json.load(f)
+    except (OSError, ValueError):
+        pass
+    return {"bound": "mfma", "kernel": "conv_split_kernel<3,4,F32_F16X3> (A14: convz | convr of the 1/4-scale ConvGRU, 384 -> 256 "
+                                       "channels, sigmoid / sigmoid x h epilogues; fp32-faithful split-fp16 on "
+                                       "v_mfma_f32_32x32x16_f16, 3 piece products; most of the loop's time is this kernel)",
+            "achieved": round(tf, 1), "peak": round(2500.0 / 3, 1), "unit": "TFLOP/s", "frac": round(tf / (2500.0 / 3), 4),
+            "traffic": None if traffic is None else traffic.get("traffic_bytes_per_launch"),
+            "traffic_source": None if traffic is None else traffic.get("source"),
+            "algorithmic_bytes": B * Hq * Wq * 128 * 4 * (3 + 3 + 2) + 384 * 256 * 9 * 4,
+            "avg_launch_ms": round(ms, 4), "executed_f16_tflops": round(3 * tf, 1),
             "frac_of_f32_mfma_peak": round(tf / MFMA_F32_PEAK, 4),
-            "sustained_bf16_mfma_tflops_random_operands": [1470, 1660],
-            "frac_of_sustained_rate": round(6 * tf / 1660.0, 3),
-            "note": "fp32-equivalent flops; MIOpen's fp32 implicit GEMM runs the same launch at ~128 TFLOP/s (0.81 of the f32 MFMA "
-                    "peak).  The 2.5 PFLOP/s bf16 figure is not reachable with real data on this part: a pure "
-                    "v_mfma_f32_32x32x16_bf16 loop sustains 2.43 PFLOP/s on CONSTANT operands but 1.47-1.66 PFLOP/s on random bits "
-                    "(power: the clock drops to 1.4-1.6 GHz; tools/mfma_rate_bf16.hip) -- frac_of_sustained_rate is against 1.66"}
+            "split_bf16_six_product_form_ms": round(ms6, 4),
+            "sustained_mfma_tflops_random_operands": [1470, 1660],
+            "frac_of_sustained_rate": round(3 * tf / 1660.0, 3),
+            "note": "fp32-equivalent flops; MIOpen's fp32 implicit GEMM runs the same convolution at ~128 TFLOP/s (0.81 of the f32 "
+                    "MFMA peak), round 2's six-product split-bf16 form at ~220.  The 2.5 PFLOP/s figure is not reachable with real "
+                    "data on this part: a pure 32x32x16 MFMA loop sustains 2.43 PFLOP/s on CONSTANT operands but 1.47-1.66 PFLOP/s "
+                    "on random bits (power: the clock drops to 1.4-1.6 GHz; tools/mfma_rate_bf16.hip) -- frac_of_sustained_rate is "
+                    "against 1.66"}
 
 
 def cfg4(dev, rank, world, steps, warmup, cpu, mixed=False):
@@ -299,7 +314,7 @@ def cfg4(dev, rank, world, steps, warmup, cpu, mixed=False):
     for mp in ((False, True, "high") if mixed else (False,)):
         hp = mp == "high"     # fp32 activations, bf16x3 convolution arithmetic (conv_precision='high')
         mp = mp is True
-        loop = S.RAFTStereoLoop([128, 128, 128], mixed_precision=mp, channels_last=True,
+        loop = S.RAFTStereoLoop([128, 128, 128], mixed_precision=mp,      # (defaults: NHWC + conv_split under no_grad)
                                 conv_precision="high" if hp else "highest").eval().to(dev)
         fn = lambda: loop(f1, f2, [n.clone() for n in nets], inps, iters=16, test_mode=True, use_graph=True)
         sec, per_rank = timed(fn, steps, warmup, world, dev)
@@ -321,7 +336,7 @@ def cfg4(dev, rank, world, steps, warmup, cpu, mixed=False):
                          B, world, sec, per_rank, steps, warmup, roof, cb,
                          {"bounded_by": ("MIOpen fp16 convolutions of the update block" if mp else
                                          "the update block's convolutions (1.2 TFLOP fp32-equivalent per iteration for 8 pairs) on "
-                                         "the split-bf16 matrix-core kernel"),
+                                         "the split-fp16 matrix-core kernel"),
                           "dtype": "f32 (+ f16 convs)" if mp else "f32"}))
         del loop
     del f1, f2, nets, inps
@@ -330,7 +345,7 @@ def cfg4(dev, rank, world, steps, warmup, cpu, mixed=False):
     disp = torch.rand(B, 1, 72, 120, device=dev, generator=g) * 20
     li = torch.randn(B, 3, 576, 960, device=dev, generator=g)
     ri = torch.randn(B, 3, 576, 960, device=dev, generator=g)
-    lp = S.LowCNNGRULoop(24, 32, 20, channels_last=True).eval().to(dev)
+    lp = S.LowCNNGRULoop(24, 32, 20).eval().to(dev)
     n = max(steps, 10)
     sec, per_rank = timed(lambda: lp(vol, disp, li, ri, iters=16, use_graph=True), n, warmup, world, dev)
     roof2 = None
@@ -357,7 +372,7 @@ def cfg5(dev, rank, world, steps, warmup, cpu):
     f1, f2, nets, inps = raft_inputs(B, Hq, Wq, dev, 500 + rank)
     att = S.CrossAttentionCostVolume(Dq, "neginf", "sqrt_c")
     torch.manual_seed(5)
-    loop = S.RAFTStereoLoop([128, 128, 128], channels_last=True).eval().to(dev)
+    loop = S.RAFTStereoLoop([128, 128, 128]).eval().to(dev)
 
     def chain():
         _, d = att(f1, f2, need_out=False)
@@ -389,7 +404,7 @@ def cfg5(dev, rank, world, steps, warmup, cpu):
     return entry("cfg-5", "KITTI 1242x375 (padded 1248x384) D=256: cross-attention at 1/4 resolution [4,256,96,312] (band 64) "
                  "-> initial disparity -> 16-iteration IterativeLocalCostVolume loop, batch=4 per GPU (32 pairs over 8 GPUs), fp32",
                  B, world, sec, per_rank, steps, warmup, roof, cb,
-                 {"bounded_by": "the update block's convolutions (split-bf16 matrix-core kernel, csrc/conv_split.hip)"})
+                 {"bounded_by": "the update block's convolutions (split-fp16 matrix-core kernel, csrc/conv_split.hip)"})
 
 
 def run_all(dev, rank=0, world=1, cpu=False, rehearsal=False, steps=3, warmup=2, only=None, mixed=False):

@@ -1,8 +1,10 @@
-"""dev: split-bf16 convolution kernel vs MIOpen fp32 at the update block's shapes.   python tools/conv_ab.py"""
+"""dev: the split-operand convolution kernel (both fp32-faithful forms) vs MIOpen fp32 at the update block's shapes, and the
+ConvGRU with its gate math in the epilogues vs linear epilogues + pointwise kernels.   python tools/conv_ab.py"""
 import os, sys, torch, torch.nn as nn
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import stereoformer_amd as S
 from stereoformer_amd import conv_split as C
+from stereoformer_amd.update_dlc import gru_blend, gru_reset
 from tools.kernel_bench import timeit
 cl = lambda t: t.contiguous(memory_format=torch.channels_last)
 for (nm, B, H, W, cs, co, relu) in (("gru08 convz|convr [8,384,136,240] -> 128+128", 8, 136, 240, (128, 128, 128), (128, 128), False),
@@ -16,13 +18,37 @@ for (nm, B, H, W, cs, co, relu) in (("gru08 convz|convr [8,384,136,240] -> 128+1
     convs = [nn.Conv2d(sum(cs), c, 3, padding=1).cuda().to(memory_format=torch.channels_last) for c in co]
     gf = 2 * B * H * W * sum(cs) * sum(co) * 9 / 1e9
     with torch.no_grad():
-        ms = timeit(lambda: C.conv_nhwc(srcs, convs, relu=relu), 10, 3)
-
+        ms = timeit(lambda: C.conv_nhwc(srcs, convs, relu=relu, precision="highest"), 10, 3)
+        ms6 = timeit(lambda: C.conv_nhwc(srcs, convs, relu=relu, precision="bf16x6"), 10, 3)
         x = torch.cat(srcs, 1)
         ms_lib = timeit(lambda: [m(x) for m in convs], 10, 3)
-        ms_lib_all = timeit(lambda: [torch.relu(m(torch.cat(srcs, 1))) if relu else m(torch.cat(srcs, 1)) for m in convs], 10, 3)
-    print(f"{nm}: split {ms:.3f} ms = {gf / ms:.0f} TFLOP/s fp32-equivalent | MIOpen convs alone {ms_lib:.3f} ms = {gf / ms_lib:.0f} | "
-          f"MIOpen + cat (+ relu) {ms_lib_all:.3f} ms", flush=True)
+    print(f"{nm}: split-fp16 (3 products) {ms:.3f} ms = {gf / ms:.0f} TFLOP/s fp32-equivalent | split-bf16 (6 products) {ms6:.3f} ms = "
+          f"{gf / ms6:.0f} | MIOpen convs alone {ms_lib:.3f} ms = {gf / ms_lib:.0f}", flush=True)
+
+# the whole ConvGRU step at 1/4 scale
+B, H, W = 8, 136, 240
+h = cl(torch.tanh(torch.randn(B, 128, H, W, device="cuda")))
+xs = [cl(torch.randn(B, 128, H, W, device="cuda")) for _ in range(2)]
+cz, cr, cq = [cl(torch.randn(B, 128, H, W, device="cuda")) for _ in range(3)]
+convz, convr, convq = [nn.Conv2d(384, 128, 3, padding=1).cuda().to(memory_format=torch.channels_last) for _ in range(3)]
+
+
+def fused(p):
+    z, g = C.conv_nhwc([h, *xs], [convz, convr], epilogue=[("sigmoid", cz), ("sigmoid_mul", cr, h)], precision=p)
+    return C.conv_nhwc([g, *xs], [convq], epilogue=[("gru_blend", cq, h, z)], precision=p)[0]
+
+
+def unfused(p):
+    zp, rp = C.conv_nhwc([h, *xs], [convz, convr], precision=p)
+    (qp,) = C.conv_nhwc([gru_reset(h, rp, cr), *xs], [convq], precision=p)
+    return gru_blend(h, zp, qp, cz, cq)
+
+
+with torch.no_grad():
+    for p in ("highest", "bf16x6"):
+        a, b = timeit(lambda: fused(p), 10, 3), timeit(lambda: unfused(p), 10, 3)
+        print(f"ConvGRU step [8,128+256,136,240], precision {p}: gate math in the epilogues {a:.3f} ms | linear epilogues + gru_reset + gru_blend {b:.3f} ms",
+              flush=True)
 
 x = cl(torch.randn(8, 256, 136, 240, device="cuda"))
 m = nn.Conv2d(256, 2, 3, padding=1).cuda().to(memory_format=torch.channels_last)
