@@ -92,6 +92,15 @@ def _gru_step_split(h, xs, conv_z, conv_r, conv_q, cz, cr, cq):
     ``[h | x...]`` (no concatenation is materialised) with the gate math in the epilogue -- ``z = sigmoid(. + cz)`` and
     ``r h = sigmoid(. + cr) * h`` leave the kernel, the pre-activations never exist in memory --, then ``convq`` over
     ``[r h | x...]`` whose epilogue is ``tanh(. + cq)`` and the ``(1 - z) h + z q`` blend (update.py:28-32)."""
+    if h.dtype == torch.float16:
+        # mixed_precision: an fp16 epilogue would fetch its operands as 2-byte accesses per lane (measured: + 55 % on the launch);
+        # linear epilogues + the vectorised pointwise kernels stay the faster form there
+        if conv_split.supported([h, *xs], [conv_z, conv_r]):
+            z_pre, r_pre = conv_split.conv_nhwc([h, *xs], [conv_z, conv_r])
+        else:
+            (z_pre,), (r_pre,) = conv_split.conv_nhwc([h, *xs], [conv_z]), conv_split.conv_nhwc([h, *xs], [conv_r])
+        (q_pre,) = conv_split.conv_nhwc([gru_reset(h, r_pre, cr), *xs], [conv_q])
+        return gru_blend(h, z_pre, q_pre, cz, cq)
     if conv_split.supported([h, *xs], [conv_z, conv_r]):
         z, gated = conv_split.conv_nhwc([h, *xs], [conv_z, conv_r], epilogue=[("sigmoid", cz), ("sigmoid_mul", cr, h)])
     else:   # hidden sizes that do not fill whole 128-channel output tiles: one launch per gate

@@ -7,7 +7,7 @@ from tools.bench_configs import raft_inputs
 dev = torch.device("cuda")
 f1, f2, nets, inps = raft_inputs(8, 136, 240, dev, 400)
 torch.manual_seed(4)
-loop = S.RAFTStereoLoop([128, 128, 128], channels_last=True, mixed_precision="mixed" in sys.argv).eval().to(dev)
+loop = S.RAFTStereoLoop([128, 128, 128], mixed_precision="mixed" in sys.argv).eval().to(dev)
 with torch.no_grad():
     for _ in range(3):
         loop(f1, f2, [n.clone() for n in nets], inps, iters=16, test_mode=True, use_graph=False)
