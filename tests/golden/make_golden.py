@@ -323,6 +323,17 @@ def g9_raft_loop():
     save("g9_raft_loop", **out)
 
 
+def _import_only_standins():
+    """scikit-image and torchvision are absent in the build container; the reference modules used here only IMPORT them (never
+    execute anything from them on these code paths): empty stand-in modules make the imports succeed (SURVEY 9.3 recipe)."""
+    import types
+    sk = types.ModuleType("skimage"); sk.io = types.ModuleType("skimage.io"); sk.transform = types.ModuleType("skimage.transform")
+    sys.modules.update({"skimage": sk, "skimage.io": sk.io, "skimage.transform": sk.transform})
+    tv = types.ModuleType("torchvision"); tvt = types.ModuleType("torchvision.transforms")
+    tvf = types.ModuleType("torchvision.transforms.functional"); tv.transforms = tvt; tvt.functional = tvf
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt, "torchvision.transforms.functional": tvf})
+
+
 # ------------------------------------------------------------------ G10
 def g10_metrics_io():
     """Metrics, disparity rescale and the PFM container."""
@@ -341,15 +352,12 @@ def g10_metrics_io():
     out["d1"] = npy(D1_metric(pred, gt))
     out["p1"] = npy(P1_metric(pred, gt))
     out["thres3"] = npy(thres_metric(pred, gt, (gt > 0) & (gt < 192), 3.0))
-    try:
-        from dataloader.preprocess import scale_disp
-        d = torch.rand(1, 1, 12, 20) * 50
-        out["scale_in"], out["scale_out"] = npy(d), npy(scale_disp(d, (1, 9, 16)))
-    except Exception as e:  # dataloader.preprocess imports skimage/torchvision, absent here
-        print("scale_disp not importable (", type(e).__name__, "): restated with nn.Upsample", file=sys.stderr)
-        d = torch.rand(1, 1, 12, 20) * 50
-        out["scale_in"] = npy(d)
-        out["scale_out"] = npy(torch.nn.Upsample(size=(9, 16), mode="bilinear")(d) * (16 * 1.0 / 20))
+    # the reference's own scale_disp (dataloader/preprocess.py:257-272; the module imports torchvision / skimage at the top but
+    # executes neither on this path: import-only stand-ins, as for G16)
+    _import_only_standins()
+    from dataloader.preprocess import scale_disp
+    d = torch.rand(1, 1, 12, 20) * 50
+    out["scale_in"], out["scale_out"] = npy(d), npy(scale_disp(d, (1, 9, 16)))
     img = (torch.rand(7, 11) * 100).numpy().astype(np.float32)
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "x.pfm")
@@ -639,11 +647,7 @@ def g16_dataset():
     import tempfile
     import types
     from PIL import Image
-    sk = types.ModuleType("skimage"); sk.io = types.ModuleType("skimage.io"); sk.transform = types.ModuleType("skimage.transform")
-    sys.modules.update({"skimage": sk, "skimage.io": sk.io, "skimage.transform": sk.transform})
-    tv = types.ModuleType("torchvision"); tvt = types.ModuleType("torchvision.transforms")
-    tvf = types.ModuleType("torchvision.transforms.functional"); tv.transforms = tvt; tvt.functional = tvf
-    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt, "torchvision.transforms.functional": tvf})
+    _import_only_standins()
     from dataloader.SceneflowLoader import StereoDataset
     from dataloader import transforms as T
     from utils.file_io import write_pfm, read_disp
@@ -703,6 +707,9 @@ def check_oracle_cfg1():
 
 if __name__ == "__main__":
     CHECK = "--check" in sys.argv
+    if "--only-g10" in sys.argv:
+        g10_metrics_io()
+        sys.exit(0)
     g1_volumes()
     g2_soft_argmin()
     g3_local_lookup()

@@ -413,3 +413,55 @@ def test_conv_nhwc_random_shapes_sweep(S):
                 r = F.relu(m(x)) if relu else m(x)
                 assert o.shape == r.shape, (case, B, H, W, cs, co, k)
                 assert float((o - r).abs().max()) <= 3e-5 * max(1.0, float(r.abs().max())), (case, B, H, W, cs, co, k, relu, bias)
+
+
+@pytest.mark.parametrize("flags", [dict(iter08=True, iter16=False, iter32=False), dict(iter08=True, iter16=True, iter32=False),
+                                   dict(iter08=True, iter16=True, iter32=True, update=False), dict(iter08=False, iter16=True, iter32=True),
+                                   dict(iter08=True, iter16=False, iter32=False, update=False)])
+def test_update_block_partial_iterations_and_early_return(S, monkeypatch, flags):
+    """The reference calls the block with subsets of its GRU levels (slow-fast schedule, raft_stereo.py:166-170) and with
+    update=False (:170): with iter16 = iter32 = False the motion encoder is NOT forked to the side stream, with update=False the
+    block returns right after the join.  Every combination under channels_last (conv_split + side stream) against the library
+    path, twice in a row (a missed join would show up in the second call), eager and inside a HIP-graph capture."""
+    from stereoformer_amd import conv_split as C
+    torch.manual_seed(97)
+    B, H, W = 1, 16, 32
+    blk = S.BasicMultiUpdateBlock_LZH(4, 4, 3, 2, [128, 128, 128]).cuda().eval().to(memory_format=torch.channels_last)
+    mk = lambda c, h, w: _cl(torch.randn(B, c, h, w, device="cuda") * 0.5)
+    nets0 = [torch.tanh(mk(128, H >> i, W >> i)) for i in range(3)]
+    inps = [[mk(128, H >> i, W >> i) for _ in range(3)] for i in range(3)]
+    corr, flow = torch.randn(B, 36, H, W, device="cuda"), torch.randn(B, 2, H, W, device="cuda")
+
+    def run():
+        nets = [n.clone() for n in nets0]
+        outs = []
+        with torch.no_grad():
+            for it in range(2):
+                r = blk(nets, inps, corr, flow + 0.1 * it, **flags)
+                nets = r if flags.get("update", True) is False else r[0]
+                outs.append(r)
+        flat = []
+        for r in outs:
+            for x in (r if flags.get("update", True) is False else [*r[0], r[1], r[2]]):
+                flat.append(x.clone())
+        return flat
+
+    a = run()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(g):
+        c = run()
+    g.replay()
+    torch.cuda.synchronize()
+    monkeypatch.setattr(C, "supported", lambda *a, **k: False)
+    monkeypatch.setattr(C, "small_supported", lambda *a, **k: False)
+    b = run()
+    for x, y, z in zip(a, b, c):
+        assert x.shape == y.shape
+        assert float((x - y).abs().max()) <= 2e-5 * max(1.0, float(y.abs().max())), float((x - y).abs().max())
+        # (replay vs eager: to rounding, not bit for bit -- the library picks its 1x1 / 7x7 solvers per call)
+        assert float((x - z).abs().max()) <= 2e-5 * max(1.0, float(x.abs().max())), float((x - z).abs().max())
