@@ -37,7 +37,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     procs = []
     # the split-bf16 attention kernels take their running maxima with nnan max (no NaN reaches them: a band's nearest key
     # is never masked): without the flag every MFMA result is canonicalised (v_max x, x, x) before its first v_max
-    extra = {"attention_bf16.hip": ["-fno-honor-nans"], "attention_chunked.hip": ["-fno-honor-nans"]}
+    extra = {"attention_bf16.hip": ["-fno-honor-nans"], "attention_chunked.hip": ["-fno-honor-nans"],
+             "attention_f16.hip": ["-fno-honor-nans"]}
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
         objs.append(obj)

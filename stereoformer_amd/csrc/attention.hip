@@ -706,7 +706,12 @@ extern "C" int stereo_cross_attention_f32(const float *left, const float *right,
             const float sc = scale_mode == STEREO_SCALE_MEAN ? 1.0f / (float)C : 1.0f / sqrtf((float)C);
             const int same_kv = (out != nullptr && value == right && Cv == C) ? 1 : 0;
             dim3 grid4((W + A4_TQ - 1) / A4_TQ, H, B);
-            if (C <= 32 && (out == nullptr || same_kv) && (forced == 7 || forced == 0)) {  // v7: split-bf16 matrix cores (default)
+            if (C <= 32 && (out == nullptr || same_kv) && (forced == 9 || forced == 0)) {  // v9: split-fp16 matrix cores (default)
+                const int rc9 = stereo_cross_attention_split16<float>(left, right, out, disp, B, C, H, W, D, mask_mode, sc,
+                                                                      as_stream(stream));
+                if (rc9 != STEREO_ERR_UNSUPPORTED) return rc9;
+            }
+            if (C <= 32 && (out == nullptr || same_kv) && forced == 7) {  // v7: split-bf16 (test hook)
                 const int rc7 = stereo_cross_attention_split<float>(left, right, out, disp, B, C, H, W, D, mask_mode, sc,
                                                                     as_stream(stream));
                 if (rc7 != STEREO_ERR_UNSUPPORTED) return rc7;
@@ -767,7 +772,11 @@ template <typename TIN>
 int stereo_corr_soft_argmin_mfma(const TIN *L, const TIN *R, float *disp, int B, int C, int H, int W, int D, float sgn,
                                  hipStream_t st)
 {
-    if (stereo_opt(OPT_ATT_KERNEL) == 0 || stereo_opt(OPT_ATT_KERNEL) == 7) {  // split-bf16 matrix cores where they apply
+    if (stereo_opt(OPT_ATT_KERNEL) == 0 || stereo_opt(OPT_ATT_KERNEL) == 9) {  // split-fp16 matrix cores where they apply
+        const int rc = stereo_cross_attention_split16<TIN>(L, R, nullptr, disp, B, C, H, W, D, STEREO_MASK_ZERO, sgn / (float)C, st);
+        if (rc != STEREO_ERR_UNSUPPORTED) return rc;
+    }
+    if (stereo_opt(OPT_ATT_KERNEL) == 7) {  // split-bf16 (test hook)
         const int rc = stereo_cross_attention_split<TIN>(L, R, nullptr, disp, B, C, H, W, D, STEREO_MASK_ZERO, sgn / (float)C, st);
         if (rc != STEREO_ERR_UNSUPPORTED) return rc;
     }
@@ -795,7 +804,11 @@ extern "C" int stereo_cross_attention_f16(const void *left, const void *right, c
     const f16 *L = static_cast<const f16 *>(left), *R = static_cast<const f16 *>(right), *V = static_cast<const f16 *>(value);
     const float sc = scale_mode == STEREO_SCALE_MEAN ? 1.0f / (float)C : 1.0f / sqrtf((float)C);
     const bool same_kv = out != nullptr && value == right && Cv == C;
-    if (C <= 32 && (out == nullptr || same_kv) && (stereo_opt(OPT_ATT_KERNEL) == 7 || stereo_opt(OPT_ATT_KERNEL) == 0)) {
+    if (C <= 32 && (out == nullptr || same_kv) && (stereo_opt(OPT_ATT_KERNEL) == 9 || stereo_opt(OPT_ATT_KERNEL) == 0)) {
+        const int rc = stereo_cross_attention_split16<f16>(L, R, out, disp, B, C, H, W, D, mask_mode, sc, as_stream(stream));
+        if (rc != STEREO_ERR_UNSUPPORTED) return rc;
+    }
+    if (C <= 32 && (out == nullptr || same_kv) && stereo_opt(OPT_ATT_KERNEL) == 7) {
         const int rc = stereo_cross_attention_split<f16>(L, R, out, disp, B, C, H, W, D, mask_mode, sc, as_stream(stream));
         if (rc != STEREO_ERR_UNSUPPORTED) return rc;
     }

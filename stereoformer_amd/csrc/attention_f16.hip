@@ -1,0 +1,343 @@
+// Epipolar cross-attention (A7), C <= 32, value = right features, on the FP16 matrix cores with SPLIT operands (v9).
+//
+// attention_bf16.hip (v7) splits every fp32 operand into three bf16 pieces and runs six piece products per fp32 product: 22
+// matrix instructions per 32-key tile (12 for Q K^T, 10 for P V).  Here every operand is TWO fp16 pieces, x = hi + 2^-11 lo'
+// (common.h: 22-23 significant bits; exact piece products), the three leading products go to two fp32 accumulators -- hi hi
+// into one, hi lo' + lo' hi into the other, result = acc0 + 2^-11 acc1 -- so a tile costs 6 + 6 v_mfma_f32_32x32x16_f16
+// instead of 22, and the probabilities reach P V with 22 bits instead of v7's 16.  fp16 FEATURES are their own single piece:
+// the score scale moves from the Q operand to the accumulator (so Q stays exactly fp16) and a tile costs 2 + 4.
+// Range: |feature| < 65 504 (fp16); beyond it the result is inf / NaN, never silently wrong -- the fp32 kernels of
+// attention.hip cover fp32's whole range (test hook att_kernel = 5 / 4).
+//
+// LDS image [piece][channel][key] f16 as in v7 (one image serves V^T row-wise and K through ds_read_b64_tr_b16), but channel
+// row r starts 16 (r & 3) + 2 (r >> 2) dwords into a row slot that is a whole number of 256-B bank rows: the transposed K read
+// of a 32-lane group touches 4 channel rows x 16 dwords -- with that offset the four tile the 64 banks exactly -- and the
+// row-wise V^T read (32 channel rows at one key offset, 2 dwords each) lands on 32 distinct even banks.  (v7's packed rows,
+// 226 dwords apart, made every transposed read 2-way conflicted: SQ_LDS_BANK_CONFLICT = 21 % of the LDS cycles.)
+// Softmax, masks, disparity expectation, persistence and register prefetch are v5's / v7's.
+#include "common.h"
+
+namespace {
+
+template <int NT, int NWV, typename TIN>
+__global__ __launch_bounds__(NWV * 64, NWV == 6 ? 3 : 1) void cross_attention_split16_kernel(const TIN *__restrict__ L, const TIN *__restrict__ R,
+                                                                           float *__restrict__ out, float *__restrict__ disp,
+                                                                           int C, int H, int W, int D, int mask_mode,
+                                                                           float scale, int tiles_per_wg, int ntiles)
+{
+    constexpr int NP = sizeof(TIN) == 4 ? 2 : 1;  // pieces of a feature value
+    constexpr int Dk = 32 * (NT - 1);
+    constexpr int TQW = 32 * NWV;
+    constexpr int NK = TQW + Dk;
+    constexpr int RSD = (NK / 2 + 62 + 63) / 64 * 64;   // row slot in dwords: a whole number of bank rows, room for the offset
+    constexpr int RSE = 2 * RSD;                        // ... in f16 elements
+    constexpr int PSE = 32 * RSE;                       // piece stride
+    constexpr int RMAX = (32 + NWV - 1) / NWV;
+    constexpr int NPASS = (NK / 4 + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) _Float16 Im16[];   // [NP][32][RSE]
+
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const unsigned HWu = (unsigned)H * (unsigned)W;  // launcher: 32 * H * W < 2^30 (32-bit byte offsets)
+    const int nx = (W + TQW - 1) / TQW;
+    const float sc2 = scale * 1.44269504088896340736f;
+    const int dl = l31 - 4 * half;
+    auto row_off = [](int row) { return row * RSE + 32 * (row & 3) + 4 * (row >> 2); };   // elements
+    // transposed K reads: lane 4 q + p of its 16-lane group supplies row (channel) R0 + q, keys K0 + 4 p .. ; R0 = 8 half + 16 s
+    // + 4 tt is a multiple of 4, so the row's offset splits into a lane part and a compile-time (s, tt) part
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
+    const int k_off = (8 * half + tq) * RSE + 32 * tq + 8 * half + 32 * wave + 16 * tg1 + 4 * tp;  // + (16 s + 4 tt) RSE + 4 (4 s + tt) + 32 t
+    const int v_off = row_off(l31) + 32 * wave + 4 * half;                                        // + 32 t + 16 s (+ 8 for elements 4..7)
+
+    int tile = blockIdx.x * tiles_per_wg;
+    const int tile_end = (tile + tiles_per_wg < ntiles) ? tile + tiles_per_wg : ntiles;
+    if (tile >= tile_end) return;
+
+    // Loads go through buffer resources (common.h): a key outside [0, W) is an out-of-range byte offset and reads 0 -- the zero
+    // padding of the band and what ZERO-mask mode wants for the values; channel rows >= C get an empty resource, Q channels
+    // >= C fall past the end of theirs.  No per-lane bound selects.
+    typename Quad<TIN>::raw rk[RMAX][NPASS];
+    TIN qn[16];
+    constexpr int ES = (int)sizeof(TIN);
+    auto issue = [&](int tl) {
+        const int x = tl % nx, bh = tl / nx;
+        const int hh = bh % H, bb = bh / H;
+        const int w0 = x * TQW, kbase = w0 - Dk;
+        const TIN *Rb = R + ((size_t)bb * C * HWu + (size_t)hh * W);
+        const TIN *Lb = L + ((size_t)bb * C * HWu + (size_t)hh * W);
+        int voff[NPASS];
+#pragma unroll
+        for (int pp = 0; pp < NPASS; ++pp) voff[pp] = (lane + 64 * pp < NK / 4) ? (kbase + 4 * (lane + 64 * pp)) * ES : -1;
+#pragma unroll
+        for (int rr = 0; rr < RMAX; ++rr) {       // one resource per row: the range check sees voffset + soffset on gfx950
+            const int row = wave + rr * NWV;
+            const __amdgpu_buffer_rsrc_t rs = buffer_rsrc(Rb + (size_t)row * HWu, row < C ? (unsigned)W * ES : 0u);
+#pragma unroll
+            for (int pp = 0; pp < NPASS; ++pp) rk[rr][pp] = BufLd<TIN>::quad(rs, voff[pp], 0);
+        }
+        const __amdgpu_buffer_rsrc_t rq = buffer_rsrc(Lb, ((unsigned)(C - 1) * HWu + (unsigned)W) * ES);
+        int vq = (int)(((unsigned)(8 * half) * HWu + (unsigned)(w0 + 32 * wave + l31)) * ES);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {           // B operand order: k-step s = i >> 3, element j = i & 7 -> channel 16 s + 8 half + j
+            qn[i] = BufLd<TIN>::one(rq, vq, 0);
+            vq += (int)((i == 7 ? 9u : 1u) * HWu * ES);
+        }
+    };
+    auto commit = [&]() {  // registers -> the f16 piece images: one 8-byte store per quad and piece
+#pragma unroll
+        for (int rr = 0; rr < RMAX; ++rr) {
+            const int row = wave + rr * NWV;
+            if (row < 32) {
+                const int ro = row_off(row);
+#pragma unroll
+                for (int pp = 0; pp < NPASS; ++pp) {
+                    if (lane + 64 * pp < NK / 4) {
+                        if constexpr (NP == 2) {
+                            const f32x4 v = Quad<TIN>::widen(rk[rr][pp]);
+                            f16x2 a[2], b[2];
+                            split_pair_f16((f32x2){v[0], v[1]}, a);
+                            split_pair_f16((f32x2){v[2], v[3]}, b);
+#pragma unroll
+                            for (int p = 0; p < 2; ++p)
+                                *reinterpret_cast<f16x4 *>(&Im16[p * PSE + ro + 4 * (lane + 64 * pp)]) =
+                                    __builtin_shufflevector(a[p], b[p], 0, 1, 2, 3);
+                        } else {
+                            *reinterpret_cast<typename Quad<TIN>::raw *>(&Im16[ro + 4 * (lane + 64 * pp)]) = rk[rr][pp];
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    issue(tile);
+    commit();
+    f16x8 qf[2][NP];
+    // a zero accumulator kept in registers for the whole kernel: the first product of every chain takes it as its C operand
+    // (clearing two fresh accumulators per key tile was 32 v_mov per tile -- a seventh of the loop's vector instructions);
+    // opaque to the compiler, which would otherwise rematerialise the zeros in front of each use
+    // (fp32 features only: with fp16 features the kernel fits 128 registers -- two workgroups per CU -- and 16 more would
+    // cost that; there the single accumulator is cleared per tile)
+    f32x16 zacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zacc[r] = 0.0f;
+    if constexpr (NP == 2) asm volatile("" : "+v"(zacc));
+    for (;;) {
+        const int x = tile % nx, bh = tile / nx;
+        const int w0 = x * TQW, kbase = w0 - Dk;
+        const int q = w0 + 32 * wave + l31;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if constexpr (NP == 2) {
+                float xq[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xq[j] = (float)qn[8 * s + j];
+                split_oct_f16(xq, qf[s]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[s][0][j] = (_Float16)qn[8 * s + j];
+            }
+        }
+        __syncthreads();  // the image is visible
+        const bool more = tile + 1 < tile_end;
+        if (more) issue(tile + 1);
+
+        if (w0 + 32 * wave < W) {  // wave-uniform
+            const bool neg_left = mask_mode == STEREO_MASK_NEGINF && kbase < 0;
+            float m = -INFINITY, ssum = 0.0f, esc = 0.0f;
+            f32x16 oh, ol;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oh[r] = 0.0f, ol[r] = 0.0f;
+#pragma unroll 1
+            for (int t = NT - 1; t >= 0; --t) {
+                f32x16 ah, al;
+                // ---- S^T tile = K_t Q^T: A = K through the transposed read, B = Q pieces
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    f16x8 kf[NP];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt) {
+                            const _Float16 *src = &Im16[p * PSE + k_off + (16 * s + 4 * tt) * RSE + 4 * (4 * s + tt) + 32 * t];
+                            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)src);
+                            const short tv[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) kf[p][4 * tt + e] = __builtin_bit_cast(_Float16, tv[e]);
+                        }
+                    }
+                    if constexpr (NP == 2) {
+                        al = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[s][1], s == 0 ? zacc : al, 0, 0, 0);
+                        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[s][0], s == 0 ? zacc : ah, 0, 0, 0);
+                        al = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qf[s][0], al, 0, 0, 0);
+                    } else {
+                        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[s][0], s == 0 ? zacc : ah, 0, 0, 0);
+                    }
+                }
+                // scores in exp2 units: (acc0 + 2^-11 acc1) x scale x log2 e
+                f32x16 a;
+                {   // (packed f32: one v_pk_mul_f32 + one v_pk_fma_f32 per register pair)
+                    const f32x2 sh2 = {sc2, sc2}, sl2 = {sc2 * SPLIT16_LO_UNSCALE, sc2 * SPLIT16_LO_UNSCALE};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        f32x2 v = (f32x2){ah[2 * k], ah[2 * k + 1]} * sh2;
+                        if constexpr (NP == 2) v = __builtin_elementwise_fma((f32x2){al[2 * k], al[2 * k + 1]}, sl2, v);
+                        a[2 * k] = v[0];
+                        a[2 * k + 1] = v[1];
+                    }
+                }
+                // ---- masks + online softmax (v5)
+                const int cb = Dk - 32 * t + dl;
+                if (t == NT - 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (cb < (r & 3) + 8 * (r >> 2)) a[r] = -INFINITY;  // d < 0
+                }
+                if (Dk - 32 * t + 31 >= D) {
+                    const int lim = cb - D;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (lim >= (r & 3) + 8 * (r >> 2)) a[r] = -INFINITY;  // d >= D
+                }
+                if (neg_left) {
+                    const int lim = cb - q;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (lim > (r & 3) + 8 * (r >> 2)) a[r] = -INFINITY;  // key = q - d < 0
+                }
+                float mt = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) mt = fmaxf(mt, fmaxf(a[r], a[r + 1]));
+                mt = fmaxf(mt, __shfl_xor(mt, 32));
+                const float mn = fmaxf(m, mt);
+                const float alpha = __builtin_amdgcn_exp2f(m - mn);
+                m = mn;
+                // packed-f32 VALU on register pairs (2 x the scalar rate): register 2k sits at key offset 2 (k & 1) + 8 (k >> 1)
+                // of its tile, register 2k + 1 one further
+                const f32x2 nm = {-mn, -mn};
+                f32x2 T2 = {0.0f, 0.0f}, U2 = {0.0f, 0.0f};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const f32x2 sh = (f32x2){a[2 * k], a[2 * k + 1]} + nm;
+                    const f32x2 pe = {__builtin_amdgcn_exp2f(sh[0]), __builtin_amdgcn_exp2f(sh[1])};
+                    a[2 * k] = pe[0];
+                    a[2 * k + 1] = pe[1];
+                    T2 += pe;
+                    const float base = (float)(2 * (k & 1) + 8 * (k >> 1));
+                    U2 = __builtin_elementwise_fma(pe, (f32x2){base, base}, U2);
+                }
+                const float ts = T2[0] + T2[1], ti = U2[0] + U2[1] + T2[1];
+                ssum = fmaf(ssum, alpha, ts);
+                esc = fmaf(esc, alpha, fmaf((float)cb, ts, -ti));
+                if (out) {
+                    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {  // wave-uniform: the running maximum rarely moves after the nearest tiles
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oh[r] *= alpha, ol[r] *= alpha;
+                    }
+                    // ---- O^T += V_t^T P: A = V^T rows from the image (accumulator key order), B = P as hi + 2^-11 lo'
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        f16x8 pq[2];
+                        float xp[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) xp[e] = a[8 * s + e];
+                        split_oct_f16(xp, pq);
+                        f16x8 vf[NP];
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) {
+                            const f16x4 lo = *reinterpret_cast<const f16x4 *>(&Im16[p * PSE + v_off + 32 * t + 16 * s]);
+                            const f16x4 hi = *reinterpret_cast<const f16x4 *>(&Im16[p * PSE + v_off + 32 * t + 16 * s + 8]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) vf[p][e] = lo[e], vf[p][4 + e] = hi[e];
+                        }
+                        ol = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0], pq[1], ol, 0, 0, 0);
+                        oh = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0], pq[0], oh, 0, 0, 0);
+                        if constexpr (NP == 2) ol = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1], pq[0], ol, 0, 0, 0);
+                    }
+                }
+            }
+            float e = esc;
+            ssum += __shfl_xor(ssum, 32);
+            e += __shfl_xor(e, 32);
+            const float inv = 1.0f / ssum;
+            if (q < W) {
+                if (disp && half == 0) disp[(size_t)bh * W + q] = e * inv;
+                if (out) {
+                    const int hh = bh % H, bb = bh / H;
+                    float *ob = out + ((size_t)bb * C * HWu + (size_t)hh * W);
+                    const __amdgpu_buffer_rsrc_t ro = buffer_rsrc(ob, ((unsigned)(C - 1) * HWu + (unsigned)W) * 4u);
+                    int vo = (int)(((unsigned)(4 * half) * HWu + (unsigned)q) * 4u);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {   // accumulator row r -> channel (r & 3) + 8 (r >> 2) + 4 half; >= C: dropped
+                        const float ov = fmaf(ol[r], SPLIT16_LO_UNSCALE, oh[r]) * inv;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov), ro, vo, 0, 0);
+                        vo += (int)(((r & 3) == 3 ? 5u : 1u) * HWu * 4u);
+                    }
+                }
+            }
+        }
+        if (!more) break;
+        __syncthreads();  // every wave is done reading the image
+        commit();
+        ++tile;
+    }
+}
+
+template <int NT, int NWV, typename TIN>
+int launch_split16(const TIN *left, const TIN *right, float *out, float *disp, int B, int C, int H, int W, int D, int mask_mode,
+                   float sc, hipStream_t st)
+{
+    constexpr int NK = 32 * NWV + 32 * (NT - 1);
+    constexpr int RSD = (NK / 2 + 62 + 63) / 64 * 64;
+    const size_t lds = (size_t)(sizeof(TIN) == 4 ? 2 : 1) * 32 * RSD * 4;
+    auto kern = cross_attention_split16_kernel<NT, NWV, TIN>;
+    static std::atomic<unsigned long long> lds_done{0};
+    static std::atomic<int> per_cu{0};
+    if (lds > 160 * 1024 || !lds_opt_in(kern, lds, lds_done)) return STEREO_ERR_UNSUPPORTED;
+    const long long ntl = (long long)((W + 32 * NWV - 1) / (32 * NWV)) * H * B;
+    if (ntl >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
+    // persistent: every resident workgroup takes an equal run of tiles
+    const int resident = 256 * workgroups_per_cu(kern, NWV * 64, lds, per_cu);
+    int tpw = (int)((ntl + resident - 1) / resident);
+    if (stereo_opt(OPT_TILES_PER_WG) > 0) tpw = stereo_opt(OPT_TILES_PER_WG);  // test hook: short persistent runs
+    const int nwg = (int)((ntl + tpw - 1) / tpw);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(NWV * 64), lds, st, left, right, out, disp, C, H, W, D, mask_mode, sc, tpw,
+                       (int)ntl);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+}  // namespace
+
+// Library-internal (common.h).  Envelope: C <= 32, D <= 192, W % 4 == 0, quad-aligned features, 32 H W < 2^30.
+template <typename TIN>
+int stereo_cross_attention_split16(const TIN *left, const TIN *right, float *out, float *disp, int B, int C, int H, int W, int D,
+                                   int mask_mode, float sc, hipStream_t st)
+{
+    // (32 H W < 2^30: the buffer resources address a 32-channel slab of a row with 32-bit BYTE offsets)
+    if (C > 32 || D > 192 || D < 1 || W % 4 != 0 || !aligned_quad<TIN>(left) || !aligned_quad<TIN>(right) ||
+        (long long)32 * H * W >= (1LL << 30))
+        return STEREO_ERR_UNSUPPORTED;
+    const int nt = (D + 31) / 32 + 1;
+    // waves (32 queries each) per workgroup: 8 (256-query tiles: the band halo is loaded and split once per tile, so wide tiles
+    // win even where they leave slots idle); rows of <= 192 / <= 128 queries take one 6- / 4-wave tile
+    const int qt = (W + 31) / 32;
+    int nwv = qt <= 4 ? 4 : (qt <= 6 ? 6 : 8);
+    const int forced = stereo_opt(OPT_ATT_WAVES);  // test hook
+    if (forced == 4 || forced == 6 || forced == 8) nwv = forced;
+#define SPL16(NTV)                                                                                            \
+    do {                                                                                                      \
+        if (nwv == 8) return launch_split16<NTV, 8, TIN>(left, right, out, disp, B, C, H, W, D, mask_mode, sc, st); \
+        if (nwv == 6) return launch_split16<NTV, 6, TIN>(left, right, out, disp, B, C, H, W, D, mask_mode, sc, st); \
+        return launch_split16<NTV, 4, TIN>(left, right, out, disp, B, C, H, W, D, mask_mode, sc, st);               \
+    } while (0)
+    if (nt <= 3) SPL16(3);
+    if (nt <= 5) SPL16(5);
+    SPL16(7);
+#undef SPL16
+}
+
+template int stereo_cross_attention_split16<float>(const float *, const float *, float *, float *, int, int, int, int, int, int,
+                                                   float, hipStream_t);
+template int stereo_cross_attention_split16<f16>(const f16 *, const f16 *, float *, float *, int, int, int, int, int, int, float,
+                                                 hipStream_t);

@@ -17,7 +17,7 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 enum StereoOpt {
     OPT_CORR_MFMA = 0,   // 1 (default): matrix-core volume kernels where their envelope allows; 0: VALU kernels
     OPT_GWC_FUSED,       // 1 (default): A3 + group mean + A4 in one launch; 0: separate launches
-    OPT_ATT_KERNEL,      // 0 (default): by shape; 2: LDS-score-sheet; 4: two-pass register; 5: fp32 online; 6: chunked; 7: split-bf16
+    OPT_ATT_KERNEL,      // 0 (default): by shape; 2: LDS-score-sheet; 4: two-pass register; 5: fp32 online; 6: chunked; 7: split-bf16; 9: split-fp16
     OPT_ATT_WAVES,       // 0 (default): by row length; 4 / 5 / 8: waves per workgroup of the persistent attention kernels
     OPT_TILES_PER_WG,    // 0 (default): sized to the resident workgroups; n > 0: tiles per persistent workgroup
     OPT_PROB_SINGLE_PASS,  // 1 (default): softmax column in registers (D <= 192); 0: two-pass kernel
@@ -156,6 +156,30 @@ __device__ __forceinline__ void split_oct(const float *x, bf16x8 *p)
 #pragma unroll
     for (int q = 0; q < NP; ++q) p[q] = cat4(cat2(t[0][q], t[1][q]), cat2(t[2][q], t[3][q]));
 }
+// Split-fp16 operands (conv_split.hip, attention_f16.hip): x = hi + 2^-11 lo', hi = fp16(x), lo' = fp16(2^11 (x - hi)): 22-23
+// significant bits for 2^-14 <= |x| < 65 504 (absolute error <= 2^-36 below, inf / NaN above -- never silently wrong).  The
+// piece products hi hi | hi lo', lo' hi go to two fp32 accumulators (each product is exact in fp32: 11 x 11 bits); result =
+// acc0 + 2^-11 acc1.  Two values at a time: v_cvt_pk_f16_f32, two widenings, v_pk_add_f32, v_pk_mul_f32, v_cvt_pk_f16_f32.
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+constexpr float SPLIT16_LO_SCALE = 2048.0f, SPLIT16_LO_UNSCALE = 1.0f / 2048.0f;
+__device__ __forceinline__ void split_pair_f16(f32x2 x, f16x2 *p)
+{
+    p[0] = __builtin_convertvector(x, f16x2);
+    const f32x2 r = (x - __builtin_convertvector(p[0], f32x2)) * SPLIT16_LO_SCALE;
+    p[1] = __builtin_convertvector(r, f16x2);
+}
+// eight fp32 values -> hi / lo' MFMA operands
+__device__ __forceinline__ void split_oct_f16(const float *x, f16x8 *p)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f16x2 t[2];
+        split_pair_f16((f32x2){x[2 * j], x[2 * j + 1]}, t);
+        p[0][2 * j] = t[0][0], p[0][2 * j + 1] = t[0][1];
+        p[1][2 * j] = t[1][0], p[1][2 * j + 1] = t[1][1];
+    }
+}
 // base pointers of quad loads: 16 B for fp32, 8 B for fp16
 template <typename T>
 static inline bool aligned_quad(const void *p) { return (reinterpret_cast<uintptr_t>(p) & (4 * sizeof(T) - 1)) == 0; }
@@ -224,6 +248,11 @@ int stereo_cross_attention_chunked(const TIN *L, const TIN *R, const TIN *V, flo
 template <typename TIN>
 int stereo_corr_volume_chunked(const TIN *L, const TIN *R, float *vol, float *disp, int B, int C, int H, int W, int D,
                                float sgn, hipStream_t st);
+// attention_f16.hip: A7 for C <= 32, value = right features, on the fp16 matrix cores with two-piece operands (hi + 2^-11 lo'),
+// three products, two accumulators: the default there.
+template <typename TIN>
+int stereo_cross_attention_split16(const TIN *left, const TIN *right, float *out, float *disp, int B, int C, int H, int W, int D,
+                                   int mask_mode, float sc, hipStream_t st);
 // attention_bf16.hip: A7 for C <= 32, value = right features, on the bf16 matrix cores with split (hi + mid + lo) operands.
 template <typename TIN>
 int stereo_cross_attention_split(const TIN *left, const TIN *right, float *out, float *disp, int B, int C, int H, int W, int D,

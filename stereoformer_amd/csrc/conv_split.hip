@@ -49,8 +49,6 @@ struct ConvDsts {          // one entry per N tile of 128 output channels
     int epi[CV_MAXNT];     // STEREO_EPI_*
 };
 
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
 // Arithmetic forms (STEREO_CONV_* of include/stereo_hip.h).  A form says how an activation / weight value becomes NP matrix-core
 // operands ("pieces"), which piece products are executed (PA[q] x PB[q]) and into which of NACC fp32 accumulators (PC[q]).
@@ -113,16 +111,7 @@ __device__ __forceinline__ void static_for(F &&f)
         static_for<I + 1, N>(f);
     }
 }
-constexpr float CV_LO_SCALE = 2048.0f, CV_LO_UNSCALE = 1.0f / 2048.0f;
-
-// x = hi + 2^-11 lo' (two fp16 pieces), two values at a time: v_cvt_pk_f16_f32, two widenings, v_pk_add_f32, v_pk_mul_f32,
-// v_cvt_pk_f16_f32
-__device__ __forceinline__ void split_pair_f16(f32x2 x, f16x2 *p)
-{
-    p[0] = __builtin_convertvector(x, f16x2);
-    const f32x2 r = (x - __builtin_convertvector(p[0], f32x2)) * CV_LO_SCALE;
-    p[1] = __builtin_convertvector(r, f16x2);
-}
+constexpr float CV_LO_UNSCALE = SPLIT16_LO_UNSCALE;
 
 // eight fp32 values -> the form's NP operands
 template <int AR>
@@ -134,13 +123,7 @@ __device__ __forceinline__ void conv_split_oct(const float *x, typename ConvAr<A
 #pragma unroll
         for (int j = 0; j < 8; ++j) p[0][j] = (_Float16)x[j];
     } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f16x2 t[2];
-            split_pair_f16((f32x2){x[2 * j], x[2 * j + 1]}, t);
-            p[0][2 * j] = t[0][0], p[0][2 * j + 1] = t[0][1];
-            p[1][2 * j] = t[1][0], p[1][2 * j + 1] = t[1][1];
-        }
+        split_oct_f16(x, p);
     }
 }
 

@@ -60,7 +60,6 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict_
 
 // fp16 in / fp16 out variants for the update block under the reference's mixed_precision flag (fp16 convolutions):
 // the gate math itself stays fp32 in registers; 8 halves (16 B) per lane.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 template <int V>
 __global__ __launch_bounds__(256) void gru_reset_f16_kernel(const _Float16 *__restrict__ h, const _Float16 *__restrict__ rc,

@@ -415,11 +415,12 @@ def test_resize_vs_oracle(S, oracle, golden):
 @pytest.mark.parametrize("cfg", [(2, 16, 5, 40, 12), (1, 32, 3, 200, 192), (1, 48, 2, 70, 33), (1, 40, 2, 300, 230),
                                  (1, 256, 2, 312, 64), (1, 8, 1, 64, 1), (1, 32, 1, 130, 320), (1, 20, 1, 96, 32),
                                  (2, 32, 3, 960, 192), (1, 24, 2, 516, 250)])
-@pytest.mark.parametrize("variant", ["auto", "v4", "v2", "v5"])
+@pytest.mark.parametrize("variant", ["auto", "v4", "v2", "v5", "v7"])
 def test_cross_attention(S, oracle, cfg, variant):
     # v2: per-tile MFMA kernel with an LDS score sheet (unaligned / ragged shapes, 256 < D <= 320)
-    # auto: v7 (split-bf16 matrix cores) for C <= 32 with value = right features, else v4; v5: the fp32 online-softmax kernel
-    with S._native.test_options(att_kernel={"auto": 0, "v4": 4, "v2": 2, "v5": 5}[variant]):
+    # auto: v9 (split-fp16 matrix cores) for C <= 32 with value = right features, else v4; v5: the fp32 online-softmax kernel;
+    # v7: the split-bf16 form v9 replaced as the default
+    with S._native.test_options(att_kernel={"auto": 0, "v4": 4, "v2": 2, "v5": 5, "v7": 7}[variant]):
         _cross_attention(S, oracle, cfg)
 
 
