@@ -125,6 +125,14 @@ int stereo_bounds_lookup_f32(const float *vol, const float *disp, const float *b
 int stereo_uncertainty_volume_f32(const float *vol, const float *disp, float *out,
                                   int B, int D, int H, int W, void *stream);
 
+/* A11 the inputs of BasicGuidanceNet's two encoders (.../Attempts/update.py:75-90) in one pass, CHANNELS-LAST and zero-padded
+ * to the channel counts stereo_conv_nhwc_* takes: err [B][H][W][err_channels] = disp_warp(right, disp) - left (border padding,
+ * utils/disparity_warper.py:83-106) in its first Ci channels, unc [B][H][W][unc_channels] = softmax_d(vol)*d*(d-disp)^2 in
+ * its first D channels, 0 elsewhere.  left / right [B,Ci,H,W] (already at the disparity's resolution), vol [B,D,H,W]. */
+int stereo_guidance_inputs_nhwc_f32(const float *vol, const float *disp, const float *left, const float *right, float *err,
+                                    float *unc, int B, int D, int Ci, int H, int W, int err_channels, int unc_channels,
+                                    void *stream);
+
 /* A8  CorrBlock1D.__init__ + .corr  models/IterativeLocalCostVolume/corr/corr.py:55-76,103-111
  *     fmap1 [B,C,H,W1], fmap2 [B,C,H,W2] -> levels[i] [B*H*W1, W2>>i], i = 0..num_levels
  *     (levels = HOST array of num_levels+1 device pointers; the reference builds
@@ -136,6 +144,11 @@ int stereo_allpairs_pyramid_f32(const float *fmap1, const float *fmap2, float *c
  *     coords [B,2,H,W1] (x = channel 0) -> out [B, num_levels*(2r+1), H, W1] */
 int stereo_corr_lookup_f32(const float *const *levels, const float *coords, float *out,
                            int B, int H, int W1, int W2, int num_levels, int radius, void *stream);
+
+/* The same, written CHANNELS-LAST for the motion encoder's first convolution (update/update.py:77,85): out [B][H][W1][out_channels],
+ * out_channels >= num_levels*(2r+1) (a multiple of 16 for stereo_conv_nhwc_*), the padding channels zeroed. */
+int stereo_corr_lookup_nhwc_f32(const float *const *levels, const float *coords, float *out,
+                                int B, int H, int W1, int W2, int num_levels, int radius, int out_channels, void *stream);
 
 /* A10 PytorchAlternateCorrBlock1D.__call__  corr.py:8-51 (no all-pairs volume).
  *     workspace: (B*C*H*(W/2 + W/4 + ...)) floats for the pooled fmap2 copies */
@@ -318,7 +331,7 @@ int stereo_relayout_nhwc_to_nchw(const void *x, int x_is_f16, void *out, int out
  *       (stereo_conv_packed_bytes(Cout, Cin, k) bytes, 16-byte aligned), once per weight tensor.  Cin % 16 == 0.
  *   stereo_conv_nhwc_f32: the K dimension runs over `nsrc` (<= 4) source tensors [B][H][W][src_channels[i]] in concatenation
  *       order (= conv(torch.cat(srcs, 1)) without the concatenation; every src_channels[i] % 16 == 0); output channels go, in
- *       order, to `nout` destination tensors [B][H][W][out_channels[j]] (every out_channels[j] but the last a multiple of 128;
+ *       order, to `nout` destination tensors [B][H][W][out_channels[j]] (every out_channels[j] but the last a multiple of 32;
  *       at most 512 output channels in all): out = conv + bias (bias [sum out_channels] or NULL), ReLU if `relu`.
  *       out_strides[j] (NULL: = out_channels[j]) is the channel count of destination j's pixels when the convolution fills
  *       only its first out_channels[j] channels (the motion encoder's 126 + 2 layout, update.py:89-91).
@@ -395,6 +408,17 @@ int stereo_conv3x3_small_nhwc_f32(const float *x, const float *weight_tco, const
  * caller rounds the weights to fp16 first if it wants the library's autocast numerics). */
 int stereo_conv3x3_small_nhwc_f16(const void *x, const float *weight_tco, const float *bias, float *out_nchw, int B, int Cin,
                                   int Cout, int H, int W, void *stream);
+
+/* KxK stride-1 "same" convolution with 1..4 INPUT channels (the motion encoder's convf1, update/update.py:79,87: 7x7 over the
+ * 2-channel flow) on the fp32 vector units: x [B,Cin,H,W] NCHW fp32, weight_tco = weight.permute(2, 3, 1, 0) contiguous
+ * ([K][K][Cin][Cout], Cout % 16 == 0, Cout <= 64), bias [Cout] or NULL, ReLU if `relu`; out [B][H][W][out_stride] channels-last
+ * (its first Cout channels are written).  K odd, K <= 7. */
+int stereo_conv_small_cin_nhwc_f32(const float *x, const float *weight_tco, const float *bias, float *out, int B, int Cin, int Cout,
+                                   int H, int W, int ksize, int out_stride, int relu, void *stream);
+
+/* The two entries above in one, with an optional ReLU on the output (OffsetPredictionHead's relu2, Attempts/update.py:103-105). */
+int stereo_conv3x3_small_nhwc_ex(const void *x, int x_is_f16, const float *weight_tco, const float *bias, float *out_nchw, int B,
+                                 int Cin, int Cout, int H, int W, int relu, void *stream);
 
 #ifdef __cplusplus
 }

@@ -43,6 +43,8 @@ SIGNATURES = {
     "stereo_uncertainty_volume_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "stereo_allpairs_pyramid_f32": [_vp, _vp, ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _i, _vp],
     "stereo_corr_lookup_f32": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_corr_lookup_nhwc_f32": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_conv_small_cin_nhwc_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_alt_corr_lookup_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_alt_corr_workspace_floats": [_i, _i, _i, _i, _i],
     "stereo_bilinear_sampler_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -64,6 +66,7 @@ SIGNATURES = {
     "stereo_relayout_nhwc_to_nchw": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_conv3x3_small_nhwc_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_conv3x3_small_nhwc_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "stereo_conv3x3_small_nhwc_ex": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_conv_packed_bytes": [_i, _i, _i],
     "stereo_conv_packed_bytes_f16": [_i, _i, _i],
     "stereo_conv_packed_bytes_bf16x3": [_i, _i, _i],
@@ -81,6 +84,7 @@ SIGNATURES = {
     "stereo_conv_nhwc_ex": [_i, ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_i),
                             ctypes.POINTER(_i), _i, ctypes.POINTER(_i), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                             ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _vp],
+    "stereo_guidance_inputs_nhwc_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_fingerprint": [ctypes.POINTER(_vp), ctypes.POINTER(_ll), _i, _vp, _vp],
     "stereo_soft_argmin_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_gwc_volume_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

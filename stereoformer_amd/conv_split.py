@@ -69,10 +69,11 @@ def _is_cl(t):
     return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
 
 
-def supported(srcs, convs) -> bool:
+def supported(srcs, convs, pad_in=False) -> bool:
     """Channels-last fp32 (or all-fp16: the mixed_precision form) HIP tensors without grad, every source channel count a multiple of 16 (<= 4 sources), 3x3 / 1x1 stride-1
-    'same' convolutions without groups or dilation, all but the last module with a multiple of 128 output channels, <= 512 in
-    all."""
+    'same' convolutions without groups or dilation, all but the last module with a multiple of 32 output channels, <= 640 in
+    all.  ``pad_in``: the modules may take FEWER input channels than the sources carry (a source zero-padded to a multiple of 16:
+    the missing weight columns are packed as zeros)."""
     if not (1 <= len(srcs) <= 4) or not convs:
         return False
     if torch.is_grad_enabled() and (any(t.requires_grad for t in srcs) or
@@ -96,12 +97,13 @@ def supported(srcs, convs) -> bool:
             return False
         if m.stride != (1, 1) or m.dilation != (1, 1) or m.groups != 1 or m.padding != (k[0] // 2, k[0] // 2):
             return False
-        if m.in_channels != cin or m.weight.dtype != torch.float32 or m.padding_mode != "zeros":
+        if (m.in_channels > cin or (m.in_channels != cin and not pad_in) or m.weight.dtype != torch.float32
+                or m.padding_mode != "zeros"):
             return False
-        if i + 1 < len(convs) and m.out_channels % 128 != 0:
+        if i + 1 < len(convs) and m.out_channels % 32 != 0:
             return False
         total += m.out_channels
-    return total <= 512
+    return total <= 640
 
 
 # ---------------------------------------------------------------------------------------------- packed-weight cache
@@ -112,17 +114,20 @@ def _version(p):
         return -1
 
 
-def _params(convs):
-    return [p for m in convs for p in (m.weight, m.bias) if p is not None]
+def _params(mods):
+    """The tensors a packed copy depends on: a convolution's weight / bias, a folded BatchNorm's affine parameters and running
+    statistics."""
+    out = []
+    for m in mods:
+        names = ("weight", "bias", "running_mean", "running_var") if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) \
+            else ("weight", "bias")
+        out += [getattr(m, n) for n in names if getattr(m, n, None) is not None]
+    return out
 
 
-def _signature(convs, device):
+def _signature(mods, device):
     """What the host can see of the parameters a packed copy depends on."""
-    sig = [device.index]
-    for m in convs:
-        for p in (m.weight, m.bias):
-            sig.append(None if p is None else (id(p), p.data_ptr(), _version(p), tuple(p.shape)))
-    return tuple(sig)
+    return (device.index,) + tuple((id(p), p.data_ptr(), _version(p), tuple(p.shape)) for p in _params(mods))
 
 
 def fingerprints(tensors):
@@ -200,30 +205,60 @@ def refresh(root):
     return dropped
 
 
-def _packed(convs, device, form):
+def _fold_bn(w, b, bn):
+    """Inference-mode BatchNorm2d behind a convolution, folded into its weights: bn(conv(x)) = conv'(x) with
+    w' = w * g / sqrt(var + eps), b' = (b - mean) * g / sqrt(var + eps) + beta (fp64 arithmetic, rounded once)."""
+    if bn.training or not bn.track_running_stats or bn.running_var is None:
+        raise ValueError("conv_nhwc: only an eval-mode BatchNorm with running statistics can be folded into a convolution")
+    s = torch.rsqrt(bn.running_var.detach().double() + bn.eps)
+    if bn.weight is not None:
+        s = s * bn.weight.detach().double()
+    b0 = torch.zeros_like(s) if b is None else b.double()
+    nb = (b0 - bn.running_mean.detach().double()) * s
+    if bn.bias is not None:
+        nb = nb + bn.bias.detach().double()
+    return (w.double() * s.view(-1, 1, 1, 1)).float(), nb.float()
+
+
+def _packed(convs, device, form, bns=None, cin=None, scales=None):
     """Packed weights of a group of modules in the operand form ``form`` (+ the concatenated fp32 bias); rebuilt when a parameter
-    is replaced or updated in place."""
+    is replaced or updated in place.  ``bns``: per module an eval-mode BatchNorm2d folded into it (or None); ``cin``: input
+    channels of the launch (>= the modules': the missing weight columns are zeros)."""
     arith = ARITH[form]
+    bns = [None] * len(convs) if bns is None else list(bns)
+    scales = [1.0] * len(convs) if scales is None else [float(x) for x in scales]
 
     def build():
         with torch.no_grad():
-            w = torch.cat([m.weight.detach().contiguous() for m in convs], 0).contiguous()
+            ws, bs = [], []
+            for m, bn, sc in zip(convs, bns, scales):
+                w, b = m.weight.detach().contiguous(), None if m.bias is None else m.bias.detach()
+                if bn is not None:
+                    w, b = _fold_bn(w, b, bn)
+                if sc != 1.0:    # (a constant factor on the module's output, e.g. the 0.25 of the mask head: folded, not launched)
+                    w, b = w * sc, None if b is None else b * sc
+                if cin is not None and w.shape[1] < cin:
+                    w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cin - w.shape[1]))
+                ws.append(w)
+                bs.append(b)
+            w = torch.cat(ws, 0).contiguous()
             bias = None
-            if any(m.bias is not None for m in convs):
-                bias = torch.cat([m.bias.detach() if m.bias is not None else torch.zeros(m.out_channels, device=device)
-                                  for m in convs]).contiguous()
-            cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
-            nbytes = N.load().stereo_conv_packed_bytes_ex(arith, cout, cin, k)
+            if any(b is not None for b in bs):
+                bias = torch.cat([b if b is not None else torch.zeros(m.out_channels, device=device)
+                                  for b, m in zip(bs, convs)]).contiguous()
+            cout, cin_, k = w.shape[0], w.shape[1], w.shape[2]
+            nbytes = N.load().stereo_conv_packed_bytes_ex(arith, cout, cin_, k)
             if nbytes <= 0:
                 raise ValueError(f"conv_nhwc: unsupported weight shape {tuple(w.shape)}")
             packed = torch.empty(nbytes, device=device, dtype=torch.uint8)
             with torch.cuda.device(device):
-                N.call("stereo_conv_pack_weights_ex", arith, N.ptr(w), N.ptr(packed), cout, cin, k, N.stream_ptr(device))
+                N.call("stereo_conv_pack_weights_ex", arith, N.ptr(w), N.ptr(packed), cout, cin_, k, N.stream_ptr(device))
         return packed, bias, k
-    return _cached(convs, "split_" + form, device, build)
+    return _cached(list(convs) + [bn for bn in bns if bn is not None], f"split_{form}_{cin}_{len(convs)}_{tuple(scales)}", device, build)
 
 
-def conv_nhwc(srcs, convs, relu=False, out_channels_total=None, epilogue=None, precision=None):
+def conv_nhwc(srcs, convs, relu=False, out_channels_total=None, epilogue=None, precision=None, bns=None, pad_in=False,
+              scales=None):
     """``[m(torch.cat(srcs, 1)) for m in convs]`` (optionally followed by ReLU), channels-last fp32 (or fp16: what the modules give
     under fp16 autocast) in and out, one launch.
     ``out_channels_total`` (single module only): allocate the output with that many channels and fill the first
@@ -231,17 +266,25 @@ def conv_nhwc(srcs, convs, relu=False, out_channels_total=None, epilogue=None, p
     ``epilogue``: one entry per module, ``None`` (linear) or a tuple -- with ``t = m(cat(srcs)) + c`` (``c`` may be ``None``):
     ``("sigmoid", c)`` -> ``sigmoid(t)``; ``("sigmoid_mul", c, h)`` -> ``sigmoid(t) * h``; ``("gru_blend", c, h, z)`` ->
     ``(1 - z) * h + z * tanh(t)`` (``"gru_blend_softsign"``: ``t / (1 + |t|)`` for the tanh); ``("linear", c)`` -> ``t``.  The operand tensors have the output's shape, layout and dtype.
-    ``precision``: see the module docstring (default: the calling thread's ``set_precision`` value)."""
+    ``precision``: see the module docstring (default: the calling thread's ``set_precision`` value).
+    ``bns``: one eval-mode ``BatchNorm2d`` (or ``None``) per module, folded into the module's packed weights:
+    ``bn(m(x))`` for the price of ``m(x)``.  ``pad_in``: the sources carry more channels than the modules take (a source
+    zero-padded to a multiple of 16 channels); the extra channels meet zero weights.  ``scales``: a constant factor per module
+    on its output (``0.25 * mask(x)``, update.py:176), folded into the packed weights and bias."""
     srcs = list(srcs)
     convs = list(convs)
-    if not supported(srcs, convs):
+    if bns is not None and (len(bns) != len(convs) or any(b is not None and b.num_features != m.out_channels for b, m in zip(bns, convs))):
+        raise ValueError("conv_nhwc: one BatchNorm2d (or None) per module, over the module's output channels")
+    if not supported(srcs, convs, pad_in=pad_in):
         raise ValueError("conv_nhwc: operands outside the kernel's envelope (see conv_split.supported)")
     if out_channels_total is not None and (len(convs) != 1 or out_channels_total < convs[0].out_channels):
         raise ValueError("conv_nhwc: out_channels_total applies to one module and must cover its output channels")
     dev = srcs[0].device
     half = srcs[0].dtype == torch.float16
     form = "f16" if half else _form(get_precision() if precision is None else precision)
-    packed, bias, k = _packed(convs, dev, form)
+    if scales is not None and len(scales) != len(convs):
+        raise ValueError("conv_nhwc: one scale per module")
+    packed, bias, k = _packed(convs, dev, form, bns, sum(t.shape[1] for t in srcs) if pad_in else None, scales)
     B, _, H, W = srcs[0].shape
     widths = [m.out_channels for m in convs] if out_channels_total is None else [int(out_channels_total)]
     outs = [torch.empty((B, c, H, W), device=dev, dtype=srcs[0].dtype, memory_format=torch.channels_last) for c in widths]
@@ -292,9 +335,9 @@ def small_supported(x, conv) -> bool:
             and x.shape[1] == conv.in_channels and x.shape[1] % 32 == 0 and x.shape[1] * x.shape[2] * x.shape[3] * 4 < 2 ** 31)
 
 
-def conv3x3_small(x, conv):
-    """``conv(x)`` for a 3x3 convolution with <= 4 output channels (``flow_head.conv2``): channels-last fp32 / fp16 in,
-    NCHW-contiguous fp32 out."""
+def conv3x3_small(x, conv, relu=False):
+    """``conv(x)`` (``relu(conv(x))``) for a 3x3 convolution with <= 4 output channels (``flow_head.conv2``, the offset head's
+    ``conv2``): channels-last fp32 / fp16 in, NCHW-contiguous fp32 out."""
     if not small_supported(x, conv):
         raise ValueError("conv3x3_small: operands outside the kernel's envelope (see conv_split.small_supported)")
     half = x.dtype == torch.float16   # mixed_precision: the weights rounded to fp16 as autocast hands them to the library
@@ -303,7 +346,35 @@ def conv3x3_small(x, conv):
     B, C, H, W = x.shape
     out = torch.empty((B, conv.out_channels, H, W), device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
-        N.call("stereo_conv3x3_small_nhwc_f32" if not half else "stereo_conv3x3_small_nhwc_f16", N.ptr(x), N.ptr(wt),
+        N.call("stereo_conv3x3_small_nhwc_ex", N.ptr(x), 1 if half else 0, N.ptr(wt),
                N.ptr(None if conv.bias is None else conv.bias.detach()),
-               N.ptr(out), B, C, conv.out_channels, H, W, N.stream_ptr(x.device))
+               N.ptr(out), B, C, conv.out_channels, H, W, 1 if relu else 0, N.stream_ptr(x.device))
+    return out
+
+
+def small_cin_supported(x, conv) -> bool:
+    """KxK (3 / 5 / 7) stride-1 'same' convolution over <= 4 input channels of an NCHW fp32 HIP tensor, 16 / 32 / 48 / 64 output
+    channels."""
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in conv.parameters())):
+        return False
+    k = conv.kernel_size[0] if isinstance(conv, torch.nn.Conv2d) else 0
+    return (isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (k, k) and k in (3, 5, 7) and conv.stride == (1, 1)
+            and conv.padding == (k // 2, k // 2) and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"
+            and conv.in_channels <= 4 and conv.out_channels % 16 == 0 and conv.out_channels <= 64
+            and conv.weight.dtype == torch.float32 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and x.shape[1] == conv.in_channels and x.is_contiguous())
+
+
+def conv_small_cin(x, conv, relu=False):
+    """``conv(x)`` (``relu(conv(x))``) for a KxK convolution over a handful of input channels (``convf1``: 7x7 over the 2-channel
+    flow, update.py:79,87) on the fp32 vector units: NCHW fp32 in, channels-last fp32 out."""
+    if not small_cin_supported(x, conv):
+        raise ValueError("conv_small_cin: operands outside the kernel's envelope (see conv_split.small_cin_supported)")
+    wt = _cached([conv], "tco_small_cin", x.device, lambda: conv.weight.detach().permute(2, 3, 1, 0).contiguous())
+    B, C, H, W = x.shape
+    out = torch.empty((B, conv.out_channels, H, W), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        N.call("stereo_conv_small_cin_nhwc_f32", N.ptr(x), N.ptr(wt), N.ptr(None if conv.bias is None else conv.bias.detach()),
+               N.ptr(out), B, C, conv.out_channels, H, W, conv.kernel_size[0], conv.out_channels, 1 if relu else 0,
+               N.stream_ptr(x.device))
     return out

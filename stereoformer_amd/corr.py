@@ -115,7 +115,10 @@ class CorrBlock1D:
         N.same_device(fmap1, fmap2)
         self.corr_pyramid = _pyramid_forward(fmap1, fmap2, num_levels)
 
-    def __call__(self, coords):
+    def __call__(self, coords, nhwc_channels=None):
+        """``nhwc_channels`` (inference; not in the reference): return the ``num_levels * (2 r + 1)`` correlation features as a
+        ``torch.channels_last`` tensor zero-padded to that many channels (a multiple of 16) -- the layout the motion encoder's
+        first convolution takes on the HIP path -- instead of NCHW."""
         B, H, W1, W2 = self._shape
         coords = N.dev_f32(coords.detach(), "CorrBlock1D: coords")  # no gradient flows to coords (raft_stereo.py:171)
         if coords.dim() != 4 or coords.shape[0] != B or coords.shape[1] < 1 or tuple(coords.shape[2:]) != (H, W1):
@@ -126,6 +129,15 @@ class CorrBlock1D:
             return _CorrLookupFn.apply(coords, self._shape, self.radius, self.num_levels,
                                        *self.corr_pyramid[:self.num_levels])
         T = 2 * self.radius + 1
+        if nhwc_channels is not None:
+            if nhwc_channels < self.num_levels * T:
+                raise ValueError("CorrBlock1D: nhwc_channels must cover num_levels * (2 * radius + 1)")
+            out = torch.empty((B, int(nhwc_channels), H, W1), device=coords.device, dtype=torch.float32,
+                              memory_format=torch.channels_last)
+            with torch.cuda.device(coords.device):
+                N.call("stereo_corr_lookup_nhwc_f32", _level_array(self.corr_pyramid[:self.num_levels]), N.ptr(coords),
+                       N.ptr(out), B, H, W1, W2, self.num_levels, self.radius, int(nhwc_channels), N.stream_ptr(coords.device))
+            return out
         out = torch.empty((B, self.num_levels * T, H, W1), device=coords.device, dtype=torch.float32)
         with torch.cuda.device(coords.device):
             N.call("stereo_corr_lookup_f32", _level_array(self.corr_pyramid[:self.num_levels]), N.ptr(coords),

@@ -211,6 +211,18 @@ __device__ __forceinline__ float ste_ceil_f(float x) { return (ceilf(x) - x) + x
 __device__ __forceinline__ float ste_floor_f(float x) { return (floorf(x) - x) + x; }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+// Sampling position of disp_warp (utils/disparity_warper.py:83-106: grid (x - disp, y) normalised with (w-1), (h-1) -- :55-56 --,
+// then grid_sample's un-normalisation with align_corners=False -- :100), in the reference's own order of fp32 operations.
+__device__ __forceinline__ void disp_warp_coords(int x, int y, float d, int W, int H, float &ux, float &uy)
+{
+    const float gx = (float)x + (-d);
+    const float gy = (float)y + 0.0f;
+    const float nx = __fsub_rn(__fmul_rn(2.0f, __fdiv_rn(gx, (float)(W - 1))), 1.0f);
+    const float ny = __fsub_rn(__fmul_rn(2.0f, __fdiv_rn(gy, (float)(H - 1))), 1.0f);
+    ux = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(nx, 1.0f), (float)W), 1.0f), 2.0f);
+    uy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(ny, 1.0f), (float)H), 1.0f), 2.0f);
+}
+
 // One interpolated tap of build_cost_volume_from_volume
 // (fixed_local_cost_volume.py:61-80).  v -> vol[b,0,h,w], stride = H*W.
 __device__ __forceinline__ float sample_tap(const float *__restrict__ v, size_t stride, int D, float c)

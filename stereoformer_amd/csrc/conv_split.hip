@@ -31,24 +31,23 @@ namespace {
 
 constexpr int CV_TW = 32;               // output pixel tile: TH (8 or 4) rows x 32 columns
 constexpr int CV_PXB = 48;             // LDS bytes per pixel and piece: 16 channels x 2 B + 16 B pad (conflict-free b128 reads)
-constexpr int CV_MAXSRC = 4, CV_MAXNT = 4;
+constexpr int CV_MAXSRC = 4, CV_MAXNT = 5, CV_MAXNB = 4 * CV_MAXNT;   // <= 640 output channels per launch
 
 struct ConvSrcs {
     const void *p[CV_MAXSRC];
     int c[CV_MAXSRC];
     int n;
 };
-struct ConvDsts {          // one entry per N tile of 128 output channels
-    void *p[CV_MAXNT];
-    const void *add[CV_MAXNT];   // per-element addend (a ConvGRU context tensor) or null; geometry of the destination
-    const void *aux0[CV_MAXNT];  // epilogue operands (hidden state / update gate), geometry of the destination
-    const void *aux1[CV_MAXNT];
-    int stride[CV_MAXNT];  // channels of the destination tensor (pixel stride)
-    int coff[CV_MAXNT];    // first channel of this tile inside it
-    int nvalid[CV_MAXNT];  // output channels of this tile that exist (<= 128)
-    int epi[CV_MAXNT];     // STEREO_EPI_*
+struct ConvDsts {          // one entry per N BLOCK of 32 output channels (a wave's MFMA column block)
+    void *p[CV_MAXNB];
+    const void *add[CV_MAXNB];   // per-element addend (a ConvGRU context tensor) or null; geometry of the destination
+    const void *aux0[CV_MAXNB];  // epilogue operands (hidden state / update gate), geometry of the destination
+    const void *aux1[CV_MAXNB];
+    int stride[CV_MAXNB];  // channels of the destination tensor (pixel stride)
+    int coff[CV_MAXNB];    // first channel of this block inside it
+    int nvalid[CV_MAXNB];  // output channels of this block that exist (<= 32; 0: none)
+    int epi[CV_MAXNB];     // STEREO_EPI_*
 };
-
 
 // Arithmetic forms (STEREO_CONV_* of include/stereo_hip.h).  A form says how an activation / weight value becomes NP matrix-core
 // operands ("pieces"), which piece products are executed (PA[q] x PB[q]) and into which of NACC fp32 accumulators (PC[q]).
@@ -429,68 +428,68 @@ __global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kern
     // (row + (r >> 3), 16 ch + (r & 3) + 8 ((r >> 2) & 1) + 4 half), output channel 32 (NBW wn + nb) + l31: a 128-B row per
     // access.  STEREO_EPI_*: bias (+ per-element addend), then ReLU / the ConvGRU gate math (update.py:28-32) in place of the
     // separate pointwise launches: sigmoid -> z; sigmoid x h -> r h (convq's first source); tanh and the (1 - z) h + z q blend.
-    const int ostride = dst.stride[nt], coff = dst.coff[nt], nvalid = dst.nvalid[nt];
-    const size_t obase = (size_t)b * H * W * ostride;      // this batch image inside the destination-shaped tensors
-    TIN *ob = static_cast<TIN *>(dst.p[nt]) + obase;
-    const TIN *addp = dst.add[nt] ? static_cast<const TIN *>(dst.add[nt]) + obase : nullptr;
-    const TIN *a0p = dst.aux0[nt] ? static_cast<const TIN *>(dst.aux0[nt]) + obase : nullptr;
-    const TIN *a1p = dst.aux1[nt] ? static_cast<const TIN *>(dst.aux1[nt]) + obase : nullptr;
-    auto epilogue = [&](auto epi_tag) {
-        constexpr int EPI = decltype(epi_tag)::value;
+    // Destinations are per N block: several modules can share one 128-channel tile (convz | convb of a 64-channel GRU).
+    auto epilogue = [&](auto epi_tag, auto nb_tag) {
+        constexpr int EPI = decltype(epi_tag)::value, nb = decltype(nb_tag)::value;
+        const int gb = 4 * nt + NBW * wn + nb;             // this wave's N block among the launch's
+        const int ostride = dst.stride[gb], coff = dst.coff[gb], nvalid = dst.nvalid[gb];
+        const size_t obase = (size_t)b * H * W * ostride;  // this batch image inside the destination-shaped tensors
+        TIN *ob = static_cast<TIN *>(dst.p[gb]) + obase;
+        const TIN *addp = dst.add[gb] ? static_cast<const TIN *>(dst.add[gb]) + obase : nullptr;
+        const TIN *a0p = dst.aux0[gb] ? static_cast<const TIN *>(dst.aux0[gb]) + obase : nullptr;
+        const TIN *a1p = dst.aux1[gb] ? static_cast<const TIN *>(dst.aux1[gb]) + obase : nullptr;
+        const int cg = 32 * gb + l31;
+        const float bv = (bias != nullptr && cg < Cout) ? bias[cg] : 0.0f;
+        if (l31 < nvalid) {
 #pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) {
-            const int cl = 32 * (NBW * wn + nb) + l31;
-            const int cg = 128 * nt + cl;
-            const float bv = (bias != nullptr && cg < Cout) ? bias[cg] : 0.0f;
-            if (cl < nvalid) {
+            for (int mb = 0; mb < 4; ++mb) {
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
+                for (int rh = 0; rh < 16; rh += 8) {   // (one row of the block: 8 registers)
+                    // the operand rows of 8 outputs are requested together, then the math, then the stores
+                    int o[8];                          // element offsets inside this batch image (< 2^31: launcher)
+                    bool in[8];
+                    float ad[8], u0[8], u1[8];
 #pragma unroll
-                    for (int rh = 0; rh < 16; rh += 8) {   // (one row of the block: 8 registers)
-                        // the operand rows of 8 outputs are requested together, then the math, then the stores
-                        int o[8];                          // element offsets inside this batch image (< 2^31: launcher)
-                        bool in[8];
-                        float ad[8], u0[8], u1[8];
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = rh + j;
+                        const int y = y0 + 4 * wm + 2 * (mb >> 1) + (r >> 3);
+                        const int x = x0 + 16 * (mb & 1) + (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
+                        in[j] = y < H && x < W;
+                        o[j] = (y * W + x) * ostride + coff + l31;
+                        ad[j] = (in[j] && addp != nullptr) ? (float)addp[o[j]] : 0.0f;
+                        if constexpr (EPI >= STEREO_EPI_SIGMOID_MUL) u0[j] = in[j] ? (float)a0p[o[j]] : 0.0f;
+                        if constexpr (EPI >= STEREO_EPI_GRU_BLEND) u1[j] = in[j] ? (float)a1p[o[j]] : 0.0f;
+                    }
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int r = rh + j;
-                            const int y = y0 + 4 * wm + 2 * (mb >> 1) + (r >> 3);
-                            const int x = x0 + 16 * (mb & 1) + (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
-                            in[j] = y < H && x < W;
-                            o[j] = (y * W + x) * ostride + coff + cl;
-                            ad[j] = (in[j] && addp != nullptr) ? (float)addp[o[j]] : 0.0f;
-                            if constexpr (EPI >= STEREO_EPI_SIGMOID_MUL) u0[j] = in[j] ? (float)a0p[o[j]] : 0.0f;
-                            if constexpr (EPI >= STEREO_EPI_GRU_BLEND) u1[j] = in[j] ? (float)a1p[o[j]] : 0.0f;
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = rh + j;
+                        float v = acc[mb][nb][0][r];
+                        if constexpr (NACC == 2) v = fmaf(acc[mb][nb][1][r], CV_LO_UNSCALE, v);
+                        v = (v + bv) + ad[j];
+                        if constexpr (EPI == STEREO_EPI_LINEAR) {
+                            if (relu) v = fmaxf(v, 0.0f);
+                        } else if constexpr (EPI == STEREO_EPI_SIGMOID) {
+                            v = gate_sigmoid(v);
+                        } else if constexpr (EPI == STEREO_EPI_SIGMOID_MUL) {
+                            v = gate_sigmoid(v) * u0[j];
+                        } else {
+                            const float q = EPI == STEREO_EPI_GRU_BLEND_SOFTSIGN ? gate_softsign(v) : gate_tanh(v);
+                            v = gate_blend(u1[j], u0[j], q);
                         }
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int r = rh + j;
-                            float v = acc[mb][nb][0][r];
-                            if constexpr (NACC == 2) v = fmaf(acc[mb][nb][1][r], CV_LO_UNSCALE, v);
-                            v = (v + bv) + ad[j];
-                            if constexpr (EPI == STEREO_EPI_LINEAR) {
-                                if (relu) v = fmaxf(v, 0.0f);
-                            } else if constexpr (EPI == STEREO_EPI_SIGMOID) {
-                                v = gate_sigmoid(v);
-                            } else if constexpr (EPI == STEREO_EPI_SIGMOID_MUL) {
-                                v = gate_sigmoid(v) * u0[j];
-                            } else {
-                                const float q = EPI == STEREO_EPI_GRU_BLEND_SOFTSIGN ? gate_softsign(v) : gate_tanh(v);
-                                v = gate_blend(u1[j], u0[j], q);
-                            }
-                            if (in[j]) ob[o[j]] = (TIN)v;
-                        }
+                        if (in[j]) ob[o[j]] = (TIN)v;
                     }
                 }
             }
         }
     };
-    const int epi = dst.epi[nt];
-    if (epi == STEREO_EPI_LINEAR) epilogue(std::integral_constant<int, STEREO_EPI_LINEAR>{});
-    else if (epi == STEREO_EPI_SIGMOID) epilogue(std::integral_constant<int, STEREO_EPI_SIGMOID>{});
-    else if (epi == STEREO_EPI_SIGMOID_MUL) epilogue(std::integral_constant<int, STEREO_EPI_SIGMOID_MUL>{});
-    else if (epi == STEREO_EPI_GRU_BLEND) epilogue(std::integral_constant<int, STEREO_EPI_GRU_BLEND>{});
-    else epilogue(std::integral_constant<int, STEREO_EPI_GRU_BLEND_SOFTSIGN>{});
+    static_for<0, NBW>([&](auto nbc) {
+        const int epi = dst.epi[4 * nt + NBW * wn + decltype(nbc)::value];
+        if (epi == STEREO_EPI_LINEAR) epilogue(std::integral_constant<int, STEREO_EPI_LINEAR>{}, nbc);
+        else if (epi == STEREO_EPI_SIGMOID) epilogue(std::integral_constant<int, STEREO_EPI_SIGMOID>{}, nbc);
+        else if (epi == STEREO_EPI_SIGMOID_MUL) epilogue(std::integral_constant<int, STEREO_EPI_SIGMOID_MUL>{}, nbc);
+        else if (epi == STEREO_EPI_GRU_BLEND) epilogue(std::integral_constant<int, STEREO_EPI_GRU_BLEND>{}, nbc);
+        else epilogue(std::integral_constant<int, STEREO_EPI_GRU_BLEND_SOFTSIGN>{}, nbc);
+    });
 }
 
 // ---- 3x3 convolutions with a handful of output channels (flow_head.conv2: 256 -> 2, update.py:11-14): a 32-channel MFMA N
@@ -501,7 +500,7 @@ __global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kern
 template <int COUT, typename TIN>
 __global__ __launch_bounds__(256) void conv3x3_small_kernel(const TIN *__restrict__ x, const float *__restrict__ wt,
                                                             const float *__restrict__ bias, float *__restrict__ out, int Cin,
-                                                            int H, int W, int tiles_x, int tiles_y)
+                                                            int H, int W, int tiles_x, int tiles_y, int relu)
 {
     constexpr int HC = 34, HR = 10, NPX = HC * HR, PXS = 36;   // halo tile, floats per pixel in LDS
     constexpr int ES = (int)sizeof(TIN), QCH = 16 / ES, QPP = 32 / QCH;   // channels per 16-B quad, quads per pixel and chunk
@@ -567,16 +566,93 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const TIN *__restric
     const int y = y0 + row, xo = x0 + col;
     if (y < H && xo < W) {
 #pragma unroll
-        for (int o = 0; o < COUT; ++o) out[(((size_t)b * COUT + o) * H + y) * W + xo] = acc[o];
+        for (int o = 0; o < COUT; ++o) out[(((size_t)b * COUT + o) * H + y) * W + xo] = relu ? fmaxf(acc[o], 0.0f) : acc[o];
+    }
+}
+
+// ---- KxK convolutions with a handful of INPUT channels (convf1: 7x7 over the 2-channel flow, 64 output channels,
+// update.py:79,87): 98 multiply-adds per output, nothing for a matrix core to do.  A thread owns one pixel of an 8 x 32 tile and
+// 16 output channels at a time; the (8 + K - 1) x (32 + K - 1) x Cin input tile sits in LDS, the weights are wave-uniform
+// (scalar loads).  NCHW fp32 in, channels-last out with the ReLU applied.
+template <int K>
+__global__ __launch_bounds__(256) void conv_small_cin_kernel(const float *__restrict__ x, const float *__restrict__ wt,
+                                                             const float *__restrict__ bias, float *__restrict__ out, int Cin,
+                                                             int Cout, int H, int W, int tiles_x, int tiles_y, int ostride, int relu)
+{
+    constexpr int HC = 32 + K - 1, HR = 8 + K - 1, HALO = K / 2, MAXC = 4;
+    __shared__ float tile[MAXC * HR * HC];
+    const int tid = threadIdx.x, row = tid >> 5, col = tid & 31;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int x0 = 32 * tx, y0 = 8 * ty;
+    for (int i = tid; i < Cin * HR * HC; i += 256) {
+        const int c = i / (HR * HC), r = i - c * (HR * HC);
+        const int hy = r / HC, hx = r - hy * HC;
+        const int yy = y0 - HALO + hy, xx = x0 - HALO + hx;
+        tile[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[(((size_t)b * Cin + c) * H + yy) * W + xx] : 0.0f;
+    }
+    __syncthreads();
+    const int y = y0 + row, xo = x0 + col;
+    float *op = out + (((size_t)b * H + y) * W + xo) * ostride;
+    for (int o0 = 0; o0 < Cout; o0 += 16) {
+        float acc[16];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[o] = bias ? bias[o0 + o] : 0.0f;
+        for (int c = 0; c < Cin; ++c) {
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const float v = tile[(c * HR + row + ky) * HC + col + kx];
+                    const float *wk = wt + ((size_t)((ky * K + kx) * Cin + c)) * Cout + o0;   // [K][K][Cin][Cout]: wave-uniform
+#pragma unroll
+                    for (int o = 0; o < 16; ++o) acc[o] = fmaf(v, wk[o], acc[o]);
+                }
+            }
+        }
+        if (y < H && xo < W) {
+#pragma unroll
+            for (int o = 0; o < 16; o += 4) {
+                f32x4 v = {acc[o], acc[o + 1], acc[o + 2], acc[o + 3]};
+                if (relu) v = __builtin_elementwise_max(v, (f32x4){0.0f, 0.0f, 0.0f, 0.0f});
+                st4(op + o0 + o, v);
+            }
+        }
     }
 }
 
 }  // namespace
 
+extern "C" int stereo_conv_small_cin_nhwc_f32(const float *x, const float *weight_tco, const float *bias, float *out, int B, int Cin,
+                                              int Cout, int H, int W, int ksize, int out_stride, int relu, void *stream)
+{
+    if (B < 0 || Cin < 1 || Cout < 1 || H < 0 || W < 0 || out_stride < Cout) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(x);
+    STEREO_REQUIRE_PTR(weight_tco);
+    STEREO_REQUIRE_PTR(out);
+    if (Cin > 4 || Cout % 16 != 0 || Cout > 64 || out_stride % 4 != 0 || !aligned16(out) || (ksize != 3 && ksize != 5 && ksize != 7))
+        return STEREO_ERR_UNSUPPORTED;
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
+    const long long nt = (long long)tiles_x * tiles_y * B;
+    if (nt >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
+#define SMALLCIN(KV)                                                                                                          \
+    hipLaunchKernelGGL((conv_small_cin_kernel<KV>), dim3((unsigned)nt), dim3(256), 0, as_stream(stream), x, weight_tco, bias, out, \
+                       Cin, Cout, H, W, tiles_x, tiles_y, out_stride, relu)
+    if (ksize == 7) SMALLCIN(7);
+    else if (ksize == 5) SMALLCIN(5);
+    else SMALLCIN(3);
+#undef SMALLCIN
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
 namespace {
 template <typename TIN>
 int conv3x3_small(const TIN *x, const float *weight_tco, const float *bias, float *out_nchw, int B, int Cin, int Cout, int H, int W,
-                  void *stream)
+                  int relu, void *stream)
 {
     if (B < 0 || Cin < 0 || Cout < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
     if (B == 0 || H == 0 || W == 0 || Cout == 0) return STEREO_OK;
@@ -590,7 +666,7 @@ int conv3x3_small(const TIN *x, const float *weight_tco, const float *bias, floa
     if (nt >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
 #define SMALL(CO)                                                                                                              \
     hipLaunchKernelGGL((conv3x3_small_kernel<CO, TIN>), dim3((unsigned)nt), dim3(256), 0, as_stream(stream), x, weight_tco, bias, \
-                       out_nchw, Cin, H, W, tiles_x, tiles_y)
+                       out_nchw, Cin, H, W, tiles_x, tiles_y, relu)
     if (Cout == 1) SMALL(1);
     else if (Cout == 2) SMALL(2);
     else if (Cout == 3) SMALL(3);
@@ -604,12 +680,18 @@ int conv3x3_small(const TIN *x, const float *weight_tco, const float *bias, floa
 extern "C" int stereo_conv3x3_small_nhwc_f32(const float *x, const float *weight_tco, const float *bias, float *out_nchw, int B,
                                              int Cin, int Cout, int H, int W, void *stream)
 {
-    return conv3x3_small<float>(x, weight_tco, bias, out_nchw, B, Cin, Cout, H, W, stream);
+    return conv3x3_small<float>(x, weight_tco, bias, out_nchw, B, Cin, Cout, H, W, 0, stream);
+}
+extern "C" int stereo_conv3x3_small_nhwc_ex(const void *x, int x_is_f16, const float *weight_tco, const float *bias, float *out_nchw,
+                                            int B, int Cin, int Cout, int H, int W, int relu, void *stream)
+{
+    if (x_is_f16) return conv3x3_small<f16>(static_cast<const f16 *>(x), weight_tco, bias, out_nchw, B, Cin, Cout, H, W, relu, stream);
+    return conv3x3_small<float>(static_cast<const float *>(x), weight_tco, bias, out_nchw, B, Cin, Cout, H, W, relu, stream);
 }
 extern "C" int stereo_conv3x3_small_nhwc_f16(const void *x, const float *weight_tco, const float *bias, float *out_nchw, int B,
                                              int Cin, int Cout, int H, int W, void *stream)
 {
-    return conv3x3_small<f16>(static_cast<const f16 *>(x), weight_tco, bias, out_nchw, B, Cin, Cout, H, W, stream);
+    return conv3x3_small<f16>(static_cast<const f16 *>(x), weight_tco, bias, out_nchw, B, Cin, Cout, H, W, 0, stream);
 }
 
 namespace {
@@ -644,7 +726,7 @@ int conv_nhwc(const void *const *srcs, const int *src_channels, int nsrc, const 
               int W, void *stream)
 {
     typedef typename ConvAr<AR>::tin TIN;
-    if (nsrc < 1 || nsrc > CV_MAXSRC || nout < 1 || nout > CV_MAXNT || (ksize != 1 && ksize != 3) || B < 0 || H < 0 || W < 0)
+    if (nsrc < 1 || nsrc > CV_MAXSRC || nout < 1 || nout > CV_MAXNB || (ksize != 1 && ksize != 3) || B < 0 || H < 0 || W < 0)
         return STEREO_ERR_BAD_SHAPE;
     if (srcs == nullptr || src_channels == nullptr || outs == nullptr || out_channels == nullptr) return STEREO_ERR_NULL_POINTER;
     STEREO_REQUIRE_PTR(packed);
@@ -660,13 +742,14 @@ int conv_nhwc(const void *const *srcs, const int *src_channels, int nsrc, const 
         s.p[i] = srcs[i];
         s.c[i] = src_channels[i];
     }
-    // destinations: every one but the last must fill whole 128-channel N tiles
-    int Cout = 0, ntn = 0;
+    // destinations: every one but the last must fill whole 32-channel N blocks (a wave's MFMA column block); a 128-channel N
+    // tile (= a workgroup) may serve several of them
+    int Cout = 0, nblk = 0;
     for (int i = 0; i < nout; ++i) {
         STEREO_REQUIRE_PTR(outs[i]);
         const int c = out_channels[i];
         const int cs = out_strides ? out_strides[i] : c;   // channels of the destination tensor (>= c: the rest is the caller's)
-        if (c < 1 || cs < c || (i + 1 < nout && c % 128 != 0)) return STEREO_ERR_UNSUPPORTED;
+        if (c < 1 || cs < c || (i + 1 < nout && c % 32 != 0)) return STEREO_ERR_UNSUPPORTED;
         if ((long long)H * W * cs >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;     // 32-bit element offsets in the epilogue
         const int epi = epilogue ? epilogue[i] : STEREO_EPI_LINEAR;
         if (epi < STEREO_EPI_LINEAR || epi > STEREO_EPI_GRU_BLEND_SOFTSIGN) return STEREO_ERR_BAD_SHAPE;
@@ -674,20 +757,22 @@ int conv_nhwc(const void *const *srcs, const int *src_channels, int nsrc, const 
         const void *ad = addend ? addend[i] : nullptr, *x0 = aux0 ? aux0[i] : nullptr, *x1 = aux1 ? aux1[i] : nullptr;
         if (epi >= STEREO_EPI_SIGMOID_MUL && x0 == nullptr) return STEREO_ERR_NULL_POINTER;
         if (epi >= STEREO_EPI_GRU_BLEND && x1 == nullptr) return STEREO_ERR_NULL_POINTER;
-        for (int o = 0; o < c; o += 128) {
-            if (ntn >= CV_MAXNT) return STEREO_ERR_UNSUPPORTED;
-            d.p[ntn] = outs[i];
-            d.add[ntn] = ad;
-            d.aux0[ntn] = x0;
-            d.aux1[ntn] = x1;
-            d.stride[ntn] = cs;
-            d.coff[ntn] = o;
-            d.nvalid[ntn] = c - o < 128 ? c - o : 128;
-            d.epi[ntn] = epi;
-            ++ntn;
+        for (int o = 0; o < c; o += 32) {
+            if (nblk >= CV_MAXNB) return STEREO_ERR_UNSUPPORTED;
+            d.p[nblk] = outs[i];
+            d.add[nblk] = ad;
+            d.aux0[nblk] = x0;
+            d.aux1[nblk] = x1;
+            d.stride[nblk] = cs;
+            d.coff[nblk] = o;
+            d.nvalid[nblk] = c - o < 32 ? c - o : 32;
+            d.epi[nblk] = epi;
+            ++nblk;
         }
         Cout += c;
     }
+    const int ntn = (nblk + 3) / 4;
+    for (int k = nblk; k < 4 * ntn; ++k) d.p[k] = outs[0], d.stride[k] = 1, d.nvalid[k] = 0, d.epi[k] = STEREO_EPI_LINEAR;   // (unused blocks of the last tile)
     const int NB = 4 * ((Cout + 127) / 128);
     const int tiles_x = (W + CV_TW - 1) / CV_TW;
     // pixel tile: 4 rows x 32 columns, a wave = 4 rows x 32 output channels (an 8-row tile with 64 channels per wave measured equal

@@ -193,6 +193,65 @@ __global__ __launch_bounds__(256) void uncertainty_kernel(const float *__restric
     }
 }
 
+// The inputs of BasicGuidanceNet's two encoders (Attempts/update.py:75-90) in ONE pass, channels-last and zero-padded to the
+// channel counts the convolution kernel takes (multiples of 16): err[b,p,c] = disp_warp(right, disp)[c] - left[c] (border
+// padding, :83-84) for c < Ci, unc[b,p,d] = softmax_d(vol)[d] * d * (d - disp)^2 (:86) for d < D; the padding channels are 0.
+// Same arithmetic as disp_warp_kernel / uncertainty_kernel (shared device functions).
+__global__ __launch_bounds__(256) void guidance_inputs_nhwc_kernel(const float *__restrict__ vol, const float *__restrict__ disp,
+                                                                   const float *__restrict__ left, const float *__restrict__ right,
+                                                                   float *__restrict__ err, float *__restrict__ unc, int D, int Ci,
+                                                                   int H, int W, int CE, int CU, long long npix)
+{
+    const long long HW = (long long)H * W;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < npix; t += (long long)gridDim.x * blockDim.x) {
+        const long long b = t / HW, p = t - b * HW;
+        const int y = (int)(p / W), x = (int)(p - (long long)y * W);
+        const float cur = disp[t];
+        {   // ---- error map
+            float ux, uy;
+            disp_warp_coords(x, y, cur, W, H, ux, uy);
+            const float sx = clampf(ux, 0.0f, (float)(W - 1)), sy = clampf(uy, 0.0f, (float)(H - 1));
+            const float fx = floorf(sx), fy = floorf(sy);
+            const float ax = sx - fx, ay = sy - fy;
+            const int ix = (int)fx, iy = (int)fy;
+            const bool x0 = ix >= 0 && ix <= W - 1, x1 = ix + 1 >= 0 && ix + 1 <= W - 1;
+            const bool y0 = iy >= 0 && iy <= H - 1, y1 = iy + 1 >= 0 && iy + 1 <= H - 1;
+            const float w00 = (1.0f - ax) * (1.0f - ay), w01 = ax * (1.0f - ay), w10 = (1.0f - ax) * ay, w11 = ax * ay;
+            float *eo = err + (size_t)t * CE;
+            for (int c = 0; c < CE; ++c) {
+                float v = 0.0f;
+                if (c < Ci) {
+                    const float *im = right + ((size_t)b * Ci + c) * HW;
+                    float s = 0.0f;
+                    if (y0 && x0) s += im[(size_t)iy * W + ix] * w00;
+                    if (y0 && x1) s += im[(size_t)iy * W + ix + 1] * w01;
+                    if (y1 && x0) s += im[(size_t)(iy + 1) * W + ix] * w10;
+                    if (y1 && x1) s += im[(size_t)(iy + 1) * W + ix + 1] * w11;
+                    v = s - left[((size_t)b * Ci + c) * HW + p];
+                }
+                eo[c] = v;
+            }
+        }
+        {   // ---- uncertainty volume
+            const float *v = vol + (size_t)b * D * HW + p;
+            float *uo = unc + (size_t)t * CU;
+            Softmax1 sm;
+            sm.init();
+            for (int d = 0; d < D; ++d) sm.push(v[(size_t)d * HW]);
+            const float inv = 1.0f / sm.s;
+            for (int d = 0; d < CU; ++d) {
+                float o = 0.0f;
+                if (d < D) {
+                    const float pd = fast_exp(v[(size_t)d * HW] - sm.m) * inv;
+                    const float e = (float)d - cur;
+                    o = pd * (float)d * e * e;
+                }
+                uo[d] = o;
+            }
+        }
+    }
+}
+
 inline unsigned grid_for(long long nthreads)
 {
     long long blocks = (nthreads + 255) / 256;
@@ -273,6 +332,25 @@ extern "C" int stereo_uncertainty_volume_f32(const float *vol, const float *disp
     const long long HW = (long long)H * W, n = (long long)B * HW;
     hipLaunchKernelGGL(uncertainty_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), vol, disp, out, D, HW,
                        n);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+extern "C" int stereo_guidance_inputs_nhwc_f32(const float *vol, const float *disp, const float *left, const float *right, float *err,
+                                               float *unc, int B, int D, int Ci, int H, int W, int err_channels, int unc_channels,
+                                               void *stream)
+{
+    if (B < 0 || D < 0 || Ci < 0 || H < 0 || W < 0 || err_channels < Ci || unc_channels < D) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(vol);
+    STEREO_REQUIRE_PTR(disp);
+    STEREO_REQUIRE_PTR(left);
+    STEREO_REQUIRE_PTR(right);
+    STEREO_REQUIRE_PTR(err);
+    STEREO_REQUIRE_PTR(unc);
+    const long long n = (long long)B * H * W;
+    hipLaunchKernelGGL(guidance_inputs_nhwc_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), vol, disp, left, right, err,
+                       unc, D, Ci, H, W, err_channels, unc_channels, n);
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }

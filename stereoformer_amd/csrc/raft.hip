@@ -262,8 +262,11 @@ __device__ __forceinline__ float lerp_zero_pad_ac(const float *__restrict__ row,
 template <int R>
 __global__ __launch_bounds__(256) void corr_lookup_kernel(LevelPtrs lv, const float *__restrict__ coords,
                                                           float *__restrict__ out, int L, int r_rt, long long HW,
-                                                          long long npix)
+                                                          long long npix, long long bstride, long long cstride,
+                                                          long long pstride, int cpad)
 {
+    // output element (b, channel c, pixel p) sits at b bstride + c cstride + p pstride: NCHW (L T HW, HW, 1) or channels-last
+    // with `cpad` >= L T channels per pixel (HW cpad, 1, cpad; the padding channels are zeroed by the level-0 threads)
     const int r = R > 0 ? R : r_rt;
     const int T = 2 * r + 1;
     const int i = blockIdx.y;
@@ -275,7 +278,9 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(LevelPtrs lv, const fl
         const long long b = t / HW, p = t - b * HW;
         const float xl = coords[(size_t)b * 2 * HW + p] / (float)(1 << i);
         const float *row = base + (size_t)t * Wl;
-        float *o = out + ((size_t)b * (size_t)(L * T) + (size_t)i * T) * HW + p;
+        float *o = out + (size_t)b * bstride + (size_t)(i * T) * cstride + (size_t)p * pstride;
+        if (i == 0)
+            for (int c = L * T; c < cpad; ++c) out[(size_t)b * bstride + (size_t)c * cstride + (size_t)p * pstride] = 0.0f;
         if (R > 0) {
             float v0[2 * R + 1], v1[2 * R + 1], w0[2 * R + 1], w1[2 * R + 1];
 #pragma unroll
@@ -294,9 +299,9 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(LevelPtrs lv, const fl
                 w1[k] = ok1 ? a : 0.0f;
             }
 #pragma unroll
-            for (int k = 0; k < 2 * R + 1; ++k) o[(size_t)k * HW] = v0[k] * w0[k] + v1[k] * w1[k];
+            for (int k = 0; k < 2 * R + 1; ++k) o[(size_t)k * cstride] = v0[k] * w0[k] + v1[k] * w1[k];
         } else {
-            for (int k = 0; k < T; ++k) o[(size_t)k * HW] = lerp_zero_pad_ac(row, Wl, __fadd_rn((float)(k - r), xl));
+            for (int k = 0; k < T; ++k) o[(size_t)k * cstride] = lerp_zero_pad_ac(row, Wl, __fadd_rn((float)(k - r), xl));
         }
     }
 }
@@ -450,11 +455,12 @@ extern "C" int stereo_allpairs_pyramid_f16(const void *fmap1, const void *fmap2,
     return pool_pyramid(levels, B, H, W1, W2, num_levels, st);
 }
 
-extern "C" int stereo_corr_lookup_f32(const float *const *levels, const float *coords, float *out, int B, int H, int W1,
-                                      int W2, int num_levels, int radius, void *stream)
+static int corr_lookup(const float *const *levels, const float *coords, float *out, int B, int H, int W1, int W2, int num_levels,
+                       int radius, int nhwc_channels, void *stream)
 {
     if (B < 0 || H < 0 || W1 < 0 || W2 < 0 || num_levels < 0 || radius < 0) return STEREO_ERR_BAD_SHAPE;
     if (num_levels > STEREO_MAX_LEVELS) return STEREO_ERR_UNSUPPORTED;
+    if (nhwc_channels != 0 && nhwc_channels < num_levels * (2 * radius + 1)) return STEREO_ERR_BAD_SHAPE;
     if (B == 0 || H == 0 || W1 == 0 || num_levels == 0) return STEREO_OK;
     STEREO_REQUIRE_PTR(levels);
     STEREO_REQUIRE_PTR(coords);
@@ -467,15 +473,30 @@ extern "C" int stereo_corr_lookup_f32(const float *const *levels, const float *c
         lv.w[i] = w;
     }
     const long long HW = (long long)H * W1, n = (long long)B * HW;
+    const long long LT = (long long)num_levels * (2 * radius + 1);
+    const long long bs = nhwc_channels ? HW * nhwc_channels : LT * HW, cs = nhwc_channels ? 1 : HW, ps = nhwc_channels ? nhwc_channels : 1;
     const dim3 grid(grid_for(n), (unsigned)num_levels);
     if (radius == 4)
         hipLaunchKernelGGL(corr_lookup_kernel<4>, grid, dim3(256), 0, as_stream(stream), lv, coords, out, num_levels,
-                           radius, HW, n);
+                           radius, HW, n, bs, cs, ps, nhwc_channels);
     else
         hipLaunchKernelGGL(corr_lookup_kernel<0>, grid, dim3(256), 0, as_stream(stream), lv, coords, out, num_levels,
-                           radius, HW, n);
+                           radius, HW, n, bs, cs, ps, nhwc_channels);
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
+}
+
+extern "C" int stereo_corr_lookup_f32(const float *const *levels, const float *coords, float *out, int B, int H, int W1,
+                                      int W2, int num_levels, int radius, void *stream)
+{
+    return corr_lookup(levels, coords, out, B, H, W1, W2, num_levels, radius, 0, stream);
+}
+
+extern "C" int stereo_corr_lookup_nhwc_f32(const float *const *levels, const float *coords, float *out, int B, int H, int W1,
+                                           int W2, int num_levels, int radius, int out_channels, void *stream)
+{
+    if (out_channels < 1) return STEREO_ERR_BAD_SHAPE;
+    return corr_lookup(levels, coords, out, B, H, W1, W2, num_levels, radius, out_channels, stream);
 }
 
 // The same with one thread per (b, level, pixel) computing ALL 2 r + 1 taps in one pass over the channels: the taps of a pixel

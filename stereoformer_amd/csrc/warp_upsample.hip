@@ -26,12 +26,8 @@ __global__ __launch_bounds__(256) void disp_warp_kernel(const float *__restrict_
          t += (long long)gridDim.x * blockDim.x) {
         const long long b = t / HW, p = t - b * HW;
         const int y = (int)(p / W), x = (int)(p - (long long)y * W);
-        const float gx = (float)x + (-disp[t]);
-        const float gy = (float)y + 0.0f;
-        const float nx = __fsub_rn(__fmul_rn(2.0f, __fdiv_rn(gx, (float)(W - 1))), 1.0f);
-        const float ny = __fsub_rn(__fmul_rn(2.0f, __fdiv_rn(gy, (float)(H - 1))), 1.0f);
-        const float ux = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(nx, 1.0f), (float)W), 1.0f), 2.0f);
-        const float uy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(ny, 1.0f), (float)H), 1.0f), 2.0f);
+        float ux, uy;
+        disp_warp_coords(x, y, disp[t], W, H, ux, uy);
         if (mask) {  // ones sampled with zeros padding, thresholded (:102-105)
             const float fx = floorf(ux), fy = floorf(uy);
             const float ax = ux - fx, ay = uy - fy;

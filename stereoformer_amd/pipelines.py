@@ -89,7 +89,11 @@ class RAFTStereoLoop(nn.Module):
 
     def _iteration(self, corr_fn, coords0, coords1, net_list, inp_list, need_mask=True):
         coords1 = coords1.detach()                                  # raft_stereo.py:171
-        corr = corr_fn(coords1)                                     # :173
+        if self._nhwc() and not self.mixed_precision and not torch.is_grad_enabled() and isinstance(corr_fn, CorrBlock1D):
+            # the HIP path's layout for the motion encoder's 1x1 convolution: channels-last, zero-padded to 16 n channels
+            corr = corr_fn(coords1, nhwc_channels=(self.corr_levels * (2 * self.corr_radius + 1) + 15) // 16 * 16)
+        else:
+            corr = corr_fn(coords1)                                 # :173
         flow = coords1 - coords0
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.mixed_precision):    # :176
             net_list, up_mask, delta_flow = self.update_block(net_list, inp_list, corr, flow,
@@ -213,12 +217,19 @@ class LowCNNGRULoop(nn.Module):
             hidden = hidden.contiguous(memory_format=torch.channels_last)
         elif self.channels_last is None:
             self.update.to(memory_format=torch.contiguous_format)         # back from an earlier inference call
+        # the images at the disparity's resolution are loop-invariant: resized once here instead of once per iteration inside
+        # BasicGuidanceNet (Attempts/update.py:76-81 -- same kernel, same values)
+        from .update_dlc import resize_bilinear
+
+        def small(img):
+            return img if img.shape[-1] == w and img.shape[-2] == h else resize_bilinear(img, (h, w), align_corners=False)
         if use_graph:
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
                 raise RuntimeError("LowCNNGRULoop: use_graph=True is an inference path; call it under torch.no_grad()")
 
             def fn(ts):
                 d, hid = ts[1], torch.zeros_like(hidden)   # (preserves the channels-last layout)
+                ts = [ts[0], ts[1], small(ts[2]), small(ts[3])]
                 outs = []
                 for it in range(iters):   # unless every iterate is wanted, only the last one is upsampled: the
                     last = it == iters - 1  # earlier mask heads are skipped
@@ -231,6 +242,7 @@ class LowCNNGRULoop(nn.Module):
                    bool(graph_all_iterates), self._nhwc())
             return self._graphs.run(key, fn, [cost_volume, disp, left_image, right_image])
         outs = []
+        left_image, right_image = small(left_image), small(right_image)
         for _ in range(iters):
             disp, hidden, mask = self.update(cost_volume, disp, left_image, right_image, hidden, True)
             outs.append(upsample_convex8(disp, mask))

@@ -132,6 +132,27 @@ def gru_blend(h, zc, qc, cz=None, cq=None, softsign=False):
     return out
 
 
+def guidance_inputs_nhwc(old_cost_volume, cur_disp, left, right, err_channels=16, unc_channels=32):
+    """Inputs of ``BasicGuidanceNet``'s two encoders in one launch (``stereo_guidance_inputs_nhwc_f32``), channels-last and
+    zero-padded to multiples of 16 channels: ``(disp_warp(right, disp) - left, uncertainty_volume(vol, disp))`` as
+    ``[B,err_channels,h,w]`` / ``[B,unc_channels,h,w]`` ``torch.channels_last`` tensors.  Inference only."""
+    vol = N.dev_f32(old_cost_volume, "guidance_inputs_nhwc: cost volume")
+    disp = N.dev_f32(cur_disp, "guidance_inputs_nhwc: disparity")
+    left, right = N.dev_f32(left, "guidance_inputs_nhwc: left"), N.dev_f32(right, "guidance_inputs_nhwc: right")
+    B, D, H, W = vol.shape
+    Ci = left.shape[1]
+    if disp.shape != (B, 1, H, W) or left.shape != (B, Ci, H, W) or right.shape != left.shape:
+        raise ValueError("guidance_inputs_nhwc: shape mismatch")
+    ce, cu = max(err_channels, (Ci + 15) // 16 * 16), max(unc_channels, (D + 15) // 16 * 16)
+    cl = torch.channels_last
+    err = torch.empty((B, ce, H, W), device=vol.device, dtype=torch.float32, memory_format=cl)
+    unc = torch.empty((B, cu, H, W), device=vol.device, dtype=torch.float32, memory_format=cl)
+    with torch.cuda.device(vol.device):
+        N.call("stereo_guidance_inputs_nhwc_f32", N.ptr(vol), N.ptr(disp), N.ptr(left), N.ptr(right), N.ptr(err), N.ptr(unc), B, D, Ci,
+               H, W, ce, cu, N.stream_ptr(vol.device))
+    return err, unc
+
+
 def _split_convs_ok(*ts):
     """Inference on channels-last fp32 HIP activations outside autocast / tracing: where the 3x3 convolutions go to
     ``conv_split`` (see ``update_raft._split_ok``)."""
@@ -163,16 +184,19 @@ class ConvGRU(nn.Module):
         self.nb_channel = nb_channel
 
     def forward(self, input, prev_h):
+        """``input``: the GRU input tensor, or a list of channels-last tensors whose concatenation it is (the guidance
+        encoder's two feature maps: never concatenated on the ``conv_split`` path)."""
+        parts = list(input) if isinstance(input, (list, tuple)) else [input]
+        x0 = parts[0]
         if prev_h is None:  # the reference hard-codes .cuda() here (:38-39)
-            prev_h = torch.zeros(input.size(0), self.nb_channel, input.size(2), input.size(3), device=input.device,
-                                 dtype=input.dtype)
-        if _split_convs_ok(input, prev_h):
+            prev_h = torch.zeros(x0.size(0), self.nb_channel, x0.size(2), x0.size(3), device=x0.device, dtype=x0.dtype)
+        if _split_convs_ok(*parts, prev_h):
             from . import conv_split as C
             if prev_h.is_contiguous() and not prev_h.is_contiguous(memory_format=torch.channels_last):
                 prev_h = prev_h.contiguous(memory_format=torch.channels_last)
-            srcs = [input, prev_h]                                    # the reference's cat order (:40)
-            if (prev_h.is_contiguous(memory_format=torch.channels_last) and C.supported(srcs, [self.conv_z])
-                    and C.supported(srcs, [self.conv_b]) and C.supported([prev_h, input], [self.conv_g])):
+            srcs = [*parts, prev_h]                                   # the reference's cat order (:40)
+            if (prev_h.is_contiguous(memory_format=torch.channels_last) and len(srcs) <= 4 and C.supported(srcs, [self.conv_z])
+                    and C.supported(srcs, [self.conv_b]) and C.supported([prev_h, *parts], [self.conv_g])):
                 # inference in torch.channels_last: the three gate convolutions on conv_split (no concatenation is
                 # materialised) with the gate math in their epilogues (:41-48): two launches per GRU step
                 if C.supported(srcs, [self.conv_z, self.conv_b]):
@@ -181,7 +205,8 @@ class ConvGRU(nn.Module):
                     (z,) = C.conv_nhwc(srcs, [self.conv_z], epilogue=[("sigmoid", None)])
                     (s,) = C.conv_nhwc(srcs, [self.conv_b], epilogue=[("sigmoid_mul", None, prev_h)])
                 blend = "gru_blend_softsign" if self.softsign else "gru_blend"
-                return C.conv_nhwc([s, input], [self.conv_g], epilogue=[(blend, None, prev_h, z)])[0]
+                return C.conv_nhwc([s, *parts], [self.conv_g], epilogue=[(blend, None, prev_h, z)])[0]
+        input = parts[0] if len(parts) == 1 else torch.cat(parts, 1)
         x1 = torch.cat((input, prev_h), 1)
         zc = self.conv_z(x1)
         bc = self.conv_b(x1)
@@ -204,19 +229,37 @@ class BasicGuidanceNet(nn.Module):
             nn.Conv2d(3, self.hidden_layers, kernel_size=3, stride=1, padding=1, bias=False),
             nn.BatchNorm2d(self.hidden_layers), nn.ReLU(inplace=True))
 
-    def forward(self, old_cost_volume, cur_disp, left_image, right_image):
+    def features(self, old_cost_volume, cur_disp, left_image, right_image, nhwc=False):
+        """``[error_feature, uncertainity_feature]`` (:75-92, un-concatenated).  ``nhwc`` (inference, eval-mode BatchNorm, fp32 HIP
+        tensors): the whole encoder is three launches -- ``stereo_guidance_inputs_nhwc_f32`` (warp + error map + uncertainty
+        volume, channels-last, zero-padded to 16 / 32 channels) and one ``conv_split`` launch per branch with the BatchNorm
+        folded into the packed weights and the ReLU in the epilogue -- instead of resize x 2, warp, subtract, uncertainty, two
+        library convolutions, two BatchNorm and two ReLU launches."""
         if cur_disp.size(-1) != left_image.size(-1):
             size = (cur_disp.size(-2), cur_disp.size(-1))
             cur_left_image = resize_bilinear(left_image, size, align_corners=False)
             cur_right_image = resize_bilinear(right_image, size, align_corners=False)
         else:
             cur_left_image, cur_right_image = left_image, right_image
+        ce, be = self.disparity_error_encoder[0], self.disparity_error_encoder[1]
+        cu, bu = self.uncertain_encoder[0], self.uncertain_encoder[1]
+        if (nhwc and not torch.is_grad_enabled() and not torch.is_autocast_enabled("cuda") and not torch.compiler.is_compiling()
+                and not be.training and not bu.training and old_cost_volume.is_cuda and old_cost_volume.dtype == torch.float32):
+            from . import conv_split as C
+            err, unc = guidance_inputs_nhwc(old_cost_volume, cur_disp, cur_left_image, cur_right_image)
+            if C.supported([err], [ce], pad_in=True) and C.supported([unc], [cu], pad_in=True):
+                (ef,) = C.conv_nhwc([err], [ce], relu=True, bns=[be], pad_in=True)
+                (uf,) = C.conv_nhwc([unc], [cu], relu=True, bns=[bu], pad_in=True)
+                return [ef, uf]
         warped_left, _ = disp_warp(cur_right_image, cur_disp)
         error_map = warped_left - cur_left_image
         uncertainity_volume = uncertainty_volume(old_cost_volume, cur_disp)
         error_feature = self.disparity_error_encoder(error_map)
         uncertainity_feature = self.uncertain_encoder(uncertainity_volume)
-        return torch.cat([error_feature, uncertainity_feature], dim=1)
+        return [error_feature, uncertainity_feature]
+
+    def forward(self, old_cost_volume, cur_disp, left_image, right_image):
+        return torch.cat(self.features(old_cost_volume, cur_disp, left_image, right_image), dim=1)
 
 
 class OffsetPredictionHead(nn.Module):
@@ -235,7 +278,7 @@ class OffsetPredictionHead(nn.Module):
             if C.supported([x], [self.conv1]):
                 (y,) = C.conv_nhwc([x], [self.conv1], relu=True)
                 if C.small_supported(y, self.conv2):
-                    return self.relu2(C.conv3x3_small(y, self.conv2))     # (64 -> 2: fp32 vector kernel, NCHW out)
+                    return C.conv3x3_small(y, self.conv2, relu=True)      # (64 -> 2: fp32 vector kernel, ReLU inside, NCHW out)
                 return self.relu2(self.conv2(y))
         return self.relu2(self.conv2(self.relu1(self.conv1(x))))
 
@@ -280,7 +323,8 @@ class DisparityUpdateDLCWithMask(nn.Module):
                 need_mask=True):
         """``need_mask=False`` (not in the reference) skips the upsampling-mask head (returns ``None`` for it): an
         inference loop that only upsamples its last iterate does not need the earlier masks."""
-        offset_features = self.encoder(old_cost_volume, cur_disp, left_image, right_image)
+        nhwc = hidden_state is not None and _split_convs_ok(hidden_state)   # the loop keeps the hidden state channels-last
+        offset_features = self.encoder.features(old_cost_volume, cur_disp, left_image, right_image, nhwc=nhwc)
         hidden_state = self.gru(offset_features, hidden_state)
         mask = None
         if need_mask:

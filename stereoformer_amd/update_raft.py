@@ -169,6 +169,24 @@ class BasicMotionEncoder_LZH(nn.Module):
         self.conv = _conv(128, 126, 3)
 
     def forward(self, flow, corr):
+        """``corr``: the lookup's ``[B, levels * (2 r + 1), H, W]`` features -- or, on the inference HIP path, the same features
+        channels-last and zero-padded to a multiple of 16 channels (``CorrBlock1D.__call__(..., nhwc_channels=)``)."""
+        cin = self.convc1.in_channels
+        if (corr.shape[1] >= cin and corr.shape[1] % 16 == 0 and _split_ok(corr) and flow.dtype == torch.float32
+                and conv_split.supported([corr], [self.convc1], pad_in=True) and conv_split.small_cin_supported(flow.contiguous(), self.convf1)
+                and conv_split.supported([corr[:, :64]], [self.convc2]) and conv_split.supported([corr[:, :64]], [self.convf2])):
+            # every convolution of the encoder on the HIP path: 1x1 over the padded correlation features, 7x7 over the flow on
+            # the vector units, then the three 3x3 ones
+            flow = flow.contiguous()
+            (c1,) = conv_split.conv_nhwc([corr], [self.convc1], relu=True, pad_in=True)
+            f1 = conv_split.conv_small_cin(flow, self.convf1, relu=True)
+            (c,) = conv_split.conv_nhwc([c1], [self.convc2], relu=True)
+            (f,) = conv_split.conv_nhwc([f1], [self.convf2], relu=True)
+            (out,) = conv_split.conv_nhwc([c, f], [self.conv], relu=True, out_channels_total=self.conv.out_channels + flow.shape[1])
+            out[:, self.conv.out_channels:] = flow     # the appended flow channels (:91), written in place
+            return out
+        if corr.shape[1] > cin:
+            corr = corr[:, :cin]
         c1, f1 = F.relu(self.convc1(corr)), F.relu(self.convf1(flow))   # 1x1 over 36 and 7x7 over 2 channels: the library's
         if (_split_ok(c1, f1) and conv_split.supported([c1], [self.convc2]) and conv_split.supported([f1], [self.convf2])
                 and conv_split.supported([c1, f1], [self.conv])):
@@ -219,7 +237,7 @@ class BasicMultiUpdateBlock_LZH(nn.Module):
             side = _side_stream(flow.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                motion = self.encoder(self._like(flow, net[0]), self._like(corr, net[0]))
+                motion = self.encoder(flow, self._like(corr, net[0]))
         if iter32:
             net[2] = self.gru32(net[2], *inp[2], pool2x(net[1]))
         if iter16:
@@ -235,7 +253,7 @@ class BasicMultiUpdateBlock_LZH(nn.Module):
                     # defer every iteration's free to the end of the capture: one motion buffer per iteration in the pool.)
                     motion.record_stream(cur)
             else:
-                motion = self.encoder(self._like(flow, net[0]), self._like(corr, net[0]))
+                motion = self.encoder(flow, self._like(corr, net[0]))
             net[0] = self.gru08(net[0], *inp[0], motion, *extra)
         if not update:
             return net
@@ -247,7 +265,12 @@ class BasicMultiUpdateBlock_LZH(nn.Module):
                 outs = conv_split.conv_nhwc([h0], heads, relu=True)
             else:
                 outs = [conv_split.conv_nhwc([h0], [m], relu=True)[0] for m in heads]
-            mask = 0.25 * self.mask[2](outs[1]) if need_mask else None
+            mask = None
+            if need_mask:      # scaled to balance gradients (:176): the factor is folded into the packed 1x1 weights
+                if conv_split.supported([outs[1]], [self.mask[2]]):
+                    (mask,) = conv_split.conv_nhwc([outs[1]], [self.mask[2]], scales=[0.25])
+                else:
+                    mask = 0.25 * self.mask[2](outs[1])
             if conv_split.small_supported(outs[0], self.flow_head.conv2):
                 return net, mask, conv_split.conv3x3_small(outs[0], self.flow_head.conv2)   # 256 -> 2: fp32 FMAs, NCHW out
             return net, mask, self.flow_head.conv2(outs[0])

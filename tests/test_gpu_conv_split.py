@@ -123,7 +123,7 @@ def test_update_block_on_the_split_convolutions_matches_the_library_path(S, monk
 
     a = run(True)
     n_split = len(calls)
-    assert n_split == 3 * (3 * 2 + 3 + 1)          # per iteration: 3 GRUs x 2 launches, 3 encoder convolutions, the heads
+    assert n_split == 3 * (3 * 2 + 3 + 1) + 1      # per iteration: 3 GRUs x 2 launches, 3 encoder convolutions, the heads; + mask[2]
     b = run(False)
     assert len(calls) == n_split
     for x, y in zip([*a[0], a[1], a[2]], [*b[0], b[1], b[2]]):
@@ -465,3 +465,107 @@ def test_update_block_partial_iterations_and_early_return(S, monkeypatch, flags)
         assert float((x - y).abs().max()) <= 2e-5 * max(1.0, float(y.abs().max())), float((x - y).abs().max())
         # (replay vs eager: to rounding, not bit for bit -- the library picks its 1x1 / 7x7 solvers per call)
         assert float((x - z).abs().max()) <= 2e-5 * max(1.0, float(x.abs().max())), float((x - z).abs().max())
+
+
+def test_conv_nhwc_folds_batchnorm_and_pads_input_channels(S):
+    """BasicGuidanceNet's encoders (Attempts/update.py:57-66: Conv2d(bias=False) -> BatchNorm2d -> ReLU over 24 / 3 channels) as
+    ONE conv_split launch each: eval-mode BatchNorm folded into the packed weights, ReLU in the epilogue, the source zero-padded
+    to a multiple of 16 channels -- against the fp64 conv -> bn -> relu of the unpadded input; the fold follows later updates
+    of the BatchNorm statistics (refresh)."""
+    from stereoformer_amd import conv_split as C
+    torch.manual_seed(98)
+    for cin, cpad in ((24, 32), (3, 16)):
+        conv = nn.Conv2d(cin, 32, 3, padding=1, bias=False).cuda()
+        bn = nn.BatchNorm2d(32).cuda().eval()
+        with torch.no_grad():
+            bn.running_mean.normal_(0, 0.5)
+            bn.running_var.uniform_(0.5, 2.0)
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.3)
+            x = torch.randn(2, cin, 11, 37, device="cuda")
+            xp = torch.zeros(2, cpad, 11, 37, device="cuda").contiguous(memory_format=torch.channels_last)
+            xp[:, :cin] = x
+            assert not C.supported([xp], [conv]) and C.supported([xp], [conv], pad_in=True)
+            (o,) = C.conv_nhwc([xp], [conv], relu=True, bns=[bn], pad_in=True)
+
+            def ref():
+                y = F.conv2d(x.double().cpu(), conv.weight.double().cpu(), None, padding=1)
+                y = F.batch_norm(y, bn.running_mean.double().cpu(), bn.running_var.double().cpu(), bn.weight.double().cpu(),
+                                 bn.bias.double().cpu(), False, 0.0, bn.eps)
+                return F.relu(y)
+            r = ref()
+            assert float((o.double().cpu() - r).abs().max()) <= 4e-6 * float(r.abs().max()) + 1e-6
+            bn.running_mean.data.add_(0.25)                       # (through .data: only the content fingerprint sees it)
+            assert C.refresh([conv, bn]) == 1
+            (o2,) = C.conv_nhwc([xp], [conv], relu=True, bns=[bn], pad_in=True)
+            r2 = ref()
+            assert float((o2.double().cpu() - r2).abs().max()) <= 4e-6 * float(r2.abs().max()) + 1e-6
+            assert not torch.allclose(o, o2)
+            bn.train()
+            with pytest.raises(ValueError):
+                C.conv_nhwc([xp], [nn.Conv2d(cin, 32, 3, padding=1, bias=False).cuda()], bns=[bn], pad_in=True)
+            bn.eval()
+
+
+def test_guidance_inputs_nhwc_matches_the_separate_kernels(S):
+    """stereo_guidance_inputs_nhwc_f32 == (disp_warp(right, disp) - left, uncertainty_volume(vol, disp)) bit for bit (shared device
+    functions), channels-last, zero in the padding channels."""
+    from stereoformer_amd.update_dlc import guidance_inputs_nhwc
+    torch.manual_seed(99)
+    B, D, H, W = 2, 24, 9, 23
+    vol = torch.randn(B, D, H, W, device="cuda") * 2
+    disp = torch.rand(B, 1, H, W, device="cuda") * 25 - 1
+    left, right = torch.randn(B, 3, H, W, device="cuda"), torch.randn(B, 3, H, W, device="cuda")
+    with torch.no_grad():
+        err, unc = guidance_inputs_nhwc(vol, disp, left, right)
+        warped, _ = S.disp_warp(right, disp)
+        u = S.uncertainty_volume(vol, disp)
+    assert err.shape == (B, 16, H, W) and unc.shape == (B, 32, H, W) and err.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(err[:, :3], warped - left) and float(err[:, 3:].abs().max()) == 0.0
+    assert torch.equal(unc[:, :D], u) and float(unc[:, D:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", [(2, 2, 64, 7, 13, 37), (1, 2, 64, 7, 8, 32), (1, 3, 32, 3, 5, 40), (2, 1, 16, 5, 9, 9), (1, 4, 48, 7, 3, 70)])
+def test_conv_small_cin(S, case):
+    """convf1 (7x7 over the 2-channel flow -> 64 channels, update.py:79,87) on the fp32 vector units: NCHW in, channels-last out,
+    ReLU inside; against fp64."""
+    from stereoformer_amd import conv_split as C
+    B, cin, cout, k, H, W = case
+    torch.manual_seed(100)
+    x = torch.randn(B, cin, H, W, device="cuda") * 3
+    m = nn.Conv2d(cin, cout, k, padding=k // 2).cuda()
+    with torch.no_grad():
+        assert C.small_cin_supported(x, m) and not C.small_cin_supported(x, nn.Conv2d(cin, cout + 1, k, padding=k // 2).cuda())
+        for relu in (False, True):
+            o = C.conv_small_cin(x, m, relu=relu)
+            r = F.conv2d(x.double().cpu(), m.weight.double().cpu(), m.bias.double().cpu(), padding=k // 2)
+            r = F.relu(r) if relu else r
+            assert o.shape == r.shape and o.is_contiguous(memory_format=torch.channels_last)
+            assert float((o.double().cpu() - r).abs().max()) <= 3e-6 * float(r.abs().max()) + 1e-6
+
+
+def test_corr_lookup_channels_last_padded(S):
+    """CorrBlock1D.__call__(coords, nhwc_channels=48): the NCHW lookup's values, channels-last, zero in the padding channels."""
+    torch.manual_seed(101)
+    B, C, H, W = 2, 64, 6, 48
+    f1, f2 = torch.randn(B, C, H, W, device="cuda"), torch.randn(B, C, H, W, device="cuda")
+    blk = S.CorrBlock1D(f1, f2, radius=4, num_levels=4)
+    coords = S.coords_grid(B, H, W, device="cuda") + torch.randn(B, 2, H, W, device="cuda") * 6
+    with torch.no_grad():
+        a = blk(coords)
+        b = blk(coords, nhwc_channels=48)
+    assert b.shape == (B, 48, H, W) and b.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(b[:, :36], a) and float(b[:, 36:].abs().max()) == 0.0
+
+
+def test_conv_nhwc_one_by_one_with_scale_and_640_channels(S):
+    """mask[2] (update.py:149-152,176: 1x1, 256 -> 576, times 0.25) as one launch with the factor folded into the weights."""
+    from stereoformer_amd import conv_split as C
+    torch.manual_seed(102)
+    x = _cl(torch.randn(1, 256, 9, 40, device="cuda"))
+    m = nn.Conv2d(256, 576, 1).cuda()
+    with torch.no_grad():
+        assert C.supported([x], [m])
+        (o,) = C.conv_nhwc([x], [m], scales=[0.25])
+    r = 0.25 * F.conv2d(x.double().cpu(), m.weight.double().cpu(), m.bias.double().cpu())
+    assert float((o.double().cpu() - r).abs().max()) <= 4e-6 * float(r.abs().max()) + 1e-6
