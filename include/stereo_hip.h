@@ -409,6 +409,11 @@ int stereo_conv3x3_small_nhwc_f32(const float *x, const float *weight_tco, const
 int stereo_conv3x3_small_nhwc_f16(const void *x, const float *weight_tco, const float *bias, float *out_nchw, int B, int Cin,
                                   int Cout, int H, int W, void *stream);
 
+/* pool2x / pool4x (update/update.py:119-123: F.avg_pool2d(x, k, stride, padding), zero padding, divisor k*k) on channels-last
+ * fp32 tensors: in [N][Hi][Wi][C] -> out [N][Ho][Wo][C], Ho = (Hi + 2 pad - k) / stride + 1; C % 4 == 0. */
+int stereo_avg_pool_nhwc_f32(const float *in, float *out, int N, int C, int Hi, int Wi, int ksize, int stride, int pad,
+                             void *stream);
+
 /* KxK stride-1 "same" convolution with 1..4 INPUT channels (the motion encoder's convf1, update/update.py:79,87: 7x7 over the
  * 2-channel flow) on the fp32 vector units: x [B,Cin,H,W] NCHW fp32, weight_tco = weight.permute(2, 3, 1, 0) contiguous
  * ([K][K][Cin][Cout], Cout % 16 == 0, Cout <= 64), bias [Cout] or NULL, ReLU if `relu`; out [B][H][W][out_stride] channels-last

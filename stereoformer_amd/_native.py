@@ -43,6 +43,7 @@ SIGNATURES = {
     "stereo_uncertainty_volume_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "stereo_allpairs_pyramid_f32": [_vp, _vp, ctypes.POINTER(_vp), _i, _i, _i, _i, _i, _i, _vp],
     "stereo_corr_lookup_f32": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "stereo_avg_pool_nhwc_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_corr_lookup_nhwc_f32": [ctypes.POINTER(_vp), _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_conv_small_cin_nhwc_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_alt_corr_lookup_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

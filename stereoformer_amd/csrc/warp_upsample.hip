@@ -391,6 +391,52 @@ extern "C" int stereo_resize_bilinear_nhwc_f32(const float *in, float *out, int 
     return STEREO_OK;
 }
 
+// pool2x / pool4x of the update block (update/update.py:119-123: F.avg_pool2d(x, 3, stride=2, padding=1) / (x, 5, stride=4,
+// padding=1): zero padding, count_include_pad -- the divisor is always k*k) on channels-last tensors: a thread owns four
+// channels of one output pixel (16-B loads of its k x k taps, one 16-B store).  The framework's NHWC pooling kernel takes
+// 0.14 ms for [8,128,136,240] -> [8,128,68,120]; this one runs at the read rate of the input.
+__global__ __launch_bounds__(256) void avg_pool_nhwc_kernel(const float *__restrict__ in, float *__restrict__ out, int C4, int Hi,
+                                                            int Wi, int Ho, int Wo, int k, int stride, int pad, float inv,
+                                                            long long nout)
+{
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nout; t += (long long)gridDim.x * blockDim.x) {
+        const int cq = (int)(t % C4);
+        long long r = t / C4;
+        const int x = (int)(r % Wo);
+        r /= Wo;
+        const int y = (int)(r % Ho);
+        const long long n = r / Ho;
+        const float *im = in + (size_t)n * Hi * Wi * 4 * C4 + 4 * cq;
+        f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int ky = 0; ky < k; ++ky) {
+            const int yy = y * stride - pad + ky;
+            if (yy < 0 || yy >= Hi) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int xx = x * stride - pad + kx;
+                if (xx >= 0 && xx < Wi) s += ld4(im + ((size_t)yy * Wi + xx) * 4 * C4);
+            }
+        }
+        st4(out + t * 4, s * inv);
+    }
+}
+
+extern "C" int stereo_avg_pool_nhwc_f32(const float *in, float *out, int N, int C, int Hi, int Wi, int ksize, int stride, int pad,
+                                        void *stream)
+{
+    if (N < 0 || C < 0 || Hi < 0 || Wi < 0 || ksize < 1 || stride < 1 || pad < 0 || 2 * pad > ksize) return STEREO_ERR_BAD_SHAPE;
+    const int Ho = (Hi + 2 * pad - ksize) / stride + 1, Wo = (Wi + 2 * pad - ksize) / stride + 1;   // floor mode
+    if (Hi + 2 * pad < ksize || Wi + 2 * pad < ksize) return STEREO_ERR_BAD_SHAPE;
+    if (N == 0 || C == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(in);
+    STEREO_REQUIRE_PTR(out);
+    if (C % 4 != 0 || !aligned16(in) || !aligned16(out)) return STEREO_ERR_UNSUPPORTED;
+    const long long nout = (long long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(avg_pool_nhwc_kernel, dim3(grid_for(nout)), dim3(256), 0, as_stream(stream), in, out, C / 4, Hi, Wi, Ho, Wo,
+                       ksize, stride, pad, 1.0f / (float)(ksize * ksize), nout);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
 extern "C" int stereo_bilinear_sampler_f32(const float *img, const float *coords, float *out, float *mask, int N, int C,
                                            int H, int W, int Ho, int Wo, void *stream)
 {

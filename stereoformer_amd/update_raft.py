@@ -23,14 +23,30 @@ def _conv(cin, cout, k, pad=None):
     return nn.Conv2d(cin, cout, k, padding=k // 2 if pad is None else pad)
 
 
+def _avg_pool(x, k, stride, pad):
+    """``F.avg_pool2d(x, k, stride=stride, padding=pad)``; channels-last fp32 HIP activations outside autograd go to the
+    library's own pooling kernel (``stereo_avg_pool_nhwc_f32``)."""
+    if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] % 4 == 0 and not x.is_contiguous()
+            and x.is_contiguous(memory_format=torch.channels_last) and not (torch.is_grad_enabled() and x.requires_grad)
+            and not torch.compiler.is_compiling()):
+        from . import _native as N
+        B, C, H, W = x.shape
+        ho, wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        out = torch.empty((B, C, ho, wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        with torch.cuda.device(x.device):
+            N.call("stereo_avg_pool_nhwc_f32", N.ptr(x), N.ptr(out), B, C, H, W, k, stride, pad, N.stream_ptr(x.device))
+        return out
+    return F.avg_pool2d(x, k, stride=stride, padding=pad)
+
+
 def pool2x(x):
     """3x3 / stride-2 average pooling (update.py:119-120)."""
-    return F.avg_pool2d(x, 3, stride=2, padding=1)
+    return _avg_pool(x, 3, 2, 1)
 
 
 def pool4x(x):
     """5x5 / stride-4 average pooling (update.py:122-123)."""
-    return F.avg_pool2d(x, 5, stride=4, padding=1)
+    return _avg_pool(x, 5, 4, 1)
 
 
 def _f32(t):
@@ -172,22 +188,18 @@ class BasicMotionEncoder_LZH(nn.Module):
         """``corr``: the lookup's ``[B, levels * (2 r + 1), H, W]`` features -- or, on the inference HIP path, the same features
         channels-last and zero-padded to a multiple of 16 channels (``CorrBlock1D.__call__(..., nhwc_channels=)``)."""
         cin = self.convc1.in_channels
-        if (corr.shape[1] >= cin and corr.shape[1] % 16 == 0 and _split_ok(corr) and flow.dtype == torch.float32
-                and conv_split.supported([corr], [self.convc1], pad_in=True) and conv_split.small_cin_supported(flow.contiguous(), self.convf1)
-                and conv_split.supported([corr[:, :64]], [self.convc2]) and conv_split.supported([corr[:, :64]], [self.convf2])):
-            # every convolution of the encoder on the HIP path: 1x1 over the padded correlation features, 7x7 over the flow on
-            # the vector units, then the three 3x3 ones
+        c1 = f1 = None
+        if corr.shape[1] >= cin and corr.shape[1] % 16 == 0 and _split_ok(corr) and flow.dtype == torch.float32:
+            # the two input convolutions on the HIP path as well: 1x1 over the padded correlation features (matrix cores), 7x7
+            # over the 2-channel flow (vector units), ReLU inside
             flow = flow.contiguous()
-            (c1,) = conv_split.conv_nhwc([corr], [self.convc1], relu=True, pad_in=True)
-            f1 = conv_split.conv_small_cin(flow, self.convf1, relu=True)
-            (c,) = conv_split.conv_nhwc([c1], [self.convc2], relu=True)
-            (f,) = conv_split.conv_nhwc([f1], [self.convf2], relu=True)
-            (out,) = conv_split.conv_nhwc([c, f], [self.conv], relu=True, out_channels_total=self.conv.out_channels + flow.shape[1])
-            out[:, self.conv.out_channels:] = flow     # the appended flow channels (:91), written in place
-            return out
-        if corr.shape[1] > cin:
-            corr = corr[:, :cin]
-        c1, f1 = F.relu(self.convc1(corr)), F.relu(self.convf1(flow))   # 1x1 over 36 and 7x7 over 2 channels: the library's
+            if conv_split.supported([corr], [self.convc1], pad_in=True) and conv_split.small_cin_supported(flow, self.convf1):
+                (c1,) = conv_split.conv_nhwc([corr], [self.convc1], relu=True, pad_in=True)
+                f1 = conv_split.conv_small_cin(flow, self.convf1, relu=True)
+        if c1 is None:
+            if corr.shape[1] > cin:
+                corr = corr[:, :cin]
+            c1, f1 = F.relu(self.convc1(corr)), F.relu(self.convf1(flow))   # 1x1 over 36 and 7x7 over 2 channels: the library's
         if (_split_ok(c1, f1) and conv_split.supported([c1], [self.convc2]) and conv_split.supported([f1], [self.convf2])
                 and conv_split.supported([c1, f1], [self.conv])):
             (c,) = conv_split.conv_nhwc([c1], [self.convc2], relu=True)

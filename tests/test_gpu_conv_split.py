@@ -556,6 +556,10 @@ def test_corr_lookup_channels_last_padded(S):
         b = blk(coords, nhwc_channels=48)
     assert b.shape == (B, 48, H, W) and b.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(b[:, :36], a) and float(b[:, 36:].abs().max()) == 0.0
+    blk3 = S.CorrBlock1D(f1, f2, radius=3, num_levels=3)          # (the generic strided kernel)
+    with torch.no_grad():
+        a3, b3 = blk3(coords), blk3(coords, nhwc_channels=32)
+    assert torch.equal(b3[:, :21], a3) and float(b3[:, 21:].abs().max()) == 0.0
 
 
 def test_conv_nhwc_one_by_one_with_scale_and_640_channels(S):
@@ -569,3 +573,19 @@ def test_conv_nhwc_one_by_one_with_scale_and_640_channels(S):
         (o,) = C.conv_nhwc([x], [m], scales=[0.25])
     r = 0.25 * F.conv2d(x.double().cpu(), m.weight.double().cpu(), m.bias.double().cpu())
     assert float((o.double().cpu() - r).abs().max()) <= 4e-6 * float(r.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 17, 30), (1, 8, 5, 7), (1, 32, 136, 240), (2, 4, 2, 3)])
+def test_pool2x_pool4x_channels_last(S, shape):
+    """pool2x / pool4x (update.py:119-123) on channels-last activations: the library's kernel against F.avg_pool2d."""
+    torch.manual_seed(103)
+    x = torch.randn(*shape, device="cuda")
+    xc = torch.empty_strided(shape, (shape[1] * shape[2] * shape[3], 1, shape[1] * shape[3], shape[1]), device="cuda").copy_(x)
+    for fn, k, st in ((S.pool2x, 3, 2), (S.pool4x, 5, 4)):
+        if shape[2] + 2 < k or shape[3] + 2 < k:
+            continue
+        with torch.no_grad():
+            a = fn(xc)
+        b = F.avg_pool2d(x, k, stride=st, padding=1)
+        assert a.shape == b.shape and a.is_contiguous(memory_format=torch.channels_last)
+        assert float((a - b).abs().max()) <= 1e-6
