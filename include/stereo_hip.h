@@ -224,6 +224,11 @@ int stereo_gwc_volume_bwd_f32(const float *left, const float *right, const float
 int stereo_local_lookup_bwd_f32(const float *vol, const float *disp, const float *grad_out,
                                 float *grad_vol_zeroed, float *grad_disp, int B, int D, int H, int W,
                                 float radius, int S, int consider_valid, void *stream);
+/* The same, writing grad_vol DENSELY (every element, zeros included) in the one launch: no zero-fill by the caller, no
+ * read-modify-write.  2 * radius + 3 <= 16 and H*W % 4 == 0, else STEREO_ERR_UNSUPPORTED (use the entry above). */
+int stereo_local_lookup_bwd_dense_f32(const float *vol, const float *disp, const float *grad_out, float *grad_vol,
+                                      float *grad_disp, int B, int D, int H, int W, float radius, int S, int consider_valid,
+                                      void *stream);
 
 /* backward of A13 (upsample.py:22-38, raft_stereo.py:110-122), f in {4, 8}: grad_out [N,Cd,fH,fW] ->
  * grad_disp [N,Cd,H,W] (MUST be zero-filled by the caller) and grad_mask [N,9*f*f,H,W] */

@@ -90,6 +90,7 @@ SIGNATURES = {
     "stereo_soft_argmin_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_gwc_volume_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_local_lookup_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "stereo_local_lookup_bwd_dense_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
     "stereo_variance_lookup_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
     "stereo_diff_volume_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_concat_volume_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -63,6 +63,91 @@ __global__ __launch_bounds__(256) void soft_argmin_bwd_kernel(const float *__res
     }
 }
 
+// The same in ONE pass over the volume (no probability cotangent, D <= NWV * SPLIT * J): regress.hip's register-resident
+// softmax column (soft_argmin_prob_regs_kernel) with the gradient as the final write -- a workgroup of NWV waves owns
+// 64 / SPLIT pixel quads, the D planes are dealt round-robin to NWV * SPLIT phases, every lane keeps its J planes of one quad
+// with all J loads in flight, max and sums meet in LDS (two barriers):  the volume is read once and the gradient written
+// once (the two-pass kernel above reads it twice: 1.93 ms at cfg-2 against 1.22 ms for the forward with probabilities).
+template <int J, int NWV, int SPLIT>
+__global__ __launch_bounds__(NWV * 64) void soft_argmin_bwd_regs_kernel(const float *__restrict__ vol,
+                                                                        const float *__restrict__ gdisp,
+                                                                        float *__restrict__ gvol, int D, long long HW, float sgn)
+{
+    constexpr int QPW = 64 / SPLIT, NPH = NWV * SPLIT;
+    __shared__ float red[3][NPH][QPW * 4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ph = wave * SPLIT + lane / QPW, ql = lane % QPW;
+    const long long p = ((long long)blockIdx.x * QPW + ql) * 4;
+    const bool okp = p < HW;  // HW % 4 == 0: a quad is entirely in or out
+    const size_t boff = (size_t)blockIdx.y * D * HW + (okp ? p : 0);
+    const float *v = vol + boff;
+    f32x4 x[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int d = ph + NPH * j;
+        if (okp && d < D) {
+            const f32x4 r = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(v + (size_t)d * HW));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[j][i] = sgn * r[i];
+        } else {
+            x[j] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+    }
+    const f32x4 g = okp ? ld4(gdisp + (size_t)blockIdx.y * HW + p) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    float m[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float mm = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < J; ++j) mm = fmaxf(mm, x[j][i]);
+        red[0][ph][ql * 4 + i] = mm;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float mm = red[0][0][ql * 4 + i];
+#pragma unroll
+        for (int k = 1; k < NPH; ++k) mm = fmaxf(mm, red[0][k][ql * 4 + i]);
+        m[i] = (mm == -INFINITY) ? 0.0f : mm;  // out-of-range quad: keep the arithmetic finite
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float ss = 0.0f, ee = 0.0f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const float e = fast_exp(x[j][i] - m[i]);  // -inf -> 0
+            x[j][i] = e;
+            ss += e;
+            ee = fmaf(e, (float)(ph + NPH * j), ee);
+        }
+        red[1][ph][ql * 4 + i] = ss;
+        red[2][ph][ql * 4 + i] = ee;
+    }
+    __syncthreads();
+    float sc[4], dm[4];   // sgn * g / S and the disparity E / S
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float S = 0.0f, E = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NPH; ++k) S += red[1][k][ql * 4 + i], E += red[2][k][ql * 4 + i];
+        const float inv = 1.0f / S;
+        dm[i] = E * inv;
+        sc[i] = sgn * g[i] * inv;
+    }
+    if (!okp) return;
+    float *o = gvol + boff;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int d = ph + NPH * j;
+        if (d < D) {
+            f32x4 q;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = x[j][i] * sc[i] * ((float)d - dm[i]);   // sgn p_d g (d - disp)
+            st4(o + (size_t)d * HW, q);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ volume backward
 // vol[b,g,d,h,w] = (1/CPG) sum_{c in g} L[c,w] R[c,w-d]  (w >= d)
 //   dL[c,w] = (1/CPG) sum_{d <= w} gv[g,d,w]   * R[c,w-d]
@@ -293,6 +378,108 @@ __global__ __launch_bounds__(256) void local_lookup_bwd_kernel(const float *__re
         }
         if (pend_idx >= 0) gvp[(size_t)pend_idx * HW] += pend_val;
         gdisp[t] = gd;
+    }
+}
+
+// The same with the gradient volume written DENSELY by the kernel itself (no zero-fill pass, no read-modify-write): a pixel's
+// candidates touch a window of at most 2 radius + 3 consecutive disparity planes, so a workgroup (256 pixels of one image)
+// first does the per-pixel math as above with the pushes going to a private 16-entry LDS window (thread = pixel), then writes
+// ALL D planes of its 256 columns -- the window values where a plane falls inside a pixel's window, zeros elsewhere -- as
+// 16-byte stores (thread = pixel quad, one plane per wave and step): the 3.19 GB gradient volume of cfg-2 is written once
+// at the store rate instead of memset + scattered updates.  radius <= 6 (window <= 16), HW % 4 == 0.
+constexpr int LLB_WIN = 16;
+__global__ __launch_bounds__(256) void local_lookup_bwd_dense_kernel(const float *__restrict__ vol,
+                                                                     const float *__restrict__ disp,
+                                                                     const float *__restrict__ gout,
+                                                                     float *__restrict__ gvol, float *__restrict__ gdisp,
+                                                                     int D, long long HW, float radius, int S, int consider_valid)
+{
+    __shared__ float win[256][LLB_WIN + 1];
+    __shared__ int wbase[256];
+    const long long p0 = (long long)blockIdx.x * 256, b = blockIdx.y;
+    const int tid = threadIdx.x;
+    {
+        const long long p = p0 + tid;
+#pragma unroll
+        for (int j = 0; j < LLB_WIN; ++j) win[tid][j] = 0.0f;
+        int base = 0;
+        if (p < HW) {
+            const long long t = b * HW + p;
+            const float *v = vol + (size_t)b * D * HW + p;
+            const float cur = disp[t], g = gout[t];
+            float lower = cur - radius, upper = cur + radius;
+            int invalid = -1;
+            float dl = 1.0f, du = 1.0f;  // d lower / d disp, d upper / d disp
+            if (consider_valid) {
+                invalid = (lower < 0.0f) || (upper >= (float)(D - 1));
+            } else {
+                if (lower < 0.0f) lower = 0.0f, dl = 0.0f;
+                if (upper < 0.0f) upper = 0.0f, du = 0.0f;
+                else if (upper > (float)D) upper = (float)D, du = 0.0f;
+            }
+            const float interval = __fdiv_rn(__fmul_rn(__fsub_rn(upper, lower), 1.0f), (float)S);
+            const float inv = invalid > 0 ? 1.0f : 0.0f;
+            float m = -INFINITY, s = 0.0f, e = 0.0f;
+            for (int k = 0; k <= S; ++k) {
+                float c = __fadd_rn(lower, __fmul_rn((float)k, interval));
+                if (invalid >= 0) c = __fadd_rn(__fmul_rn(c, 1.0f - inv), __fmul_rn(inv, cur));
+                const float val = sample_tap(v, (size_t)HW, D, c);
+                const float cm = fmaxf(m, val);
+                const float sc = (m == cm) ? 1.0f : fast_exp(m - cm);
+                const float pe = fast_exp(val - cm);
+                s = s * sc + pe;
+                e = e * sc + pe * c;
+                m = cm;
+            }
+            const float out = e / s, invs = 1.0f / s;
+            float gd = 0.0f;
+            bool first = true;
+            for (int k = 0; k <= S; ++k) {
+                float c = __fadd_rn(lower, __fmul_rn((float)k, interval));
+                if (invalid >= 0) c = __fadd_rn(__fmul_rn(c, 1.0f - inv), __fmul_rn(inv, cur));
+                const float cc = clampf(ste_ceil_f(c), 0.0f, (float)(D - 1));
+                const float cf = clampf(ste_floor_f(c), 0.0f, (float)(D - 1));
+                const int ic = (int)cc, ifl = (int)cf;
+                if (first) base = ifl < ic ? ifl : ic, first = false;   // candidates (hence taps) are monotone in k
+                const float fr = (float)ic - c, cr = 1.0f - fr;
+                const float vf = v[(size_t)ifl * HW], vc = v[(size_t)ic * HW];
+                const float pk = fast_exp(vf * fr + vc * cr - m) * invs;
+                const float a = g * pk * (c - out);
+                const int jf = ifl - base, jc = ic - base;               // inside the window by construction (launcher: radius)
+                if (jf >= 0 && jf < LLB_WIN) win[tid][jf] += a * fr;
+                if (jc >= 0 && jc < LLB_WIN) win[tid][jc] += a * cr;
+                const float dc = g * pk + a * (vc - vf);
+                float dcd;
+                if (consider_valid) {
+                    dcd = 1.0f;
+                } else {
+                    const float tk = (float)k / (float)S;
+                    dcd = (1.0f - tk) * dl + tk * du;
+                }
+                gd = fmaf(dc, dcd, gd);
+            }
+            gdisp[t] = gd;
+        }
+        wbase[tid] = base;
+    }
+    __syncthreads();
+    // dense write: wave w writes planes w, w + 4, ...; lane l the pixel quad 4 l .. 4 l + 3 of the block
+    const int wave = tid >> 6, lane = tid & 63;
+    const long long pq = p0 + 4 * lane;
+    if (pq < HW) {
+        int bs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bs[i] = wbase[4 * lane + i];
+        float *o = gvol + (size_t)b * D * HW + pq;
+        for (int d = wave; d < D; d += 4) {
+            f32x4 q;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = d - bs[i];
+                q[i] = (j >= 0 && j < LLB_WIN) ? win[4 * lane + i][j] : 0.0f;
+            }
+            st4(o + (size_t)d * HW, q);
+        }
     }
 }
 
@@ -639,7 +826,17 @@ extern "C" int stereo_soft_argmin_bwd_f32(const float *vol, const float *grad_di
 #define SAB(V, GP) \
     hipLaunchKernelGGL((soft_argmin_bwd_kernel<V, GP>), dim3(grid_for(n)), dim3(256), 0, st, vol, grad_disp, grad_prob, \
                        grad_vol, D, HW, n, sgn)
-    if (vec && grad_prob) SAB(4, true);
+    if (vec && !grad_prob && D <= 192 && fits_grid_yz(B) && aligned16(vol) && aligned16(grad_disp) && aligned16(grad_vol) &&
+        stereo_opt(OPT_PROB_SINGLE_PASS) != 0) {   // one pass over the volume: the softmax column in registers
+#define SAB_REGS(JV, NWVV, SPL)                                                                                             \
+    hipLaunchKernelGGL((soft_argmin_bwd_regs_kernel<JV, NWVV, SPL>),                                                        \
+                       dim3((unsigned)((HW / 4 + 64 / SPL - 1) / (64 / SPL)), (unsigned)B), dim3(NWVV * 64), 0, st, vol,    \
+                       grad_disp, grad_vol, D, HW, sgn)
+        if (D <= 48) SAB_REGS(12, 4, 1);
+        else if (D <= 96) SAB_REGS(24, 4, 1);
+        else SAB_REGS(24, 4, 2);
+#undef SAB_REGS
+    } else if (vec && grad_prob) SAB(4, true);
     else if (vec) SAB(4, false);
     else if (grad_prob) SAB(1, true);
     else SAB(1, false);
@@ -716,6 +913,28 @@ extern "C" int stereo_local_lookup_bwd_f32(const float *vol, const float *disp, 
     const long long HW = (long long)H * W, n = (long long)B * HW;
     hipLaunchKernelGGL(local_lookup_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), vol, disp, grad_out,
                        grad_vol_zeroed, grad_disp, D, HW, n, radius, S, consider_valid);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+extern "C" int stereo_local_lookup_bwd_dense_f32(const float *vol, const float *disp, const float *grad_out, float *grad_vol,
+                                                 float *grad_disp, int B, int D, int H, int W, float radius, int S,
+                                                 int consider_valid, void *stream)
+{
+    if (B < 0 || D < 0 || H < 0 || W < 0 || S <= 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0) return STEREO_OK;
+    if (D == 0) return STEREO_ERR_BAD_SHAPE;
+    STEREO_REQUIRE_PTR(vol);
+    STEREO_REQUIRE_PTR(disp);
+    STEREO_REQUIRE_PTR(grad_out);
+    STEREO_REQUIRE_PTR(grad_vol);
+    STEREO_REQUIRE_PTR(grad_disp);
+    const long long HW = (long long)H * W;
+    // window of touched planes: floor(lower) .. ceil(upper) <= 2 radius + 3 planes
+    if (!(radius >= 0.0f) || 2.0f * radius + 3.0f > (float)LLB_WIN || HW % 4 != 0 || !aligned16(grad_vol) || !fits_grid_yz(B))
+        return STEREO_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(local_lookup_bwd_dense_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)B), dim3(256), 0,
+                       as_stream(stream), vol, disp, grad_out, grad_vol, grad_disp, D, HW, radius, S, consider_valid);
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }

@@ -38,11 +38,20 @@ class _LocalLookupFn(torch.autograd.Function):
         radius, S, cv = ctx.cfg
         B, D, H, W = vol.shape
         go = N.dev_f32(grad_out, "LocalCostVolume backward: grad")
-        gvol = torch.zeros_like(vol)      # taps are accumulated into it
         gdisp = torch.empty_like(disp)
         with torch.cuda.device(vol.device):
-            N.call("stereo_local_lookup_bwd_f32", N.ptr(vol), N.ptr(disp), N.ptr(go), N.ptr(gvol), N.ptr(gdisp), B, D, H,
-                   W, radius, S, 1 if cv else 0, N.stream_ptr(vol.device))
+            # the dense form writes every element of the gradient volume itself (one pass at the store rate); wide radii /
+            # ragged H*W take the zero-fill + accumulate form
+            gvol = torch.empty_like(vol)
+            try:
+                N.call("stereo_local_lookup_bwd_dense_f32", N.ptr(vol), N.ptr(disp), N.ptr(go), N.ptr(gvol), N.ptr(gdisp), B, D,
+                       H, W, radius, S, 1 if cv else 0, N.stream_ptr(vol.device))
+            except N.StereoHipError as e:
+                if e.code != N.ERR_UNSUPPORTED:
+                    raise
+                gvol.zero_()
+                N.call("stereo_local_lookup_bwd_f32", N.ptr(vol), N.ptr(disp), N.ptr(go), N.ptr(gvol), N.ptr(gdisp), B, D, H,
+                       W, radius, S, 1 if cv else 0, N.stream_ptr(vol.device))
         return gvol, gdisp, None, None, None
 
 

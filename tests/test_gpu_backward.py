@@ -446,3 +446,53 @@ def test_alternate_corr_block_under_grad(S):
     bad[:, 1] += 0.25
     with pytest.raises(RuntimeError, match="own row"):
         S.PytorchAlternateCorrBlock1D(a1, a2, 4, 4)(bad)
+
+
+@pytest.mark.parametrize("D", [7, 48, 100, 192])
+def test_soft_argmin_backward_single_pass_vs_two_pass_vs_torch(S, D):
+    """A4's backward with the softmax column held in registers (one read of the volume, one write of the gradient) against the
+    two-pass kernel (test hook) and torch's own autograd of softmax-expectation, both similarity signs, ragged last block."""
+    torch.manual_seed(700 + D)
+    B, H, W = 2, 5, 52
+    for sim in (True, False):
+        v = (torch.randn(B, D, H, W, device="cuda") * 3).requires_grad_(True)
+        cot = torch.randn(B, H, W, device="cuda")
+        (g1,) = torch.autograd.grad(S.DisparityEstimation(D, sim)(v), v, cot)
+        with S._native.test_options(prob_single_pass=0):
+            (g2,) = torch.autograd.grad(S.DisparityEstimation(D, sim)(v), v, cot)
+        x = v.detach().double().requires_grad_(True)
+        p = torch.softmax(x if sim else -x, 1)
+        ref = (p * torch.arange(D, device="cuda", dtype=torch.float64).view(1, D, 1, 1)).sum(1)
+        (g3,) = torch.autograd.grad(ref, x, cot.double())
+        assert float((g1 - g2).abs().max()) <= 5e-6 * max(1.0, float(g2.abs().max()))   # (fp32 summation order of the expectation)
+        assert float((g1.double() - g3).abs().max()) <= 2e-5 * max(1.0, float(g3.abs().max()))
+
+
+@pytest.mark.parametrize("cfg", [(2, 24, 6, 20, 2.0, 20, True), (1, 48, 3, 52, 4.0, 10, False), (2, 12, 5, 8, 6.0, 7, True),
+                                 (1, 30, 7, 36, 0.0, 3, False), (1, 20, 3, 7, 2.0, 20, True), (1, 40, 2, 12, 9.0, 12, True)])
+def test_local_lookup_backward_dense_vs_accumulate(S, cfg):
+    """LocalCostVolume's backward writes the gradient volume densely in one launch (2 r + 3 <= 16, H*W % 4 == 0); the zero-fill +
+    accumulate kernel serves the rest: both must agree (same per-pixel arithmetic), incl. disparities at / beyond the volume's
+    ends and both validity modes."""
+    from stereoformer_amd import _native as N
+    B, D, H, W, radius, Sp, cv = cfg
+    torch.manual_seed(800 + D)
+    vol = torch.randn(B, D, H, W, device="cuda") * 2
+    disp = torch.rand(B, 1, H, W, device="cuda") * (D + 4) - 2
+    go = torch.randn(B, 1, H, W, device="cuda")
+    a, ad = torch.zeros_like(vol), torch.empty_like(disp)
+    N.call("stereo_local_lookup_bwd_f32", N.ptr(vol), N.ptr(disp), N.ptr(go), N.ptr(a), N.ptr(ad), B, D, H, W, radius, Sp, int(cv),
+           N.stream_ptr())
+    v = vol.clone().requires_grad_(True)
+    d = disp.clone().requires_grad_(True)
+    gv, gd = torch.autograd.grad(S.LocalCostVolume(radius, Sp)(v, d, cv), (v, d), go)
+    assert float((gv - a).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max())) and float((gd - ad).abs().max()) <= 1e-6 * max(1.0, float(ad.abs().max()))
+    if 2 * radius + 3 <= 16 and (H * W) % 4 == 0:      # the dense kernel took it: check it directly too
+        b_, bd = torch.full_like(vol, float("nan")), torch.empty_like(disp)
+        N.call("stereo_local_lookup_bwd_dense_f32", N.ptr(vol), N.ptr(disp), N.ptr(go), N.ptr(b_), N.ptr(bd), B, D, H, W, radius, Sp,
+               int(cv), N.stream_ptr())
+        assert torch.isfinite(b_).all() and float((b_ - a).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max()))
+    else:
+        with pytest.raises(N.StereoHipError):
+            N.call("stereo_local_lookup_bwd_dense_f32", N.ptr(vol), N.ptr(disp), N.ptr(go), N.ptr(a), N.ptr(ad), B, D, H, W, radius,
+                   Sp, int(cv), N.stream_ptr())
