@@ -234,7 +234,99 @@ def _guard(fn):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def cpu_train_step_torch(C, H, W, D, G, rows):
+    """BASELINE LEG ONLY ('port'): the cfg-2 training step on `rows` image rows of ONE pair in plain torch-CPU ops under autograd,
+    following the reference's own formulations -- build_gwc_volume's per-disparity loop (GWC_Cost_Volume.py:5-24), mean over the
+    groups, softmax expectation (estimation.py:7-35), LocalCostVolume's candidate sampling with straight-through ceil / floor
+    (fixed_local_cost_volume.py:13-80) -- forward + backward w.r.t. both feature maps; seconds scaled to the full H rows."""
+    torch.manual_seed(0)
+    L = torch.randn(1, C, rows, W, requires_grad=True)
+    R = torch.randn(1, C, rows, W, requires_grad=True)
+    t0 = time.perf_counter()
+    vol = L.new_zeros(1, G, D, rows, W)
+    cpg = C // G
+    for d in range(D):
+        if d > 0:
+            vol[:, :, d, :, d:] = (L[..., d:] * R[..., :-d]).view(1, G, cpg, rows, W - d).mean(2)
+        else:
+            vol[:, :, d] = (L * R).view(1, G, cpg, rows, W).mean(2)
+    mean = vol.mean(1)
+    disp = (torch.softmax(mean, 1) * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)).sum(1, keepdim=True)
+    radius, S_ = 2.0, 20
+    lower, upper = disp - radius, disp + radius
+    invalid = ((lower < 0) | (upper >= D - 1)).float()
+    cand = lower + (upper - lower) / S_ * torch.arange(S_ + 1, dtype=torch.float32).view(1, S_ + 1, 1, 1)
+    cand = cand * (1 - invalid) + invalid * disp
+    ce = (torch.ceil(cand) - cand).detach() + cand
+    fl = (torch.floor(cand) - cand).detach() + cand
+    ce, fl = ce.clamp(0, D - 1), fl.clamp(0, D - 1)
+    fr = ce - cand
+    val = torch.gather(mean, 1, fl.long()) * fr + torch.gather(mean, 1, ce.long()) * (1 - fr)
+    out = (torch.softmax(val, 1) * cand).sum(1)
+    torch.autograd.grad(out.mean(), (L, R))
+    return (time.perf_counter() - t0) * H / rows
+
+
 # ----------------------------------------------------------------------------------------------------------- configs
+def cfg2_train(dev, rank, world, steps, warmup, cpu):
+    """The cfg-2 chain as a TRAINING step (the reference's train_low.py:44-76 trains this head): features ->
+    fused volume stage (group-wise volume + group mean + soft-argmin) -> LocalCostVolume -> scalar loss -> gradients w.r.t. both
+    feature maps, 2 pairs per GPU (the group-wise volume and its transient gradient state are 6.4 GB per pair)."""
+    B, C, H, W, D, G = 2, 32, 540, 960, 192, 8
+    g = torch.Generator(device=dev).manual_seed(200 + rank)
+    L = torch.randn(B, C, H, W, device=dev, generator=g)
+    R = torch.roll(L, 9, 3) + 0.1 * torch.randn(B, C, H, W, device=dev, generator=g)
+    lk = S.LocalCostVolume(2, 20)
+
+    def step():
+        with torch.enable_grad():
+            Lt, Rt = L.detach().requires_grad_(True), R.detach().requires_grad_(True)
+            _, dsp, mean = S.build_gwc_volume_with_disparity(Lt, Rt, D, G, return_mean=True)
+            out = lk(mean, dsp.unsqueeze(1), True)
+            return torch.autograd.grad(out.mean(), (Lt, Rt))
+
+    sec, per_rank = timed(step, steps, warmup, world, dev)
+    roof = None
+    if rank == 0:
+        with torch.no_grad():
+            ms_f = event_ms(lambda: S.build_gwc_volume_with_disparity(L, R, D, G, return_mean=True))
+        vd = S.CostVolume(D)(L, R).detach().requires_grad_(True)
+        with torch.enable_grad():
+            dsp = S.DisparityEstimation(D)(vd)
+        cd = torch.randn_like(dsp)
+
+        def a4_bwd():
+            with torch.enable_grad():
+                torch.autograd.grad(dsp, vd, cd, retain_graph=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a4_bwd()
+        e0.record()
+        for _ in range(5):
+            a4_bwd()
+        e1.record()
+        torch.cuda.synchronize()
+        ms_b = e0.elapsed_time(e1) / 5
+        n = B * H * W
+        gb_f = (2 * n * C * 4 + n * G * D * 4 + n * D * 4 + n * 4) / 1e9
+        gb_b = (2 * n * D * 4 + n * 4) / 1e9
+        roof = {"bound": "hbm", "kernel": "corr_volume_mfma_kernel (the fused volume stage, forward of the step: the group-wise "
+                                          "volume is written once and never read back -- its backward runs through the mean volume)",
+                "achieved": round(gb_f / ms_f * 1e3, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gb_f / ms_f * 1e3 / 8000.0, 4),
+                "traffic": None, "avg_launch_ms": round(ms_f, 4), "algorithmic_bytes": int(gb_f * 1e9),
+                "backward_kernels": {"soft_argmin_bwd_regs_kernel (A4 backward, one read + one write of the mean volume)":
+                                     {"avg_launch_ms": round(ms_b, 4), "GB/s": round(gb_b / ms_b * 1e3, 1),
+                                      "frac": round(gb_b / ms_b * 1e3 / 8000.0, 4)}}}
+        del vd, dsp, cd
+    cb = None
+    if cpu and rank == 0:
+        cb = _guard(lambda: _cpu_entry(cpu_train_step_torch(C, H, W, D, G, 40),
+                                       "forward + backward of the step on 40 of the 540 rows of 1 pair (rows are independent), scaled "
+                                       "x13.5; plain torch-CPU ops under autograd in the reference's own formulation"))
+    return entry("cfg-2 (training step)", "SceneFlow 960x540 D=192: features -> group-wise volume + group mean + soft-argmin (one fused "
+                 "launch) -> LocalCostVolume -> loss, forward + backward w.r.t. both feature maps, batch=2 per GPU, fp32", B, world,
+                 sec, per_rank, steps, warmup, roof, cb, {"unit_note": "pairs/s = training pairs per second (forward + backward)"})
+
+
 def cfg3(dev, rank, world, steps, warmup, cpu):
     B, C, H, W, D = 8, 32, 540, 960, 192
     g = torch.Generator(device=dev).manual_seed(300 + rank)
@@ -411,7 +503,8 @@ def run_all(dev, rank=0, world=1, cpu=False, rehearsal=False, steps=3, warmup=2,
     """Compact entries for cfg-3/4/5.  A failing config is reported in place, it never raises into the headline line."""
     want = lambda n: only is None or only in n
     out = []
-    for name, fn in (("cfg3", lambda: [cfg3(dev, rank, world, max(steps, 10), warmup, cpu)]),
+    for name, fn in (("cfg2train", lambda: [cfg2_train(dev, rank, world, max(steps, 5), warmup, cpu)]),
+                     ("cfg3", lambda: [cfg3(dev, rank, world, max(steps, 10), warmup, cpu)]),
                      ("cfg4", lambda: cfg4(dev, rank, world, steps, warmup, cpu, mixed)),
                      ("cfg5", lambda: [cfg5(dev, rank, world, steps, warmup, cpu)])):
         if not want(name):

@@ -312,6 +312,31 @@ def main():
                 timeit(lambda: torch.autograd.grad(vg, (L1g, R1g), cg, retain_graph=True), 3, 1),
                 (2 * n2 * G * D * 4 + 4 * n2 * C * 4) / 1e9)
             del vg, cg
+            # the backward paths added in round 2 (A6, A2, A7 by composition), one pair
+            v1 = S.CostVolume(D)(L[:1], R[:1]).detach().requires_grad_(True)
+            d6 = S.DisparityEstimation(D)(v1.detach()).unsqueeze(1).requires_grad_(True)
+            o6 = S.Variance_Based_Local_Cost_Volume(1, 20)(v1, d6, True)
+            c6 = torch.randn_like(o6)
+            n1 = H * W
+            add("bwd A6 variance-based lookup, 1 pair (incl. zero-fill of grad volume)",
+                timeit(lambda: torch.autograd.grad(o6, (v1, d6), c6, retain_graph=True), 5, 1), (2 * n1 * D * 4 + 4 * n1 * 4) / 1e9)
+            del v1, d6, o6, c6
+            La, Ra = L[:1, :8].detach().requires_grad_(True), R[:1, :8].detach().requires_grad_(True)
+            for kind in ("difference", "concat"):
+                va = S.CostVolume(D, kind)(La, Ra)
+                ca = torch.randn_like(va)
+                add(f"bwd A2 {kind} volume, 1 pair, 8 channels (dL + dR)",
+                    timeit(lambda: torch.autograd.grad(va, (La, Ra), ca, retain_graph=True), 3, 1),
+                    (va.numel() * 4 + 4 * n1 * 8 * 4) / 1e9)
+                del va, ca
+            Lq, Rq = L[:1].detach().requires_grad_(True), R[:1].detach().requires_grad_(True)
+            att = S.CrossAttentionCostVolume(D, "zero", "sqrt_c")
+            oq, dq = att(Lq, Rq)
+            cq, cdq = torch.randn_like(oq), torch.randn_like(dq)
+            add("bwd A7 cross-attention under grad (composition of A1 forward / backward kernels), 1 pair fwd+bwd",
+                timeit(lambda: torch.autograd.grad(att(Lq, Rq), (Lq, Rq), (cq, cdq)), 3, 1), None,
+                note="materialises the [1,D,H,W] score volume (training path; inference uses the fused kernel)")
+            del oq, dq, cq, cdq
             # one training step of the cfg-2 chain at B=2 (features -> volume stage -> local lookup -> scalar loss)
             lk = S.LocalCostVolume(2, 20)
 
