@@ -372,6 +372,10 @@ int stereo_conv_nhwc_f16(const void *const *srcs, const int *src_channels, int n
  *                                   bits), the three leading piece products (each exact in fp32) into two fp32 accumulators:
  *                                   fp32-faithful for |x| < 65 504 (inf / NaN beyond, never silently wrong), HALF the matrix
  *                                   work of the bf16 form.  The host layer's default for fp32 activations.
+ *           STEREO_CONV_F32_F16X3S  the same three products into ONE accumulator: every output channel's weights are pre-scaled
+ *                                   by a power of two (max into [2^13, 2^14)) and packed as three fp16 pieces (hi, unscaled
+ *                                   lo, 2^-11 hi), the epilogue undoes the scale; wave tile 4 x 2 blocks (8-row pixel tiles):
+ *                                   half the LDS operand traffic per MFMA -- the host layer's choice for large images
  *           STEREO_CONV_F32_BF16X6  = stereo_conv_nhwc_f32 (three bf16 pieces, six products: fp32's full exponent range)
  *           STEREO_CONV_F32_BF16X3  = stereo_conv_nhwc_f32_bf16x3        STEREO_CONV_F16  = stereo_conv_nhwc_f16
  *           (`packed` must come from stereo_conv_pack_weights_ex with the same `arith`.)
@@ -387,6 +391,7 @@ int stereo_conv_nhwc_f16(const void *const *srcs, const int *src_channels, int n
 #define STEREO_CONV_F32_BF16X3 1
 #define STEREO_CONV_F16 2
 #define STEREO_CONV_F32_F16X3 3
+#define STEREO_CONV_F32_F16X3S 4
 #define STEREO_EPI_LINEAR 0
 #define STEREO_EPI_SIGMOID 1
 #define STEREO_EPI_SIGMOID_MUL 2

@@ -67,7 +67,7 @@ struct ConvAr<STEREO_CONV_F32_BF16X6> {
     typedef float tin;
     typedef bf16x8 frag;
     typedef __bf16 welem;
-    static constexpr int NP = 3, NPROD = 6, NACC = 1;
+    static constexpr int NP = 3, NPB = 3, NPROD = 6, NACC = 1;
     // smallest first: (a1 b1) (a0 b2) (a2 b0) (a0 b1) (a1 b0) (a0 b0)
     static constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0}, PC[6] = {0, 0, 0, 0, 0, 0};
     static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
@@ -77,7 +77,7 @@ struct ConvAr<STEREO_CONV_F32_BF16X3> {
     typedef float tin;
     typedef bf16x8 frag;
     typedef __bf16 welem;
-    static constexpr int NP = 2, NPROD = 3, NACC = 1;
+    static constexpr int NP = 2, NPB = 2, NPROD = 3, NACC = 1;
     static constexpr int PA[6] = {0, 1, 0, 0, 0, 0}, PB[6] = {1, 0, 0, 0, 0, 0}, PC[6] = {0, 0, 0, 0, 0, 0};
     static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
@@ -86,7 +86,7 @@ struct ConvAr<STEREO_CONV_F16> {
     typedef f16 tin;
     typedef f16x8 frag;
     typedef _Float16 welem;
-    static constexpr int NP = 1, NPROD = 1, NACC = 1;
+    static constexpr int NP = 1, NPB = 1, NPROD = 1, NACC = 1;
     static constexpr int PA[6] = {0, 0, 0, 0, 0, 0}, PB[6] = {0, 0, 0, 0, 0, 0}, PC[6] = {0, 0, 0, 0, 0, 0};
     static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
@@ -95,7 +95,7 @@ struct ConvAr<STEREO_CONV_F32_F16X3> {
     typedef float tin;
     typedef f16x8 frag;
     typedef _Float16 welem;
-    static constexpr int NP = 2, NPROD = 3, NACC = 2;
+    static constexpr int NP = 2, NPB = 2, NPROD = 3, NACC = 2;
     // the two products of accumulator 1 are separated by the one of accumulator 0 (no back-to-back dependent MFMAs)
     static constexpr int PA[6] = {0, 0, 1, 0, 0, 0}, PB[6] = {1, 0, 0, 0, 0, 0}, PC[6] = {1, 0, 1, 0, 0, 0};
     static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
@@ -110,6 +110,23 @@ __device__ __forceinline__ void static_for(F &&f)
         static_for<I + 1, N>(f);
     }
 }
+// F32_F16X3S: the same three products into ONE accumulator -- which frees the registers for a wave tile of 4 M blocks x 2 N
+// blocks (8-row pixel tile, 64 channels per wave): half the LDS fragment reads per MFMA of the 4 x 1 tile above.  What makes
+// one accumulator possible is that the WEIGHTS are ours to scale: output channel n's weights are multiplied by 2^k[n] (exact)
+// so that their maximum lies in [2^13, 2^14), and packed as THREE fp16 pieces b0 = fp16(w'), b1 = fp16(w' - b0) (unscaled: a
+// normal fp16 wherever |w'| >= 2^-3, i.e. down to 2^-17 of the channel's largest weight) and b2 = 2^-11 b0 (exact above the
+// same threshold).  With the activation pieces a0 = fp16(x), a1 = fp16(2^11 (x - a0)) the products a0 b0, a0 b1 and a1 b2 =
+// (x - a0) b0 all carry the scale 2^k[n]; the epilogue multiplies by 2^-k[n] (exact).  Same error budget as F32_F16X3.
+template <>
+struct ConvAr<STEREO_CONV_F32_F16X3S> {
+    typedef float tin;
+    typedef f16x8 frag;
+    typedef _Float16 welem;
+    static constexpr int NP = 2, NPB = 3, NPROD = 3, NACC = 1;
+    // (per block the two N blocks' chains are interleaved by `products`, so dependent MFMAs are two apart)
+    static constexpr int PA[6] = {0, 1, 0, 0, 0, 0}, PB[6] = {1, 2, 0, 0, 0, 0}, PC[6] = {0, 0, 0, 0, 0, 0};
+    static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 constexpr float CV_LO_UNSCALE = SPLIT16_LO_UNSCALE;
 
 // eight fp32 values -> the form's NP operands
@@ -121,8 +138,46 @@ __device__ __forceinline__ void conv_split_oct(const float *x, typename ConvAr<A
     } else if constexpr (AR == STEREO_CONV_F16) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) p[0][j] = (_Float16)x[j];
+    } else if constexpr (AR == STEREO_CONV_F32_F16X3S) {   // weights (already scaled by 2^k[n]): b0, b1 = unscaled low piece, b2 = 2^-11 b0
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const _Float16 b0 = (_Float16)x[j];
+            p[0][j] = b0;
+            p[1][j] = (_Float16)(x[j] - (float)b0);
+            p[2][j] = (_Float16)((float)b0 * SPLIT16_LO_UNSCALE);
+        }
     } else {
         split_oct_f16(x, p);
+    }
+}
+
+// F32_F16X3S: per output channel the power of two that brings its largest |weight| into [2^13, 2^14) -- wscale[n] = 2^k[n] for
+// the packing kernel, wscale[Cpad + n] = 2^-k[n] for the convolution's epilogue.  One workgroup per channel.
+__global__ __launch_bounds__(256) void conv_wscale_kernel(const float *__restrict__ w, float *__restrict__ wscale, int Cout, int Cpad,
+                                                          int per_channel)
+{
+    __shared__ float red[256];
+    const int n = blockIdx.x;
+    float m = 0.0f;
+    if (n < Cout)
+        for (int i = threadIdx.x; i < per_channel; i += 256) m = fmaxf(m, fabsf(w[(size_t)n * per_channel + i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int k = 0;
+        const float mx = red[0];
+        if (mx > 0.0f && mx < INFINITY) {
+            int e;
+            frexpf(mx, &e);              // mx = f 2^e, f in [0.5, 1)  ->  mx 2^(14 - e) in [2^13, 2^14)
+            k = 14 - e;
+            k = k > 100 ? 100 : (k < -100 ? -100 : k);
+        }
+        wscale[n] = ldexpf(1.0f, k);
+        wscale[Cpad + n] = ldexpf(1.0f, -k);
     }
 }
 
@@ -131,10 +186,10 @@ __device__ __forceinline__ void conv_split_oct(const float *x, typename ConvAr<A
 // the pieces of the form (F16: the weight rounded to fp16, what autocast hands the library)
 template <int AR>
 __global__ void conv_pack_kernel(const float *__restrict__ w, typename ConvAr<AR>::welem *__restrict__ packed, int Cout, int Cin,
-                                 int taps, int NB)
+                                 int taps, int NB, const float *__restrict__ wscale)
 {
     typedef ConvAr<AR> Ar;
-    constexpr int NP = Ar::NP;
+    constexpr int NP = Ar::NPB;
     const long long total = (long long)(Cin / 16) * taps * NB * 64;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -148,6 +203,7 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, typename ConvAr<AR
     for (int j = 0; j < 8; ++j) {
         const int c = 16 * chunk + 8 * (lane >> 5) + j;
         x[j] = n < Cout ? w[((size_t)n * Cin + c) * taps + tap] : 0.0f;
+        if constexpr (AR == STEREO_CONV_F32_F16X3S) x[j] *= wscale[n];     // (exact: a power of two)
     }
     const size_t base = ((((size_t)chunk * taps + tap) * NB + nb) * NP) * 64 + lane;
     typename Ar::frag pc[NP];
@@ -159,7 +215,7 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, typename ConvAr<AR
 template <int AR>
 constexpr int conv_min_wg_per_cu()
 {
-    return AR == STEREO_CONV_F16 ? 2 : (AR == STEREO_CONV_F32_F16X3 ? 2 : 4);
+    return AR == STEREO_CONV_F16 ? 2 : ((AR == STEREO_CONV_F32_F16X3 || AR == STEREO_CONV_F32_F16X3S) ? 2 : 4);
 }
 
 template <int KS, int TH, int AR>
@@ -167,13 +223,14 @@ __global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kern
                                                                                     const typename ConvAr<AR>::welem *__restrict__ packed,
                                                                                     const float *__restrict__ bias, ConvDsts dst, int relu,
                                                                                     int H, int W, int tiles_x, int tiles_y, int NB, int Cout,
-                                                                                    int ntn, int nbatch, int tiles_per_xcd)
+                                                                                    int ntn, int nbatch, int tiles_per_xcd,
+                                                                                    const float *__restrict__ oscale)
 {
     typedef ConvAr<AR> Ar;
     typedef typename Ar::tin TIN;
     typedef typename Ar::frag frag;
     typedef typename Ar::welem welem;
-    constexpr int NP = Ar::NP, NPROD = Ar::NPROD, NACC = Ar::NACC;
+    constexpr int NP = Ar::NP, NPB = Ar::NPB, NPROD = Ar::NPROD, NACC = Ar::NACC;   // A pieces (LDS image), B pieces (weights)
     constexpr int ES = (int)sizeof(TIN), QCH = 16 / ES, QPP = 16 / QCH;   // channels per 16-B quad, quads per pixel and chunk
     constexpr int HALO = KS / 2, TAPS = KS * KS;
     constexpr int WN = TH == 8 ? 2 : 4;          // waves along the output channels (the other 4 / WN along the rows)
@@ -190,7 +247,7 @@ __global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kern
     // PIPE (the split-fp16 form: three MFMAs per fragment pair, two waves per SIMD -- too little of either to hide an LDS
     // round trip behind): two chunk images in LDS, ONE barrier per chunk, A fragments fetched a block ahead and B fragments a
     // tap ahead of the MFMAs that use them
-    constexpr bool PIPE = AR == STEREO_CONV_F32_F16X3;
+    constexpr bool PIPE = AR == STEREO_CONV_F32_F16X3 || AR == STEREO_CONV_F32_F16X3S;
     constexpr int IMG = NP * PS;                 // one chunk image
     __shared__ __attribute__((aligned(16))) char img[(PIPE ? 2 : 1) * IMG];
 
@@ -247,7 +304,7 @@ __global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kern
                     split_pair<NP>((f32x2){v[2], v[3]}, c);
 #pragma unroll
                     for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4 *>(im + p * PS + lw[i]) = cat2(a[p], c[p]);
-                } else if constexpr (AR == STEREO_CONV_F32_F16X3) {
+                } else if constexpr (AR == STEREO_CONV_F32_F16X3 || AR == STEREO_CONV_F32_F16X3S) {
                     const f32x4 v = __builtin_bit_cast(f32x4, rk[i]);
                     f16x2 a[2], c[2];
                     split_pair_f16((f32x2){v[0], v[1]}, a);
@@ -283,8 +340,8 @@ __global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kern
     // A fragment of (mb, tap (ky, kx), piece p): that pixel shifted by the tap in the halo tile, channels 8 half ..
     const char *abase = img + (4 * wm + (l31 >> 4)) * ROWB + (l31 & 15) * CV_PXB + half * 16;
     // B fragments of this wave: n blocks 4 nt + NBW wn + {0 .. NBW - 1}
-    const welem *wbase = packed + ((size_t)(4 * nt + NBW * wn) * NP * 64 + lane) * 8;
-    const size_t kstep = (size_t)NB * NP * 64 * 8;   // elements per k-step (one tap of one chunk)
+    const welem *wbase = packed + ((size_t)(4 * nt + NBW * wn) * NPB * 64 + lane) * 8;
+    const size_t kstep = (size_t)NB * NPB * 64 * 8;   // elements per k-step (one tap of one chunk)
 
     // which of this wave's four M blocks lie inside the image (wave-uniform): all of them (the common case), the left column
     // half only (last tile of a row whose width is 16 mod 32), or some other subset (bottom edge).  The K loop -- and with it
@@ -304,11 +361,11 @@ __global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kern
     }
 
     // one chunk's 9 taps; MODE selects the M blocks.
-    auto load_b = [&](frag (&bf)[NBW][NP], const welem *wt) {
+    auto load_b = [&](frag (&bf)[NBW][NPB], const welem *wt) {
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) bf[nb][p] = *reinterpret_cast<const frag *>(wt + ((size_t)nb * NP + p) * 64 * 8);
+            for (int p = 0; p < NPB; ++p) bf[nb][p] = *reinterpret_cast<const frag *>(wt + ((size_t)nb * NPB + p) * 64 * 8);
     };
     auto load_a = [&](frag (&af)[NP], int buf, int mb, int ky, int kx) {
 #pragma unroll
@@ -316,14 +373,14 @@ __global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kern
             af[p] = *reinterpret_cast<const frag *>(abase + buf * IMG + p * PS + (2 * (mb >> 1) + ky) * ROWB +
                                                     (16 * (mb & 1) + kx) * CV_PXB);
     };
-    auto products = [&](int m0, const frag (&a0)[NP], const frag (&bf)[NBW][NP]) {
+    auto products = [&](int m0, const frag (&a0)[NP], const frag (&bf)[NBW][NPB]) {
 #pragma unroll
         for (int q = 0; q < NPROD; ++q)
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb)
                 acc[m0][nb][Ar::PC[q]] = Ar::mma(a0[Ar::PA[q]], bf[nb][Ar::PB[q]], acc[m0][nb][Ar::PC[q]]);
     };
-    auto single = [&](int m0, int ky, int kx, const frag (&bf)[NBW][NP]) {
+    auto single = [&](int m0, int ky, int kx, const frag (&bf)[NBW][NPB]) {
         frag a0[NP];
         load_a(a0, 0, m0, ky, kx);
         products(m0, a0, bf);
@@ -333,7 +390,7 @@ __global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kern
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int ky = tap / KS, kx = tap % KS;
-            frag bc[NBW][NP];
+            frag bc[NBW][NPB];
             load_b(bc, wk + (size_t)tap * kstep);
             if (MODE == 0) {
 #pragma unroll
@@ -373,7 +430,7 @@ __global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kern
     auto run_pipe = [&](auto mode_tag) {
         constexpr int MODE = decltype(mode_tag)::value;   // 0: all four M blocks; 1: blocks 0 and 2
         constexpr int NBLK = MODE == 0 ? 4 : 2, BSTEP = MODE == 0 ? 1 : 2, NSTEP = TAPS * NBLK;
-        frag bq[2][NBW][NP], aq[2][NP];
+        frag bq[2][NBW][NPB], aq[2][NP];
         issue();
         load_b(bq[0], wbase);
         commit(0);
@@ -408,7 +465,7 @@ __global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kern
 #pragma unroll
                 for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
-                    for (int p = 0; p < NP; ++p) bq[0][nb][p] = bq[1][nb][p];
+                    for (int p = 0; p < NPB; ++p) bq[0][nb][p] = bq[1][nb][p];
             }
             __syncthreads();   // every wave is done with image `cur`; the commits into the other one are visible
         }
@@ -440,6 +497,8 @@ __global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kern
         const TIN *a1p = dst.aux1[gb] ? static_cast<const TIN *>(dst.aux1[gb]) + obase : nullptr;
         const int cg = 32 * gb + l31;
         const float bv = (bias != nullptr && cg < Cout) ? bias[cg] : 0.0f;
+        float osc = 1.0f;       // F32_F16X3S: 2^-k of this output channel
+        if constexpr (AR == STEREO_CONV_F32_F16X3S) osc = oscale[cg];
         if (l31 < nvalid) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
@@ -465,6 +524,7 @@ __global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kern
                         const int r = rh + j;
                         float v = acc[mb][nb][0][r];
                         if constexpr (NACC == 2) v = fmaf(acc[mb][nb][1][r], CV_LO_UNSCALE, v);
+                        if constexpr (AR == STEREO_CONV_F32_F16X3S) v *= osc;
                         v = (v + bv) + ad[j];
                         if constexpr (EPI == STEREO_EPI_LINEAR) {
                             if (relu) v = fmaxf(v, 0.0f);
@@ -697,11 +757,17 @@ extern "C" int stereo_conv3x3_small_nhwc_f16(const void *x, const float *weight_
 namespace {
 
 template <int AR>
+long long weight_bytes(int Cin, int ksize, long long NB)
+{
+    return (long long)(Cin / 16) * ksize * ksize * NB * ConvAr<AR>::NPB * 64 * 8 * 2;
+}
+
+template <int AR>
 long long packed_bytes(int Cout, int Cin, int ksize)
 {
     if (Cout < 1 || Cin < 16 || Cin % 16 != 0 || (ksize != 1 && ksize != 3)) return 0;
     const long long NB = 4LL * ((Cout + 127) / 128);
-    return (long long)(Cin / 16) * ksize * ksize * NB * ConvAr<AR>::NP * 64 * 8 * 2;
+    return weight_bytes<AR>(Cin, ksize, NB) + (AR == STEREO_CONV_F32_F16X3S ? 2LL * NB * 32 * 4 : 0);   // (+ the channel scales)
 }
 
 template <int AR>
@@ -713,8 +779,14 @@ int pack_weights(const float *weight, void *packed, int Cout, int Cin, int ksize
     if (!aligned16(packed)) return STEREO_ERR_UNSUPPORTED;
     const int NB = 4 * ((Cout + 127) / 128), taps = ksize * ksize;
     const long long total = (long long)(Cin / 16) * taps * NB * 64;
+    float *wscale = nullptr;
+    if (AR == STEREO_CONV_F32_F16X3S) {   // channel scales behind the weights: [2^k | 2^-k] x (NB * 32)
+        wscale = reinterpret_cast<float *>(static_cast<char *>(packed) + weight_bytes<AR>(Cin, ksize, NB));
+        hipLaunchKernelGGL(conv_wscale_kernel, dim3((unsigned)(NB * 32)), dim3(256), 0, as_stream(stream), weight, wscale, Cout,
+                           NB * 32, Cin * taps);
+    }
     hipLaunchKernelGGL((conv_pack_kernel<AR>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), weight,
-                       static_cast<typename ConvAr<AR>::welem *>(packed), Cout, Cin, taps, NB);
+                       static_cast<typename ConvAr<AR>::welem *>(packed), Cout, Cin, taps, NB, wscale);
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }
@@ -734,7 +806,9 @@ int conv_nhwc(const void *const *srcs, const int *src_channels, int nsrc, const 
     ConvSrcs s{};
     ConvDsts d{};
     s.n = nsrc;
+    int csum = 0;   // input channels of the launch (= the packed weights' Cin)
     for (int i = 0; i < nsrc; ++i) {
+        csum += src_channels[i];
         STEREO_REQUIRE_PTR(srcs[i]);
         if (src_channels[i] < 16 || src_channels[i] % 16 != 0) return STEREO_ERR_UNSUPPORTED;
         if (!aligned16(srcs[i]) || (long long)H * W * src_channels[i] * (long long)sizeof(TIN) >= (1LL << 31))
@@ -779,16 +853,19 @@ int conv_nhwc(const void *const *srcs, const int *src_channels, int nsrc, const 
     // at the large shapes and 7-18 % behind at 1/8 and 1/16 scale: finer workgroups spread a launch more evenly over the chip)
     // (fp16 activations: one MFMA per fragment instead of six makes the 4-row shape LDS-bound -- every A fragment feeds a single
     // MFMA; the 8-row shape, a wave = 4 rows x 64 channels, halves the fragment reads per MFMA)
-    constexpr int th = sizeof(TIN) == 4 ? 4 : 8;
+    constexpr int th = (sizeof(TIN) == 4 && AR != STEREO_CONV_F32_F16X3S) ? 4 : 8;
     const int tiles_y = (H + th - 1) / th;
     const long long nt = (long long)tiles_x * tiles_y * B;
     const long long per_xcd = (nt + 7) / 8;
     if (per_xcd * 8 * ntn >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
     dim3 grid((unsigned)(per_xcd * 8 * ntn));
     typedef typename ConvAr<AR>::welem welem;
+    const float *oscale = nullptr;
+    if (AR == STEREO_CONV_F32_F16X3S)
+        oscale = reinterpret_cast<const float *>(static_cast<const char *>(packed) + weight_bytes<AR>(csum, ksize, NB)) + NB * 32;
 #define CONV_LAUNCH(KSV)                                                                                                        \
     hipLaunchKernelGGL((conv_split_kernel<KSV, th, AR>), grid, dim3(256), 0, as_stream(stream), s, static_cast<const welem *>(packed), \
-                       bias, d, relu, H, W, tiles_x, tiles_y, NB, Cout, ntn, B, (int)per_xcd)
+                       bias, d, relu, H, W, tiles_x, tiles_y, NB, Cout, ntn, B, (int)per_xcd, oscale)
     if (ksize == 3) CONV_LAUNCH(3);
     else CONV_LAUNCH(1);
 #undef CONV_LAUNCH
@@ -804,6 +881,7 @@ int conv_nhwc(const void *const *srcs, const int *src_channels, int nsrc, const 
     case STEREO_CONV_F32_BF16X3: return CALL(STEREO_CONV_F32_BF16X3); \
     case STEREO_CONV_F16: return CALL(STEREO_CONV_F16);       \
     case STEREO_CONV_F32_F16X3: return CALL(STEREO_CONV_F32_F16X3); \
+    case STEREO_CONV_F32_F16X3S: return CALL(STEREO_CONV_F32_F16X3S); \
     default: break;                                            \
     }
 

@@ -42,7 +42,7 @@ def _ref64(srcs, convs, relu):
     (1, 6, 70, (32, 16, 16, 64), (24,), 1, False, True),              # 1x1
     (1, 34, 60, (128, 128), (128,), 3, False, True),
 ])
-@pytest.mark.parametrize("precision", ["highest", "bf16x6"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16x3s", "bf16x6"])
 def test_conv_nhwc_matches_fp64_and_miopen(S, case, precision):
     from stereoformer_amd import conv_split as C
     B, H, W, cs, co, k, relu, bias = case
@@ -225,7 +225,7 @@ def _gru_ref64(h, xs, cz, cr, cq, convz, convr, convq, softsign=False):
 
 @pytest.mark.parametrize("case", [(2, 13, 40, 128, (128, 128), True, False), (1, 9, 33, 128, (128,), True, False),
                                   (1, 7, 20, 64, (32,), False, True), (2, 6, 18, 64, (32,), False, False)])
-@pytest.mark.parametrize("precision", ["highest", "bf16x6"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16x3s", "bf16x6"])
 def test_conv_nhwc_gru_epilogues(S, case, precision):
     """The ConvGRU as two launches with the gate math in the epilogues (sigmoid -> z, sigmoid x h -> r h, tanh / softsign + blend)
     against the fp64 statement of update.py:28-32, and bit-for-bit against the unfused form (linear epilogue + the pointwise

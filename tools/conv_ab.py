@@ -18,11 +18,13 @@ for (nm, B, H, W, cs, co, relu) in (("gru08 convz|convr [8,384,136,240] -> 128+1
     convs = [nn.Conv2d(sum(cs), c, 3, padding=1).cuda().to(memory_format=torch.channels_last) for c in co]
     gf = 2 * B * H * W * sum(cs) * sum(co) * 9 / 1e9
     with torch.no_grad():
-        ms = timeit(lambda: C.conv_nhwc(srcs, convs, relu=relu, precision="highest"), 10, 3)
+        ms = timeit(lambda: C.conv_nhwc(srcs, convs, relu=relu, precision="f16x3"), 10, 3)
+        mss = timeit(lambda: C.conv_nhwc(srcs, convs, relu=relu, precision="f16x3s"), 10, 3)
         ms6 = timeit(lambda: C.conv_nhwc(srcs, convs, relu=relu, precision="bf16x6"), 10, 3)
         x = torch.cat(srcs, 1)
         ms_lib = timeit(lambda: [m(x) for m in convs], 10, 3)
-    print(f"{nm}: split-fp16 (3 products) {ms:.3f} ms = {gf / ms:.0f} TFLOP/s fp32-equivalent | split-bf16 (6 products) {ms6:.3f} ms = "
+    print(f"{nm}: split-fp16 (3 products) 4x1 tile, two accumulators {ms:.3f} ms = {gf / ms:.0f} TFLOP/s fp32-equivalent | 4x2 tile, one "
+          f"accumulator {mss:.3f} ms = {gf / mss:.0f} | split-bf16 (6 products) {ms6:.3f} ms = "
           f"{gf / ms6:.0f} | MIOpen convs alone {ms_lib:.3f} ms = {gf / ms_lib:.0f}", flush=True)
 
 # the whole ConvGRU step at 1/4 scale
@@ -45,7 +47,7 @@ def unfused(p):
 
 
 with torch.no_grad():
-    for p in ("highest", "bf16x6"):
+    for p in ("f16x3", "f16x3s", "bf16x6"):
         a, b = timeit(lambda: fused(p), 10, 3), timeit(lambda: unfused(p), 10, 3)
         print(f"ConvGRU step [8,128+256,136,240], precision {p}: gate math in the epilogues {a:.3f} ms | linear epilogues + gru_reset + gru_blend {b:.3f} ms",
               flush=True)
