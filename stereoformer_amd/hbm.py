@@ -17,17 +17,24 @@ from __future__ import annotations
 import torch
 
 
-def place(alloc, probe, max_tries=6, good_enough_ms=None, reserve_bytes=8 << 30, bytes_per_try=None):
+def place(alloc, probe, max_tries=6, good_enough_ms=None, reserve_bytes=8 << 30, bytes_per_try=None, device=None,
+          max_hold_fraction=0.85, release_to_driver=True):
     """Allocate with ``alloc()`` up to ``max_tries`` times, time each candidate with ``probe(candidate) -> ms``, keep the
     fastest and release the rest.  Rejected candidates stay alive until the end (freeing one would hand the same physical
-    block back to the next ``alloc``).  Stops early at a candidate within ``good_enough_ms`` or when fewer than
-    ``reserve_bytes`` + ``bytes_per_try`` of device memory remain.  Returns ``(candidate, report)``."""
+    block back to the next ``alloc``), so the search holds up to ``max_tries * bytes_per_try`` transiently: it stops early at a
+    candidate within ``good_enough_ms``, when fewer than ``reserve_bytes`` + ``bytes_per_try`` of ``device``'s memory remain
+    free, or when the candidates held would exceed ``max_hold_fraction`` of the device's total memory.
+    ``release_to_driver``: finish with ``torch.cuda.empty_cache()`` so that the rejected blocks really leave the process --
+    NOTE that this flushes the whole caching allocator of the process (every cached free block, not only ours); a service that
+    shares the process with other GPU work can pass ``False`` and let the allocator keep the blocks for reuse.
+    Returns ``(candidate, report)``."""
     held, times = [], []
     best = None
+    dev = torch.device(device) if device is not None else None
     for _ in range(max(1, int(max_tries))):
         if held and bytes_per_try is not None and torch.cuda.is_available():
-            free, _total = torch.cuda.mem_get_info()
-            if free < bytes_per_try + reserve_bytes:
+            free, total = torch.cuda.mem_get_info(dev)
+            if free < bytes_per_try + reserve_bytes or (len(held) + 1) * bytes_per_try > max_hold_fraction * total:
                 break
         cand = alloc()
         ms = float(probe(cand))
@@ -39,9 +46,10 @@ def place(alloc, probe, max_tries=6, good_enough_ms=None, reserve_bytes=8 << 30,
             break
     chosen = held[best]
     report = {"probe_ms": [round(t, 4) for t in times], "chosen": best, "chosen_ms": round(times[best], 4),
-              "first_allocation_ms": round(times[0], 4)}
+              "first_allocation_ms": round(times[0], 4),
+              "peak_bytes_held": None if bytes_per_try is None else len(held) * int(bytes_per_try)}
     del held, cand
-    if torch.cuda.is_available():
+    if release_to_driver and torch.cuda.is_available():
         torch.cuda.empty_cache()   # the rejected blocks go back to the driver; `chosen` stays allocated
     return chosen, report
 
@@ -83,7 +91,7 @@ def place_volume_stage_outputs(left, right, maxdisp, num_groups, max_tries=6, pr
             return _event_ms(lambda: build_gwc_volume_with_disparity(left, right, D, G, return_mean=True, out=bufs), probe_reps)
 
     bufs, report = place(alloc, probe, max_tries=max_tries, good_enough_ms=algorithmic / (good_enough_tbs * 1e12) * 1e3,
-                         bytes_per_try=n_bytes)
+                         bytes_per_try=n_bytes, device=dev)
     report["policy"] = ("fastest of up to %d candidate allocations, each timed with the launch that will write it; stop at "
                         ">= %.1f TB/s; rejected blocks returned to the driver" % (max_tries, good_enough_tbs))
     report["bytes_per_candidate"] = n_bytes
