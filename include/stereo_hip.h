@@ -375,7 +375,8 @@ int stereo_conv_nhwc_f16(const void *const *srcs, const int *src_channels, int n
  *           STEREO_CONV_F32_F16X3S  the same three products into ONE accumulator: every output channel's weights are pre-scaled
  *                                   by a power of two (max into [2^13, 2^14)) and packed as three fp16 pieces (hi, unscaled
  *                                   lo, 2^-11 hi), the epilogue undoes the scale; wave tile 4 x 2 blocks (8-row pixel tiles):
- *                                   half the LDS operand traffic per MFMA -- the host layer's choice for large images
+ *                                   half the LDS operand traffic per MFMA (opt-in on the host side: 7 % faster on the widest launch, equal over
+ *                                   a whole loop)
  *           STEREO_CONV_F32_BF16X6  = stereo_conv_nhwc_f32 (three bf16 pieces, six products: fp32's full exponent range)
  *           STEREO_CONV_F32_BF16X3  = stereo_conv_nhwc_f32_bf16x3        STEREO_CONV_F16  = stereo_conv_nhwc_f16
  *           (`packed` must come from stereo_conv_pack_weights_ex with the same `arith`.)

@@ -13,9 +13,11 @@ Arithmetic on fp32 activations (``precision``):
 * ``"highest"`` (default, the parity configuration) -- every operand as two fp16 pieces ``x = hi + 2^-11 lo'`` (22-23 significant
   bits), the three leading piece products (each exact in fp32) on ``v_mfma_f32_32x32x16_f16``: fp32-faithful for
   ``|x| < 65504`` -- the range the reference's own ``mixed_precision`` flag assumes for this block; beyond it the result is
-  inf / NaN, never silently wrong.  Two tilings of the same arithmetic, picked per launch: ``"f16x3"`` (two fp32 accumulators,
-  4-row pixel tiles) and ``"f16x3s"`` (one accumulator -- the weights are pre-scaled per output channel by a power of two and
-  packed as three pieces --, 8-row tiles with 64 channels per wave: half the LDS traffic per MFMA; large, wide launches).
+  inf / NaN, never silently wrong.  (= ``"f16x3"``: two fp32 accumulators, 4-row pixel tiles.)
+* ``"f16x3s"`` -- the same three products into ONE accumulator: the weights are pre-scaled per output channel by a power of two
+  and packed as three pieces; 8-row tiles with 64 channels per wave, half the LDS traffic per MFMA.  Same error budget; 7 %
+  faster on the widest launch (384 -> 256 channels at [8,.,136,240]: 1.22 vs 1.31 ms), behind on narrow / small ones, equal
+  over a whole RAFT loop (the kernel is power-bound either way) -- opt-in.
 * ``"bf16x6"`` -- three bf16 pieces, six piece products: the same fidelity over fp32's whole exponent range at twice the matrix
   work (round 2's default).
 * ``"high"`` -- two bf16 pieces, three products ("bf16x3", ~2^-16 relative error per product: the counterpart of
@@ -50,7 +52,7 @@ _tls = threading.local()
 def _form(precision):
     name = _ALIAS.get(precision, precision)
     if name not in ("f16x3", "f16x3s", "bf16x6", "bf16x3"):
-        raise ValueError("conv_split: precision is 'highest' (split-fp16: 'f16x3' / 'f16x3s' by image size), 'bf16x6' or 'high' (= 'bf16x3')")
+        raise ValueError("conv_split: precision is 'highest' (= 'f16x3'), 'f16x3s', 'bf16x6' or 'high' (= 'bf16x3')")
     return name
 
 

@@ -72,7 +72,7 @@ class RAFTStereoLoop(nn.Module):
         ``"high"`` = two bf16 pieces / three products per fp32 product (like ``torch.set_float32_matmul_precision('high')``):
         ~2^-16 relative error per product."""
         super().__init__()
-        if conv_precision not in ("highest", "f16x3", "bf16x6", "high", "bf16x3"):
+        if conv_precision not in ("highest", "f16x3", "f16x3s", "bf16x6", "high", "bf16x3"):
             raise ValueError("RAFTStereoLoop: conv_precision is 'highest' (fp32-faithful, the parity configuration), 'bf16x6' or 'high'")
         self.conv_precision = conv_precision
         self.mixed_precision = bool(mixed_precision)
