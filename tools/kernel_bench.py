@@ -258,7 +258,7 @@ def main():
             blk14 = blk14.to(memory_format=cl)
             nets_cl = [t.contiguous(memory_format=cl) for t in nets]
             inps_cl = [[t.contiguous(memory_format=cl) for t in lvl] for lvl in inps]
-            add("A14 one iteration B=8 @136x240 [channels-last: split-bf16 conv kernel, no concatenations]",
+            add("A14 one iteration B=8 @136x240 [channels-last: split-fp16 conv kernel, gate epilogues, no concatenations]",
                 timeit(lambda: blk14(list(nets_cl), inps_cl, corr, flow), 3, 1), None, 8 * 168.0, bound="mfma",
                 note="fp32-equivalent flops; frac is against the f32 MFMA peak (157.3): the split-bf16 formulation is not bound by it")
             import torch.nn as nn
