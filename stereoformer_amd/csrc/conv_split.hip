@@ -219,7 +219,7 @@ constexpr int conv_min_wg_per_cu()
 }
 
 template <int KS, int TH, int AR>
-__global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kernel(ConvSrcs src,
+__global__ __launch_bounds__(256, TH == 2 ? 4 : conv_min_wg_per_cu<AR>()) void conv_split_kernel(ConvSrcs src,
                                                                                     const typename ConvAr<AR>::welem *__restrict__ packed,
                                                                                     const float *__restrict__ bias, ConvDsts dst, int relu,
                                                                                     int H, int W, int tiles_x, int tiles_y, int NB, int Cout,
@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kern
     constexpr int ES = (int)sizeof(TIN), QCH = 16 / ES, QPP = 16 / QCH;   // channels per 16-B quad, quads per pixel and chunk
     constexpr int HALO = KS / 2, TAPS = KS * KS;
     constexpr int WN = TH == 8 ? 2 : 4;          // waves along the output channels (the other 4 / WN along the rows)
+    constexpr int MBW = TH == 2 ? 2 : 4;         // M blocks (2 rows x 16 columns) per wave: 2-row tiles (small images) have two
     constexpr int NBW = 4 / WN;                  // 32-channel N blocks per wave
     constexpr int HCOLS = CV_TW + 2 * HALO, HROWS = TH + 2 * HALO, NPX = HROWS * HCOLS;
     // LDS row stride: a multiple of the 256-B bank row.  ds_read_b128 is served in four 16-lane groups that mix the two pixel
@@ -324,9 +325,9 @@ __global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kern
     for (int s = 0; s < CV_MAXSRC; ++s)
         if (s < src.n) nchunks += src.c[s] / 16;
 
-    f32x16 acc[4][NBW][NACC];
+    f32x16 acc[MBW][NBW][NACC];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
+    for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
@@ -347,16 +348,17 @@ __global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kern
     // half only (last tile of a row whose width is 16 mod 32), or some other subset (bottom edge).  The K loop -- and with it
     // the barrier sequence -- is chosen for the WORKGROUP: the waves of an 8-row tile (wm = 0, 1) can see different subsets at
     // the bottom edge, and then all of them take the generic loop with their own predicates.
-    bool mbv[4];
+    bool mbv[4] = {false, false, false, false};
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) mbv[mb] = y0 + 4 * wm + 2 * (mb >> 1) < H && x0 + 16 * (mb & 1) < W;
+    for (int mb = 0; mb < MBW; ++mb) mbv[mb] = y0 + 4 * wm + 2 * (mb >> 1) < H && x0 + 16 * (mb & 1) < W;
     int mode = -1;
 #pragma unroll
     for (int w = 0; w < 4 / WN; ++w) {
         bool v[4];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) v[mb] = y0 + 4 * w + 2 * (mb >> 1) < H && x0 + 16 * (mb & 1) < W;
-        const int m = (v[0] && v[1] && v[2] && v[3]) ? 0 : ((v[0] && v[2] && !v[1] && !v[3]) ? 1 : 2);
+        for (int mb = 0; mb < 4; ++mb) v[mb] = mb >= MBW || (y0 + 4 * w + 2 * (mb >> 1) < H && x0 + 16 * (mb & 1) < W);
+        const bool right1 = MBW == 2 ? !v[1] : (!v[1] && !v[3]);
+        const int m = (v[0] && v[1] && v[2] && v[3]) ? 0 : ((v[0] && v[2] && right1) ? 1 : 2);
         mode = (w == 0 || m == mode) ? m : 2;
     }
 
@@ -394,18 +396,19 @@ __global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kern
             load_b(bc, wk + (size_t)tap * kstep);
             if (MODE == 0) {
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
+                for (int mb = 0; mb < MBW; ++mb) {
                     single(mb, ky, kx, bc);
                     __builtin_amdgcn_sched_barrier(0);   // (hoisting every block's fragments over the unrolled taps spills)
                 }
             } else if (MODE == 1) {
-                single(0, ky, kx, bc);
-                __builtin_amdgcn_sched_barrier(0);
-                single(2, ky, kx, bc);
-                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mb = 0; mb < MBW; mb += 2) {
+                    single(mb, ky, kx, bc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             } else {
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
+                for (int mb = 0; mb < MBW; ++mb)
                     if (mbv[mb]) single(mb, ky, kx, bc);
             }
         }
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kern
     // of the NEXT tap (of the next chunk after the last tap), then its own MFMAs.
     auto run_pipe = [&](auto mode_tag) {
         constexpr int MODE = decltype(mode_tag)::value;   // 0: all four M blocks; 1: blocks 0 and 2
-        constexpr int NBLK = MODE == 0 ? 4 : 2, BSTEP = MODE == 0 ? 1 : 2, NSTEP = TAPS * NBLK;
+        constexpr int NBLK = MODE == 0 ? MBW : MBW / 2, BSTEP = MODE == 0 ? 1 : 2, NSTEP = TAPS * NBLK;
         frag bq[2][NBW][NPB], aq[2][NP];
         issue();
         load_b(bq[0], wbase);
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(256, conv_min_wg_per_cu<AR>()) void conv_split_kern
         if constexpr (AR == STEREO_CONV_F32_F16X3S) osc = oscale[cg];
         if (l31 < nvalid) {
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
+            for (int mb = 0; mb < MBW; ++mb) {
 #pragma unroll
                 for (int rh = 0; rh < 16; rh += 8) {   // (one row of the block: 8 registers)
                     // the operand rows of 8 outputs are requested together, then the math, then the stores
@@ -854,15 +857,41 @@ int conv_nhwc(const void *const *srcs, const int *src_channels, int nsrc, const 
     // (fp16 activations: one MFMA per fragment instead of six makes the 4-row shape LDS-bound -- every A fragment feeds a single
     // MFMA; the 8-row shape, a wave = 4 rows x 64 channels, halves the fragment reads per MFMA)
     constexpr int th = (sizeof(TIN) == 4 && AR != STEREO_CONV_F32_F16X3S) ? 4 : 8;
+    typedef typename ConvAr<AR>::welem welem;
+    const float *oscale = nullptr;
+    if (AR == STEREO_CONV_F32_F16X3S)
+        oscale = reinterpret_cast<const float *>(static_cast<const char *>(packed) + weight_bytes<AR>(csum, ksize, NB)) + NB * 32;
+    // Launches with a SHORT K loop (<= 128 input channels at small sizes, <= 64 at any size) or very few tiles take 2-row pixel
+    // tiles: twice as many workgroups of half the work, four resident per CU instead of two.  With few chunks per workgroup the
+    // prologue / epilogue and the tile quantisation dominate (576 four-row tiles on 512 slots run as two rounds, the second one
+    // eighth full): the LowCNN updater's convolutions at [8,.,72,120] run 10-20 % faster (tools/conv_rows_ab.py); with 384 input
+    // channels the 4-row tile's weight reuse wins at every size.
+    if constexpr (AR == STEREO_CONV_F32_F16X3) {
+        const long long nt4 = (long long)tiles_x * ((H + 3) / 4) * B * ntn;
+        const int forced = stereo_opt(OPT_CONV_ROWS);   // test hook
+        const bool small = csum <= 64 || (csum <= 128 && nt4 <= 1024) || nt4 <= 320;
+        if (forced == 2 || (forced != 4 && small)) {
+            const int tiles_y2 = (H + 1) / 2;
+            const long long nt2 = (long long)tiles_x * tiles_y2 * B;
+            const long long per2 = (nt2 + 7) / 8;
+            dim3 grid2((unsigned)(per2 * 8 * ntn));
+            if (ksize == 3)
+                hipLaunchKernelGGL((conv_split_kernel<3, 2, AR>), grid2, dim3(256), 0, as_stream(stream), s,
+                                   static_cast<const welem *>(packed), bias, d, relu, H, W, tiles_x, tiles_y2, NB, Cout, ntn, B,
+                                   (int)per2, oscale);
+            else
+                hipLaunchKernelGGL((conv_split_kernel<1, 2, AR>), grid2, dim3(256), 0, as_stream(stream), s,
+                                   static_cast<const welem *>(packed), bias, d, relu, H, W, tiles_x, tiles_y2, NB, Cout, ntn, B,
+                                   (int)per2, oscale);
+            STEREO_LAUNCH_CHECK();
+            return STEREO_OK;
+        }
+    }
     const int tiles_y = (H + th - 1) / th;
     const long long nt = (long long)tiles_x * tiles_y * B;
     const long long per_xcd = (nt + 7) / 8;
     if (per_xcd * 8 * ntn >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
     dim3 grid((unsigned)(per_xcd * 8 * ntn));
-    typedef typename ConvAr<AR>::welem welem;
-    const float *oscale = nullptr;
-    if (AR == STEREO_CONV_F32_F16X3S)
-        oscale = reinterpret_cast<const float *>(static_cast<const char *>(packed) + weight_bytes<AR>(csum, ksize, NB)) + NB * 32;
 #define CONV_LAUNCH(KSV)                                                                                                        \
     hipLaunchKernelGGL((conv_split_kernel<KSV, th, AR>), grid, dim3(256), 0, as_stream(stream), s, static_cast<const welem *>(packed), \
                        bias, d, relu, H, W, tiles_x, tiles_y, NB, Cout, ntn, B, (int)per_xcd, oscale)

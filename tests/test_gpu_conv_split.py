@@ -42,9 +42,12 @@ def _ref64(srcs, convs, relu):
     (1, 6, 70, (32, 16, 16, 64), (24,), 1, False, True),              # 1x1
     (1, 34, 60, (128, 128), (128,), 3, False, True),
 ])
-@pytest.mark.parametrize("precision", ["f16x3", "f16x3s", "bf16x6"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16x3-rows4", "f16x3s", "bf16x6"])
 def test_conv_nhwc_matches_fp64_and_miopen(S, case, precision):
     from stereoformer_amd import conv_split as C
+    if precision == "f16x3-rows4":     # small launches of the default form take 2-row pixel tiles: force the 4-row shape too
+        with S._native.test_options(conv_rows=4):
+            return test_conv_nhwc_matches_fp64_and_miopen(S, case, "f16x3")
     B, H, W, cs, co, k, relu, bias = case
     torch.manual_seed(81)
     srcs = [_cl(torch.randn(B, c, H, W, device="cuda")) for c in cs]
@@ -225,8 +228,11 @@ def _gru_ref64(h, xs, cz, cr, cq, convz, convr, convq, softsign=False):
 
 @pytest.mark.parametrize("case", [(2, 13, 40, 128, (128, 128), True, False), (1, 9, 33, 128, (128,), True, False),
                                   (1, 7, 20, 64, (32,), False, True), (2, 6, 18, 64, (32,), False, False)])
-@pytest.mark.parametrize("precision", ["f16x3", "f16x3s", "bf16x6"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16x3-rows4", "f16x3s", "bf16x6"])
 def test_conv_nhwc_gru_epilogues(S, case, precision):
+    if precision == "f16x3-rows4":
+        with S._native.test_options(conv_rows=4):
+            return test_conv_nhwc_gru_epilogues(S, case, "f16x3")
     """The ConvGRU as two launches with the gate math in the epilogues (sigmoid -> z, sigmoid x h -> r h, tanh / softsign + blend)
     against the fp64 statement of update.py:28-32, and bit-for-bit against the unfused form (linear epilogue + the pointwise
     gate kernels): both evaluate the same device functions on the same accumulator values."""
@@ -387,9 +393,14 @@ def test_conv_nhwc_tiny_and_empty_images(S, shape):
         assert float((o - r).abs().max()) <= 2e-5 * max(1.0, float(r.abs().max()))
 
 
-def test_conv_nhwc_random_shapes_sweep(S):
-    """40 random (batch, size, source split, output split, kernel, ReLU, bias) combinations against the library's fp32 result."""
+@pytest.mark.parametrize("rows", [0, 2, 4])
+def test_conv_nhwc_random_shapes_sweep(S, rows):
+    """40 random (batch, size, source split, output split, kernel, ReLU, bias) combinations against the library's fp32 result,
+    with the pixel-tile shape picked by launch size and forced to 2 / 4 rows."""
     from stereoformer_amd import conv_split as C
+    if rows:
+        with S._native.test_options(conv_rows=rows):
+            return test_conv_nhwc_random_shapes_sweep(S, 0)
     g = torch.Generator().manual_seed(90)
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
     for case in range(40):
