@@ -620,9 +620,16 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const TIN *__restric
             for (int q = 0; q < 8; ++q) {
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(pp + 4 * q);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (COUT == 2) {   // (the flow head: both outputs in one v_pk_fma_f32)
+                        const f32x2 w2 = *reinterpret_cast<const f32x2 *>(wk + (4 * q + i) * 2);
+                        const f32x2 a2 = __builtin_elementwise_fma((f32x2){v[i], v[i]}, w2, (f32x2){acc[0], acc[1]});
+                        acc[0] = a2[0], acc[1] = a2[1];
+                    } else {
 #pragma unroll
-                    for (int o = 0; o < COUT; ++o) acc[o] = fmaf(v[i], wk[(4 * q + i) * COUT + o], acc[o]);
+                        for (int o = 0; o < COUT; ++o) acc[o] = fmaf(v[i], wk[(4 * q + i) * COUT + o], acc[o]);
+                    }
+                }
             }
         }
     }
@@ -660,27 +667,28 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(const float *__rest
     const int y = y0 + row, xo = x0 + col;
     float *op = out + (((size_t)b * H + y) * W + xo) * ostride;
     for (int o0 = 0; o0 < Cout; o0 += 16) {
-        float acc[16];
+        f32x2 acc[8];    // channel pairs: v_pk_fma_f32 does two multiply-adds in the issue slot of one
 #pragma unroll
-        for (int o = 0; o < 16; ++o) acc[o] = bias ? bias[o0 + o] : 0.0f;
+        for (int o = 0; o < 8; ++o) acc[o] = bias ? (f32x2){bias[o0 + 2 * o], bias[o0 + 2 * o + 1]} : (f32x2){0.0f, 0.0f};
         for (int c = 0; c < Cin; ++c) {
 #pragma unroll
             for (int ky = 0; ky < K; ++ky) {
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {
                     const float v = tile[(c * HR + row + ky) * HC + col + kx];
-                    const float *wk = wt + ((size_t)((ky * K + kx) * Cin + c)) * Cout + o0;   // [K][K][Cin][Cout]: wave-uniform
+                    const f32x2 vv = {v, v};
+                    const f32x2 *wk = reinterpret_cast<const f32x2 *>(wt + ((size_t)((ky * K + kx) * Cin + c)) * Cout + o0);   // wave-uniform
 #pragma unroll
-                    for (int o = 0; o < 16; ++o) acc[o] = fmaf(v, wk[o], acc[o]);
+                    for (int o = 0; o < 8; ++o) acc[o] = __builtin_elementwise_fma(vv, wk[o], acc[o]);
                 }
             }
         }
         if (y < H && xo < W) {
 #pragma unroll
-            for (int o = 0; o < 16; o += 4) {
-                f32x4 v = {acc[o], acc[o + 1], acc[o + 2], acc[o + 3]};
+            for (int o = 0; o < 8; o += 2) {
+                f32x4 v = {acc[o][0], acc[o][1], acc[o + 1][0], acc[o + 1][1]};
                 if (relu) v = __builtin_elementwise_max(v, (f32x4){0.0f, 0.0f, 0.0f, 0.0f});
-                st4(op + o0 + o, v);
+                st4(op + o0 + 2 * o, v);
             }
         }
     }

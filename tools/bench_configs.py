@@ -77,6 +77,20 @@ def entry(name, workload, pairs_per_gpu, world, sec, per_rank, steps, warmup, ro
     return out
 
 
+def pmc_traffic(fname, key_part):
+    """HBM bytes per launch of a kernel from a COMMITTED counter pass under profiles/ (never measured in the bench run itself):
+    (bytes, source) or (None, None)."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", fname)) as f:
+            d = json.load(f)
+        for k, e in d.get("kernels", {}).items():
+            if key_part in k and e.get("traffic_bytes_per_launch") is not None:
+                return e["traffic_bytes_per_launch"], d.get("source")
+    except (OSError, ValueError):
+        pass
+    return None, None
+
+
 def raft_inputs(B, Hq, Wq, dev, seed):
     g = torch.Generator(device=dev).manual_seed(seed)
     rn = lambda *s: torch.randn(*s, device=dev, generator=g)
@@ -347,7 +361,9 @@ def cfg3(dev, rank, world, steps, warmup, cpu):
         # the matrix pipe -- halving the MFMAs (22 -> 12 per key tile against round 2's split-bf16 form) moved it by 5 %.
         roof = {"bound": "mfma", "kernel": "cross_attention_split16_kernel<7,8,float> (A7 on v_mfma_f32_32x32x16_f16, hi + 2^-11 lo' operands)",
                 "achieved": round(tf, 2), "peak": MFMA_F32_PEAK, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK, 4),
-                "traffic": None, "avg_launch_ms": round(ms, 4), "algorithmic_flops": flops,
+                "traffic": pmc_traffic("pmc_a7_latest.json", "cfg3: ")[0], "traffic_source": pmc_traffic("pmc_a7_latest.json", "cfg3: ")[1],
+                "algorithmic_bytes": 3 * B * C * H * W * 4 + B * H * W * 4,
+                "avg_launch_ms": round(ms, 4), "algorithmic_flops": flops,
                 "executed_f16_tflops": round(3 * tf, 1), "frac_of_f16_peak_2500": round(3 * tf / 2500.0, 4)}
     del L, R
     cb = None
@@ -444,10 +460,27 @@ def cfg4(dev, rank, world, steps, warmup, cpu, mixed=False):
     sec, per_rank = timed(lambda: lp(vol, disp, li, ri, iters=16, use_graph=True), n, warmup, world, dev)
     roof2 = None
     if rank == 0:
-        bnd = torch.rand(B, 2, 72, 120, device=dev) * 3
-        ms = event_ms(lambda: S.bounds_lookup(vol, disp, bnd, 20, True))
-        roof2 = {"bound": "hbm", "kernel": "lookup_kernel<BOUNDS> (A11 sampler; latency-scale at this size)", "achieved": None,
-                 "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None, "avg_launch_ms": round(ms, 4)}
+        # the loop's dominant hand-written launch: conv_z | conv_b of the updater's ConvGRU over [err feat | unc feat | h]
+        # (32 + 32 + 64 -> 64 + 64 channels, gate epilogues) at [8,.,72,120] -- 4 of the 9 launches of an iteration are this kernel
+        import torch.nn as nn
+        from stereoformer_amd import conv_split as C
+        cl = torch.channels_last
+        srcs = [torch.randn(B, c, 72, 120, device=dev).contiguous(memory_format=cl) for c in (32, 32, 64)]
+        convs = [nn.Conv2d(128, 64, 3, padding=1).to(dev) for _ in range(2)]
+        epi = [("sigmoid", None), ("sigmoid_mul", None, srcs[2])]
+        with torch.no_grad():
+            ms = event_ms(lambda: C.conv_nhwc(srcs, convs, epilogue=epi), reps=20)
+        gf = 2 * B * 72 * 120 * 128 * 128 * 9 / 1e9
+        tf = gf / ms
+        roof2 = {"bound": "mfma", "kernel": "conv_split_kernel<3,2,F32_F16X3> (A11: conv_z | conv_b of the updater's ConvGRU, 128 -> 64 + 64 "
+                                            "channels at [8,.,72,120], sigmoid / sigmoid x h epilogues; 2-row pixel tiles)",
+                 "achieved": round(tf, 1), "peak": round(2500.0 / 3, 1), "unit": "TFLOP/s", "frac": round(tf / (2500.0 / 3), 4),
+                 "traffic": None, "avg_launch_ms": round(ms, 4),
+                 "algorithmic_bytes": B * 72 * 120 * 4 * (128 + 64 + 128) + 128 * 128 * 9 * 4,
+                 "note": "a 20-GFLOP launch of 1 152 workgroups: tile quantisation and the 8-chunk K loop's prologue / epilogue, not "
+                         "the matrix pipe, set its time; per iteration the loop is 9 launches (guidance inputs, two encoder "
+                         "convolutions, two GRU launches, offset conv1 / conv2, the bounds sampler)"}
+        del srcs, convs
     cb = None
     if cpu and rank == 0:
         def leg2():
@@ -483,7 +516,9 @@ def cfg5(dev, rank, world, steps, warmup, cpu):
         # 11 flop/B at C = 256: left of the f32 ridge, so HBM is the roofline; the matrix-core figure is reported beside it
         roof = {"bound": "hbm", "kernel": "cross_attention_chunked_split_kernel<3,*> at C=256 (A7, disparity only: the QK^T half; "
                                           "split-bf16 operands on v_mfma_f32_32x32x16_bf16)",
-                "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": None,
+                "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+                "traffic": pmc_traffic("pmc_a7_latest.json", "cfg5: ")[0], "traffic_source": pmc_traffic("pmc_a7_latest.json", "cfg5: ")[1],
+                "algorithmic_bytes": 2 * B * 256 * Hq * Wq * 4 + B * Hq * Wq * 4,
                 "avg_launch_ms": round(ms, 4), "fp32_equivalent_tflops": round(tf, 2),
                 "frac_of_f32_mfma_peak": round(tf / MFMA_F32_PEAK, 4)}
     cb = None

@@ -14,6 +14,9 @@ cp $O/bench_under_rocprof.log $P/r03_bench_under_rocprof.log 2>/dev/null
 bash tools/conv_pmc.sh r03 > $O/conv_pmc.log 2>&1
 cp gpurun_out/conv_pmc_r03/pmc_conv.json $P/r03_pmc_conv.json 2>/dev/null
 cp gpurun_out/conv_pmc_r03/pmc_conv.json $P/pmc_conv_latest.json 2>/dev/null
+bash tools/a7_pmc.sh > $O/a7_pmc.log 2>&1
+cp gpurun_out/a7_pmc/pmc_a7.json $P/r03_pmc_a7.json 2>/dev/null
+cp gpurun_out/a7_pmc/pmc_a7.json $P/pmc_a7_latest.json 2>/dev/null
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/cfg4 -o run --output-format csv -- python3 $ROOT/tools/cfg4_trace.py > $O/cfg4_trace.log 2>&1)
 python3 - $O <<'PY' > $P/r03_cfg4_loop_kernel_trace.txt
 import csv, collections, re, sys
