@@ -22,6 +22,7 @@ enum StereoOpt {
     OPT_TILES_PER_WG,    // 0 (default): sized to the resident workgroups; n > 0: tiles per persistent workgroup
     OPT_PROB_SINGLE_PASS,  // 1 (default): softmax column in registers (D <= 192); 0: two-pass kernel
     OPT_CONV_ROWS,       // 0 (default): pixel-tile rows of the split-fp16 convolution by launch size; 2 / 4: forced
+    OPT_CORR_F16P,       // 1 (default): split-fp16 matrix phase of the A1 volume kernel; 0: f32 MFMA
     OPT_COUNT
 };
 int stereo_opt(int which);

@@ -34,7 +34,11 @@ namespace {
 // flushes into volg[b, g]; then the all-channel pass produces the mean volume and the disparity as before.  The key
 // tile and the Q registers are fetched once for both; the 25.5 GB group-wise volume leaves through the same
 // row-contiguous flush path (which sustains > 6 TB/s on its own) and is never read back.
-template <int NT, bool ARGMIN, int CM_NWV, int RINGB, int CPG2 = 0, bool MEANPASS = true, typename TIN = float>
+// F16P (round 3; CPG2 == 0: A1 / A1 + A4 with the volume stored): the matrix phase on v_mfma_f32_32x32x16_f16 with split operands
+// (common.h: x = hi + 2^-11 lo', two fp32 accumulators; fp16 features are their own single piece) -- 6 (2) MFMAs of 32 cycles per
+// key tile instead of 16 of 64.  The key image keeps its footprint ([piece][channel][key] f16: 2 x 2 B = the fp32 image's 4 B per
+// element); K fragments come through ds_read_b64_tr_b16, Q pieces sit in registers, 1/C moves to the accumulator.
+template <int NT, bool ARGMIN, int CM_NWV, int RINGB, int CPG2 = 0, bool MEANPASS = true, typename TIN = float, bool F16P = false>
 __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const TIN *__restrict__ L,
                                                                        const TIN *__restrict__ R,
                                                                        float *__restrict__ vol, float *__restrict__ disp,
@@ -51,9 +55,12 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const TIN
     constexpr int KS = NK + 4;
     constexpr int RMAX = (32 + CM_NWV - 1) / CM_NWV;  // staged rows per wave (row = wave, wave + NWV, ... < 32)
     constexpr int NPASS = (NK / 4 + 63) / 64;  // 16-B quads per lane and row
+    static_assert(!F16P || CPG2 == 0, "the split-fp16 matrix phase serves the all-channel pass only");
+    constexpr int NPK = sizeof(TIN) == 4 ? 2 : 1;   // F16P: pieces per feature value
     extern __shared__ f32x4 smem4[];
     f32x4 *Ks4 = smem4;
     float *Ks = reinterpret_cast<float *>(smem4);
+    _Float16 *Kh = reinterpret_cast<_Float16 *>(smem4);   // F16P: [NPK][32][KS] f16 in the same bytes
     float *Sh = Ks + 32 * KS;  // [CM_RING][CM_RSTR]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -97,7 +104,8 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const TIN
         const int q = w0 + 32 * wave + l31;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const int c = 2 * s + half;
+            // f32 MFMA: k-step s contracts channels 2 s + half; f16 MFMA: k-step s >> 3, element s & 7 -> channel 16 (s >> 3) + 8 half + (s & 7)
+            const int c = F16P ? 16 * (s >> 3) + 8 * half + (s & 7) : 2 * s + half;
             qn[s] = Lb[(c < C && q < W) ? (unsigned)c * HWu + (unsigned)q : 0u];
         }
     };
@@ -107,9 +115,25 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const TIN
             const int row = wave + rr * CM_NWV;
 #pragma unroll
             for (int pp = 0; pp < NPASS; ++pp) {
-                if (row < 32 && lane + 64 * pp < NK / 4)
-                    Ks4[(row * KS) / 4 + lane + 64 * pp] =
-                        (((okbits >> pp) & 1u) && row < C) ? Quad<TIN>::widen(rk[rr][pp]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (row < 32 && lane + 64 * pp < NK / 4) {
+                    const bool ok = ((okbits >> pp) & 1u) && row < C;
+                    if constexpr (!F16P) {
+                        Ks4[(row * KS) / 4 + lane + 64 * pp] = ok ? Quad<TIN>::widen(rk[rr][pp]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    } else if constexpr (NPK == 2) {
+                        const f32x4 v = ok ? Quad<TIN>::widen(rk[rr][pp]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        f16x2 a[2], b[2];
+                        split_pair_f16((f32x2){v[0], v[1]}, a);
+                        split_pair_f16((f32x2){v[2], v[3]}, b);
+#pragma unroll
+                        for (int p = 0; p < 2; ++p)
+                            *reinterpret_cast<f16x4 *>(&Kh[(p * 32 + row) * KS + 4 * (lane + 64 * pp)]) =
+                                __builtin_shufflevector(a[p], b[p], 0, 1, 2, 3);
+                    } else {
+                        const f16x4 z = {0, 0, 0, 0};
+                        *reinterpret_cast<f16x4 *>(&Kh[row * KS + 4 * (lane + 64 * pp)]) =
+                            ok ? __builtin_bit_cast(f16x4, rk[rr][pp]) : z;
+                    }
+                }
             }
         }
     };
@@ -130,6 +154,10 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const TIN
     issue(tile);
     commit();
     float qv[16];
+    f16x8 qf[2][NPK];   // F16P: Q pieces per k-step
+    // F16P: transposed K reads (attention_bf16.hip): lane 4 q + p of its 16-lane group supplies channel row R0 + q, keys K0 + 4 p ..
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
+    const int k_off = (8 * half + tq) * KS + 32 * wave + 16 * tg1 + 4 * tp;   // + (16 s + 4 tt) KS + 32 (key tile)
     const float l2 = sgn * 1.44269504088896340736f;  // mean -> logit in units of log2
     for (;;) {
         const int x = tile % nx, bh = tile / nx;
@@ -137,10 +165,25 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const TIN
         const int w0 = x * CM_TQW;
         const int q = w0 + 32 * wave + l31;
         const size_t row_off = (size_t)bb * D * HWu + (size_t)hh * W;  // vol[bb, 0, hh, 0]
+        if constexpr (!F16P) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int c = 2 * s + half;
-            qv[s] = (c < C && q < W) ? (float)qn[s] * inv_c : 0.0f;
+            for (int s = 0; s < 16; ++s) {
+                const int c = 2 * s + half;
+                qv[s] = (c < C && q < W) ? (float)qn[s] * inv_c : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float xq[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xq[j] = (16 * s + 8 * half + j < C && q < W) ? (float)qn[8 * s + j] : 0.0f;
+                if constexpr (NPK == 2) {
+                    split_oct_f16(xq, qf[s]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) qf[s][0][j] = (_Float16)xq[j];
+                }
+            }
         }
         __syncthreads();  // the key tile is visible; the previous tile's last sheet reads are done
         const bool more = tile + 1 < tile_end;
@@ -199,10 +242,39 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const TIN
                 f32x16 a;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a[r] = 0.0f;
-                const float *kpt = kp + 32 * (NT - 1 - s);
+                if constexpr (!F16P) {
+                    const float *kpt = kp + 32 * (NT - 1 - s);
 #pragma unroll
-                for (int t = 0; t < 16; ++t)
-                    a = __builtin_amdgcn_mfma_f32_32x32x2f32(kpt[2 * t * KS], qv[t], a, 0, 0, 0);
+                    for (int t = 0; t < 16; ++t)
+                        a = __builtin_amdgcn_mfma_f32_32x32x2f32(kpt[2 * t * KS], qv[t], a, 0, 0, 0);
+                } else {
+                    f32x16 al = a;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        f16x8 kf[NPK];
+#pragma unroll
+                        for (int p = 0; p < NPK; ++p) {
+#pragma unroll
+                            for (int tt = 0; tt < 2; ++tt) {
+                                const _Float16 *src = &Kh[p * 32 * KS + k_off + (16 * ks + 4 * tt) * KS + 32 * (NT - 1 - s)];
+                                const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)src);
+                                const short tv[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) kf[p][4 * tt + e] = __builtin_bit_cast(_Float16, tv[e]);
+                            }
+                        }
+                        if constexpr (NPK == 2) {
+                            al = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[ks][1], al, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[ks][0], a, 0, 0, 0);
+                            al = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qf[ks][0], al, 0, 0, 0);
+                        } else {
+                            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[ks][0], a, 0, 0, 0);
+                        }
+                    }
+                    const float il = inv_c * SPLIT16_LO_UNSCALE;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[r] = NPK == 2 ? fmaf(al[r], il, a[r] * inv_c) : a[r] * inv_c;
+                }
                 sheet_write(a, sb);
                 if (ARGMIN) {
                     const int cb = 32 * s + dl;  // d of register r = cb - i_r
@@ -259,13 +331,13 @@ __global__ __launch_bounds__(CM_NWV * 64) void corr_volume_mfma_kernel(const TIN
     }
 }
 
-template <int NT, bool ARGMIN, int NWV, int RINGB, int CPG2 = 0, bool MEANPASS = true, typename TIN = float>
+template <int NT, bool ARGMIN, int NWV, int RINGB, int CPG2 = 0, bool MEANPASS = true, typename TIN = float, bool F16P = false>
 int launch_cm(const TIN *L, const TIN *R, float *vol, float *disp, int B, int C, int H, int W, int D, float sgn,
               hipStream_t st, float *volg = nullptr, int G = 0)
 {
     constexpr int Dk = 32 * (NT - 1), TQW = 32 * NWV;
     const size_t lds = ((size_t)32 * (TQW + Dk + 4) + (size_t)32 * RINGB * (TQW + 4)) * sizeof(float);
-    auto kern = corr_volume_mfma_kernel<NT, ARGMIN, NWV, RINGB, CPG2, MEANPASS, TIN>;
+    auto kern = corr_volume_mfma_kernel<NT, ARGMIN, NWV, RINGB, CPG2, MEANPASS, TIN, F16P>;
     if (lds > 160 * 1024) return STEREO_ERR_UNSUPPORTED;
     static std::atomic<unsigned long long> lds_done{0};  // per instantiation: a bit per device
     if (!lds_opt_in(kern, lds, lds_done)) return STEREO_ERR_UNSUPPORTED;
@@ -297,9 +369,15 @@ int stereo_corr_volume_mfma(const TIN *L, const TIN *R, float *vol, float *disp,
     if (nt > 7)  // 192 < D <= 256: six waves (192 queries) keep key tile + sheet inside the 160 KB of LDS
         return disp ? launch_cm<9, true, 6, 3, 0, true, TIN>(L, R, vol, disp, B, C, H, W, D, sgn, st)
                     : launch_cm<9, false, 6, 3, 0, true, TIN>(L, R, vol, disp, B, C, H, W, D, sgn, st);
-#define CM_CASE(NTV)                                                                     \
-    return disp ? launch_cm<NTV, true, 8, 3, 0, true, TIN>(L, R, vol, disp, B, C, H, W, D, sgn, st) \
-                : launch_cm<NTV, false, 8, 3, 0, true, TIN>(L, R, vol, disp, B, C, H, W, D, sgn, st)
+    const bool f16p = stereo_opt(OPT_CORR_F16P) != 0;   // test hook: 0 = the f32-MFMA matrix phase
+#define CM_CASE(NTV)                                                                                              \
+    do {                                                                                                          \
+        if (f16p)                                                                                                 \
+            return disp ? launch_cm<NTV, true, 8, 3, 0, true, TIN, true>(L, R, vol, disp, B, C, H, W, D, sgn, st)  \
+                        : launch_cm<NTV, false, 8, 3, 0, true, TIN, true>(L, R, vol, disp, B, C, H, W, D, sgn, st); \
+        return disp ? launch_cm<NTV, true, 8, 3, 0, true, TIN>(L, R, vol, disp, B, C, H, W, D, sgn, st)            \
+                    : launch_cm<NTV, false, 8, 3, 0, true, TIN>(L, R, vol, disp, B, C, H, W, D, sgn, st);          \
+    } while (0)
     if (nt <= 3) CM_CASE(3);
     if (nt <= 5) CM_CASE(5);
     CM_CASE(7);

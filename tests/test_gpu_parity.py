@@ -764,3 +764,22 @@ def test_out_buffers_and_placement(S, oracle):
         S.build_gwc_volume_with_disparity(L, R, D, G, out=(bufs[0], bufs[1], bufs[2][:, :-1]))
     with pytest.raises(RuntimeError, match="inference option"):
         S.build_gwc_volume_with_disparity(L.clone().requires_grad_(True), R, D, G, out=bufs)
+
+
+@pytest.mark.parametrize("cfg", [(2, 32, 3, 520, 192), (1, 20, 2, 260, 70), (1, 7, 1, 64, 5), (1, 32, 2, 960, 130), (2, 16, 2, 100, 33)])
+@pytest.mark.parametrize("f16p", [1, 0])
+def test_corr_volume_matrix_phase_forms(S, oracle, cfg, f16p):
+    """A1 (+ A4) on the matrix-core volume kernel with the split-fp16 matrix phase (default) and with the f32 MFMA (test hook):
+    both against the oracle at the fp32 tolerances, fp32 and fp16 features."""
+    B, C, H, W, D = cfg
+    rng = np.random.default_rng(77)
+    L = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    R = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    with S._native.test_options(corr_f16p=f16p):
+        close(S.CostVolume(D)(dev(L), dev(R)), oracle.corr_volume(L, R, D), **VOL_TOL)
+        vol, disp = S.corr_volume_with_disparity(dev(L), dev(R), D)
+        ov = oracle.corr_volume(L, R, D)
+        close(vol, ov, **VOL_TOL)
+        close(disp, oracle.soft_argmin(ov), rtol=0, atol=1e-3)
+        Lh, Rh = L.astype(np.float16), R.astype(np.float16)
+        close(S.CostVolume(D)(dev(Lh), dev(Rh)), oracle.corr_volume(Lh.astype(np.float32), Rh.astype(np.float32), D), **VOL_TOL)
