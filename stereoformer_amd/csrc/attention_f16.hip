@@ -20,7 +20,7 @@
 namespace {
 
 template <int NT, int NWV, typename TIN>
-__global__ __launch_bounds__(NWV * 64, NWV == 6 ? 3 : 1) void cross_attention_split16_kernel(const TIN *__restrict__ L, const TIN *__restrict__ R,
+__global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const TIN *__restrict__ L, const TIN *__restrict__ R,
                                                                            float *__restrict__ out, float *__restrict__ disp,
                                                                            int C, int H, int W, int D, int mask_mode,
                                                                            float scale, int tiles_per_wg, int ntiles)
