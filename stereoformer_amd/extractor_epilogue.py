@@ -51,19 +51,27 @@ def instance_norm_relu(x, weight=None, bias=None, eps=1e-5, relu=True, out_dtype
     lib = N.load()
     ws = torch.empty(max(1, lib.stereo_instance_norm_workspace_bytes(B, C) // 8), device=x.device, dtype=torch.float64)
     with torch.cuda.device(x.device):
-        try:
-            if nhwc:   # channels-last activations (fp32 / fp16) straight from the convolution: no .contiguous() pass
+        if nhwc:   # channels-last activations (fp32 / fp16) straight from the convolution: no .contiguous() pass
+            try:
                 N.call("stereo_instance_norm_relu_nhwc", N.ptr(x), 1 if x.dtype == torch.float16 else 0, N.ptr(w), N.ptr(b),
                        N.ptr(out), N.ptr(ws), 1 if out_dtype == torch.float16 else 0, B, C, H, W, float(eps), 1 if relu else 0,
                        N.stream_ptr(x.device))
                 return out
+            except N.StereoHipError as e:
+                if e.code != N.ERR_UNSUPPORTED:
+                    raise
+                # outside the channels-last kernel's envelope (channel count, H*W % 4, a misaligned view): bring the tensor to
+                # NCHW fp32 -- the tiled relayout kernel where it applies, else contiguous() -- and take the planar kernel
+                x = N.dev_f32(x.float() if x.dtype == torch.float16 else x, "instance_norm_relu: x")
+        try:
             N.call("stereo_instance_norm_relu_f32", N.ptr(x), N.ptr(w), N.ptr(b), N.ptr(out), N.ptr(ws),
                    1 if out_dtype == torch.float16 else 0, B, C, H, W, float(eps), 1 if relu else 0, N.stream_ptr(x.device))
         except N.StereoHipError as e:
             if e.code != N.ERR_UNSUPPORTED:
                 raise
-            raise N.StereoHipError(f"instance_norm_relu: H*W = {H * W} must be a multiple of 4 (16-byte plane rows); "
-                                   "pad the image like the reference's InputPadder does", e.code) from None
+            raise N.StereoHipError(f"instance_norm_relu: the planar kernel needs H*W = {H * W} to be a multiple of 4 and 16-byte "
+                                   "aligned tensors (16-byte plane rows); pad the image like the reference's InputPadder does",
+                                   e.code) from None
     return out
 
 
