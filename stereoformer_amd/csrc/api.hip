@@ -19,10 +19,10 @@ extern "C" const char *stereo_strerror(int code)
 #include <string.h>
 
 namespace {
-const int kOptDefault[OPT_COUNT] = {1, 1, 0, 0, 0, 1, 0, 1};
+const int kOptDefault[OPT_COUNT] = {1, 1, 0, 0, 0, 1, 0, 1, 1};
 const char *const kOptName[OPT_COUNT] = {"corr_mfma", "gwc_fused", "att_kernel", "att_waves", "tiles_per_wg",
-                                         "prob_single_pass", "conv_rows", "corr_f16p"};
-std::atomic<int> g_opt[OPT_COUNT] = {{1}, {1}, {0}, {0}, {0}, {1}, {0}, {1}};
+                                         "prob_single_pass", "conv_rows", "corr_f16p", "corr_bwd_fused"};
+std::atomic<int> g_opt[OPT_COUNT] = {{1}, {1}, {0}, {0}, {0}, {1}, {0}, {1}, {1}};
 }  // namespace
 
 int stereo_opt(int which) { return g_opt[which].load(std::memory_order_relaxed); }

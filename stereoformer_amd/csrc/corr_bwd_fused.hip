@@ -1,0 +1,366 @@
+// Backward of the correlation volume (A1; the mean path of the fused volume stage; Q K^T / P V of A7 under grad) with BOTH
+// feature gradients from ONE read of the gradient volume:
+//     dL[c, w] = 1/C * sum_d g[d, w]     * R[c, w - d]
+//     dR[c, v] = 1/C * sum_d g[d, v + d] * L[c, v + d]
+// corr_mfma_bwd.hip runs two launches (dL, then dR in mirrored coordinates), each streaming the 4-GB volume through the f32
+// matrix cores; the volume is 6 x the size of everything else the backward touches, so this kernel reads it once.
+//
+// Geometry.  A workgroup walks whole image rows left to right in RECTANGLES of 128 columns x all D disparities; a rectangle is
+// streamed as 32-row BLOCKS (step s = rows 32 s .. 32 s + 31) through a three-block LDS sheet, exactly the ring of the
+// two-launch kernel.  Waves 0-3 own the four 32-column dL tiles of the rectangle: at step s wave i multiplies the key tile
+// k = w0 + 32 i - 32 s .. + 31 of R (keys x channels) by the sheet read along its diagonals, B[k][w] = g[w - k][w].  Waves 4-7
+// compute dR from the same sheet: the KEYS of dR are the rectangle's own columns, B[w][v] = g[w - v][w] (sheet columns read
+// downwards), and the outputs v = w - d lie up to D columns to the LEFT of the rectangle.  Wave i takes key tile
+// (i + s) mod 4 at step s, which makes its output tile v0 = 128 (j - r) + 32 i with r = (i + s) div 4 in {0, 1, 2}: tile i of
+// this rectangle, of the previous one or of the one before.  Because the workgroup walks the row, those three output tiles
+// are simply three accumulators the wave carries from rectangle to rectangle: after rectangle j the tile of rectangle j - 2
+// is complete and is stored -- no atomics, no partial buffers, a fixed summation order.  R's keys reach 192 columns to the left
+// of the rectangle: they are still in LDS from the rectangles before (ring of 448 keys); L is needed for the rectangle only.
+//
+// Arithmetic.  Split-fp16 on v_mfma_f32_32x32x16_f16 (6 per wave and step instead of 16 v_mfma_f32_32x32x2_f32 of twice the
+// latency): x = hi + lo, products hi hi + hi lo -> acc0, lo' hi -> acc1 (lo' = 2^11 lo on the feature side).  Features are split once per rectangle
+// when they enter LDS (same range contract as the forward's split-fp16 matrix phase: fp32-faithful for 2^-14 <= |x| < 65504).
+// GRADIENTS have no natural scale (a mean-reduced loss gives 1e-7 and below), so each wave scales its 32 x 32 gradient tile per
+// OUTPUT COLUMN by the power of two that puts that column's largest element into [2^14, 2^15) before splitting, runs the six
+// MFMAs from zero accumulators and adds acc0 / sigma + acc1 / (2^11 sigma) to its fp32 totals: a per-column scale commutes with
+// the product, so the result is fp32-faithful for every gradient magnitude in fp32's normal range.
+//
+// Latency.  One workgroup per CU (143 KB of LDS); a step's arithmetic is ~0.3 us, a loaded memory system answers in 2-3 us,
+// so the blocks of the next FOUR steps are in flight in registers (the flat item stream continues across rectangles and rows),
+// and the next rectangle's features are loaded at its predecessor's first step and stored at its last.
+//
+// C <= 32, D <= 192 (the R ring holds 32 * 6 + 128 keys in use + 128 being filled), W % 4 == 0, both gradients requested; anything else: STEREO_ERR_UNSUPPORTED (two-launch kernel).
+
+#include "common.h"
+
+namespace {
+
+constexpr int FB_TW = 128;            // rectangle columns
+constexpr int FB_NQ = FB_TW / 32;     // 32-column tiles per rectangle = waves per role
+constexpr int FB_NTH = 2 * FB_NQ * 64;
+constexpr int FB_RS = FB_TW + 2;      // sheet row stride (dwords): even (8-byte stores), (RS + 1) odd (dL diagonal reads conflict-free)
+constexpr int FB_RING = 96;           // sheet rows: three 32-row blocks
+constexpr int FB_RK = 448;            // R ring (keys): 320 in use + 128 being filled; a multiple of 32
+constexpr int FB_RB = 912;            // bytes per channel row of an R plane: 16 x odd (conflict-free ds_read_b128), >= 2 * FB_RK
+constexpr int FB_LB = 272;            // bytes per channel row of an L plane: 16 x 17
+constexpr int FB_SHEET_BYTES = FB_RING * FB_RS * 4;
+constexpr int FB_RPLANE = 32 * FB_RB, FB_LPLANE = 32 * FB_LB;
+constexpr int FB_LDS = FB_SHEET_BYTES + 2 * FB_RPLANE + 4 * FB_LPLANE;
+
+struct FbCursor {
+    int row, j, s;  // image row (b * H + h), rectangle, block
+};
+
+// gradient tile of one wave and step: 16 values per lane (two MFMAs x 8 k-slots) -> scaled split-fp16 operands
+template <bool DR>
+__device__ __forceinline__ float fb_gradient_tile(const float *__restrict__ Sh, int cs, int w0, int cb, f16x8 (&bh)[2],
+                                                  f16x8 (&bl)[2])
+{
+    constexpr int SG = DR ? 1 : -1;
+    float raw[16];
+    if (cs != 0) {
+        const float *p = Sh + (32 * cs + w0) * FB_RS + cb;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int kk = 16 * (q >> 3) + (q & 7);
+            raw[q] = p[SG * kk * FB_RS + (DR ? kk : 0)];
+        }
+    } else {  // block s-1 sits in the last slot of the ring
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int kk = 16 * (q >> 3) + (q & 7);
+            const int ro = w0 + SG * kk;
+            raw[q] = Sh[(ro + (ro < 0 ? FB_RING : 0)) * FB_RS + cb + (DR ? kk : 0)];
+        }
+    }
+    float m = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) m = fmaxf(m, fabsf(raw[q]));
+    {   // the other 16 keys of this output column live in lane ^ 32
+        const unsigned mu = __float_as_uint(m);
+        const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+        m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    int ex = (int)(__float_as_uint(m) >> 23);
+    ex = ex < 16 ? 16 : (ex > 254 ? 254 : ex);
+    const float sig = __uint_as_float((unsigned)(268 - ex) << 23);  // column max -> [2^14, 2^15)
+    // hi = fp16(x sigma), lo = fp16(x sigma - hi) UNSCALED: lo's absolute error is <= 2^-25 (fp16's subnormal spacing) against
+    // a column maximum of >= 2^14, i.e. 2^-39 of the largest term of the dot product -- the features carry the 2^11 instead
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const f32x2 t = (f32x2){raw[2 * q], raw[2 * q + 1]} * sig;
+        const f16x2 h = __builtin_convertvector(t, f16x2);
+        const f16x2 l = __builtin_convertvector(t - __builtin_convertvector(h, f32x2), f16x2);
+        bh[q >> 2][2 * (q & 3)] = h[0], bh[q >> 2][2 * (q & 3) + 1] = h[1];
+        bl[q >> 2][2 * (q & 3)] = l[0], bl[q >> 2][2 * (q & 3) + 1] = l[1];
+    }
+    return __uint_as_float((unsigned)(ex - 14) << 23);  // 1 / sigma
+}
+
+__device__ __forceinline__ void fb_products(const unsigned char *__restrict__ ahi, const unsigned char *__restrict__ alo,
+                                            const f16x8 (&bh)[2], const f16x8 (&bl)[2], float inv, f32x16 &tot)
+{
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const f16x8 ah0 = *reinterpret_cast<const f16x8 *>(ahi), ah1 = *reinterpret_cast<const f16x8 *>(ahi + 32);
+    const f16x8 al0 = *reinterpret_cast<const f16x8 *>(alo), al1 = *reinterpret_cast<const f16x8 *>(alo + 32);
+    f32x16 a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[0], z, 0, 0, 0);
+    f32x16 a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[0], z, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh[1], a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh[1], a1, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[0], a0, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl[1], a0, 0, 0, 0);
+    const float inv_lo = inv * SPLIT16_LO_UNSCALE;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tot[r] = fmaf(a1[r], inv_lo, fmaf(a0[r], inv, tot[r]));
+}
+
+__device__ __forceinline__ void fb_store_tile(float *__restrict__ out, int C, unsigned HWu, int col, int W, int half,
+                                              const f32x16 &tot, float inv_c)
+{
+    if (col < W) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (c < C) out[(unsigned)c * HWu + (unsigned)col] = tot[r] * inv_c;
+        }
+    }
+}
+
+__global__ __launch_bounds__(FB_NTH) void corr_volume_bwd_fused_kernel(const float *__restrict__ G, const float *__restrict__ Lf,
+                                                                       const float *__restrict__ Rf, float *__restrict__ dL,
+                                                                       float *__restrict__ dR, int C, int H, int W, int D,
+                                                                       float inv_c, int nrows, int rows_per_wg, int dbg)
+{
+    extern __shared__ f32x4 smem4[];
+    float *Sh = reinterpret_cast<float *>(smem4);
+    unsigned char *Rhi = reinterpret_cast<unsigned char *>(smem4) + FB_SHEET_BYTES;
+    unsigned char *Rlo = Rhi + FB_RPLANE;
+    unsigned char *Lhi = Rlo + FB_RPLANE;  // [2 buffers][hi, lo]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: roles, phases and cursors stay on the SALU
+    const int l31 = lane & 31, half = lane >> 5;
+    const bool role_dr = wave >= FB_NQ;
+    const int wi = wave & (FB_NQ - 1);
+    const unsigned HWu = (unsigned)H * (unsigned)W;
+    const int nrect = (W + FB_TW - 1) / FB_TW;
+    const int NT = max((D + 31) / 32 + 1, 5);  // blocks per rectangle; blocks at d >= D are zeros (>= 5: see the feature schedule)
+    const int row_begin = blockIdx.x * rows_per_wg;
+    const int row_end = min(nrows, row_begin + rows_per_wg);
+    if (row_begin >= row_end) return;
+    const int nitems = (row_end - row_begin) * nrect * NT;
+
+    // ---- gradient blocks: item (row, j, s) = rows 32 s .. + 31 of the volume slice of `row`, columns 128 j .. + 127.
+    //      Item t belongs to the wave PAIR t mod 4 (even wave: rows 0-15, odd wave: rows 16-31; a lane two columns, so one
+    //      512-byte row segment per wave instruction).  The pair issues item t + 4 at the top of step t and stores item t + 1 at
+    //      the end of step t: every wave has ONE statically named register set that is in flight for three steps, and the wait in
+    //      front of its LDS stores is for loads that are three steps old.  (A rotating register set shared by all waves makes the
+    //      compiler wait for everything in flight; so does overwriting a load's destination with zeros first -- hence clamped
+    //      addresses here and the zeroing at store time.)
+    const int my_phase = wave >> 1, my_rows = 16 * (wave & 1);
+    f32x2 q[16];
+    int q_d0 = D;        // first volume row of the registers' content (>= D: a zero block, nothing was loaded)
+    bool q_colok = false;
+    auto load_item = [&](const FbCursor &c) {
+        const int b = c.row / H, h = c.row - b * H;
+        const int col = FB_TW * c.j + 2 * lane;
+        q_d0 = dbg == 3 ? D : 32 * c.s + my_rows;
+        q_colok = col < W;
+        if (q_d0 < D) {
+            const float *gb = G + ((size_t)b * D * HWu + (size_t)h * W) + min(col, W - 2);
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                q[k] = *reinterpret_cast<const f32x2 *>(gb + (size_t)min(q_d0 + k, D - 1) * HWu);
+        }
+    };
+    auto store_item = [&](int slot) {
+        float *sp = Sh + (32 * slot + my_rows) * FB_RS + 2 * lane;
+        if (q_d0 < D) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const bool ok = q_colok && q_d0 + k < D;
+                *reinterpret_cast<f32x2 *>(sp + k * FB_RS) = ok ? q[k] : (f32x2){0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x2 *>(sp + k * FB_RS) = (f32x2){0.f, 0.f};
+        }
+    };
+    auto advance = [&](FbCursor &c) {
+        if (++c.s == NT) {
+            c.s = 0;
+            if (++c.j == nrect) c.j = 0, ++c.row;
+        }
+    };
+    // ---- features of a rectangle, a quarter (8 channels) per wave pair: lane = (channel, eight columns).  A pair fetches its
+    //      quarter of the NEXT rectangle right before the first gradient item it issues inside the current one (steps 0-3)
+    //      and stores it together with that item three steps later: one wait covers both.
+    const int fc = 8 * my_phase + 4 * (wave & 1) + (lane >> 4), fx = (lane & 15) * 8;
+    f32x4 fl[2], fr[2];
+    int f_col = 0;
+    bool f_pending = false;
+    auto load_features = [&](int row, int j) {
+        const int b = row / H, h = row - b * H;
+        const size_t off = (size_t)b * C * HWu + (size_t)min(fc, C - 1) * HWu + (size_t)h * W;
+        f_col = FB_TW * j + fx;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int col = min(f_col + 4 * k, W - 4);
+            fl[k] = ld4(Lf + off + col);
+            fr[k] = ld4(Rf + off + col);
+        }
+    };
+    auto store_features = [&](int lb, int rb) {
+        float x[8];
+        f16x8 p[2];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = (fc < C && f_col + 4 * (k >> 2) < W) ? fl[k >> 2][k & 3] : 0.0f;
+        split_oct_f16(x, p);
+        unsigned char *lp = Lhi + lb * 2 * FB_LPLANE + fc * FB_LB + 2 * fx;
+        *reinterpret_cast<f16x8 *>(lp) = p[0];
+        *reinterpret_cast<f16x8 *>(lp + FB_LPLANE) = p[1];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = (fc < C && f_col + 4 * (k >> 2) < W) ? fr[k >> 2][k & 3] : 0.0f;
+        split_oct_f16(x, p);
+        int pos = rb + fx;
+        pos = pos >= FB_RK ? pos - FB_RK : pos;
+        *reinterpret_cast<f16x8 *>(Rhi + fc * FB_RB + 2 * pos) = p[0];
+        *reinterpret_cast<f16x8 *>(Rlo + fc * FB_RB + 2 * pos) = p[1];
+    };
+
+    // ---- prologue
+    FbCursor lc = {row_begin, 0, 0};  // this wave pair's next item
+    int li = my_phase;                // ... and its index in the stream
+    for (int k = 0; k < my_phase; ++k) advance(lc);
+    load_features(row_begin, 0);
+    if (li < nitems) load_item(lc);
+    store_features(0, 0);
+    if (my_phase == 0) {
+        store_item(0);
+        li += 4;
+        for (int k = 0; k < 4; ++k) advance(lc);
+        if (li < nitems) load_item(lc);
+    } else if (my_phase == 1) {
+        // "block -1" of the first step (d < 0): zeros
+#pragma unroll
+        for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x2 *>(Sh + (64 + my_rows + k) * FB_RS + 2 * lane) = (f32x2){0.f, 0.f};
+    }
+    __syncthreads();
+
+    f32x16 t0, t1, t2;  // dL waves: t0; dR waves: output tiles of rectangles j, j-1, j-2
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t0[r] = t1[r] = t2[r] = 0.0f;
+
+    FbCursor cc = {row_begin, 0, 0};
+    int cs = 0;        // ring slot of the current block; block s-1 is in slot cs-1 (mod 3)
+    int rbase = 0;     // ring position of the current rectangle's first key
+    int lbuf = 0;
+    const int w0 = role_dr ? 8 * half - l31 : l31 - 8 * half;
+#pragma unroll 1
+    for (int t = 0; t < nitems; ++t) {
+        // next rectangle of this workgroup
+        int nrow = cc.row, nj = cc.j + 1;
+        if (nj == nrect) nj = 0, ++nrow;
+        const bool has_next = nrow < row_end;
+        const bool last_step = cc.s == NT - 1;
+        if ((t & 3) == my_phase) {
+            if (cc.s < 4 && has_next) load_features(nrow, nj), f_pending = true;
+            // item t went to the sheet at the end of step t - 1: fetch item t + 4 into the same registers
+            if (t > 0) {
+                li += 4;
+                for (int k = 0; k < 4; ++k) advance(lc);
+                if (li < nitems) load_item(lc);
+            }
+        }
+
+        if (dbg == 2) {
+        } else if (!role_dr) {
+            const int kb = FB_TW * cc.j + 32 * wi - 32 * cc.s;  // first key of the step's key tile
+            if (kb >= 0 && FB_TW * cc.j + 32 * wi < W) {
+                f16x8 bh[2], bl[2];
+                const float inv = fb_gradient_tile<false>(Sh, cs, w0, 32 * wi + l31, bh, bl);
+                int pos = rbase + 32 * wi - 32 * cc.s;
+                pos = pos < 0 ? pos + FB_RK : (pos >= FB_RK ? pos - FB_RK : pos);
+                const int ao = l31 * FB_RB + 2 * (pos + 8 * half);
+                fb_products(Rhi + ao, Rlo + ao, bh, bl, inv, t0);
+            }
+        } else {
+            const int kt = (wi + cc.s) & (FB_NQ - 1), r = (wi + cc.s) / FB_NQ;
+            if (cc.j - r >= 0 && FB_TW * cc.j + 32 * kt < W) {
+                f16x8 bh[2], bl[2];
+                const float inv = fb_gradient_tile<true>(Sh, cs, w0, 32 * kt + 8 * half, bh, bl);
+                const unsigned char *ap = Lhi + lbuf * 2 * FB_LPLANE + l31 * FB_LB + 2 * (32 * kt + 8 * half);
+                if (r == 0) fb_products(ap, ap + FB_LPLANE, bh, bl, inv, t0);
+                else if (r == 1) fb_products(ap, ap + FB_LPLANE, bh, bl, inv, t1);
+                else fb_products(ap, ap + FB_LPLANE, bh, bl, inv, t2);
+            }
+        }
+
+        // -- item t + 1 into the sheet slot of item t - 2 (its last readers passed the previous barrier)
+        const int ns = cs == 2 ? 0 : cs + 1;
+        const bool my_store = ((t + 1) & 3) == my_phase;
+        if (my_store && t + 1 < nitems) store_item(ns);
+        const int nb = rbase + FB_TW >= FB_RK ? rbase + FB_TW - FB_RK : rbase + FB_TW;
+        if (f_pending && (my_store || last_step)) store_features(lbuf ^ 1, nb), f_pending = false;
+
+        // -- results of the rectangle (after the LDS stores: the next wait of this wave is a step away)
+        if (last_step) {
+            const int b = cc.row / H, h = cc.row - b * H;
+            const int oc = FB_TW * cc.j + 32 * wi + l31;
+            if (!role_dr) {
+                fb_store_tile(dL + ((size_t)b * C * HWu + (size_t)h * W), C, HWu, oc, W, half, t0, inv_c);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t0[r] = 0.0f;
+            } else {
+                float *ob = dR + ((size_t)b * C * HWu + (size_t)h * W);
+                if (cc.j >= 2) fb_store_tile(ob, C, HWu, oc - 2 * FB_TW, W, half, t2, inv_c);
+                if (cc.j == nrect - 1) {  // end of the row: nothing to the right contributes any more
+                    if (cc.j >= 1) fb_store_tile(ob, C, HWu, oc - FB_TW, W, half, t1, inv_c);
+                    fb_store_tile(ob, C, HWu, oc, W, half, t0, inv_c);
+#pragma unroll
+                    for (int r2 = 0; r2 < 16; ++r2) t0[r2] = t1[r2] = t2[r2] = 0.0f;
+                } else {
+#pragma unroll
+                    for (int r2 = 0; r2 < 16; ++r2) t2[r2] = t1[r2], t1[r2] = t0[r2], t0[r2] = 0.0f;
+                }
+            }
+            rbase = nb, lbuf ^= 1;
+        }
+        advance(cc);
+        cs = ns;
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// grad_vol [B,D,H,W] -> grad_left AND grad_right [B,C,H,W] from one pass over grad_vol.  STEREO_ERR_UNSUPPORTED outside the
+// envelope (the caller then runs the two-launch kernel of corr_mfma_bwd.hip).
+int stereo_corr_volume_bwd_fused(const float *left, const float *right, const float *grad_vol, float *grad_left,
+                                 float *grad_right, int B, int C, int H, int W, int D, hipStream_t st)
+{
+    if (!grad_left || !grad_right || C > 32 || C < 1 || D > 192 || D < 1 || W % 4 != 0 || B < 1 || H < 1 || W < 4)
+        return STEREO_ERR_UNSUPPORTED;
+    if (!aligned16(left) || !aligned16(right) || !aligned16(grad_vol)) return STEREO_ERR_UNSUPPORTED;
+    if ((long long)32 * H * W >= (1LL << 31) || (long long)D * H * W >= (1LL << 31) || (long long)B * H >= (1LL << 30))
+        return STEREO_ERR_UNSUPPORTED;
+    auto kern = corr_volume_bwd_fused_kernel;
+    static std::atomic<unsigned long long> lds_done{0};
+    if (!lds_opt_in(kern, FB_LDS, lds_done)) return STEREO_ERR_UNSUPPORTED;
+    static std::atomic<int> ncu_cache{0};
+    int ncu = ncu_cache.load(std::memory_order_relaxed);
+    if (ncu <= 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1)
+            ncu = 256;
+        ncu_cache.store(ncu, std::memory_order_relaxed);
+    }
+    const int nrows = B * H;
+    const int rpw = (nrows + ncu - 1) / ncu;  // one resident workgroup per CU, contiguous rows each
+    const int nwg = (nrows + rpw - 1) / rpw;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(FB_NTH), FB_LDS, st, grad_vol, left, right, grad_left, grad_right, C, H, W, D,
+                       1.0f / (float)C, nrows, rpw, stereo_opt(OPT_CORR_BWD_FUSED));
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}

@@ -21,6 +21,7 @@ constexpr int CB_NWV = 8;
 constexpr int CB_TQW = 32 * CB_NWV;
 constexpr int CB_RSTR = CB_TQW + 4;
 constexpr int CB_RING = 96;
+constexpr int CB_PD = 3;  // gradient blocks in flight (registers)
 
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 4-byte aligned quad (sheared rows)
 
@@ -115,10 +116,15 @@ __global__ __launch_bounds__(CB_NWV * 64) void corr_volume_bwd_mfma_kernel(const
                 *reinterpret_cast<f32x4 *>(Sh + (32 * slot + row) * CB_RSTR + 4 * c4) = q[k];
             }
         };
+        // gradient blocks travel PD steps ahead of their use in registers: one step's arithmetic (~0.5 us) is far shorter
+        // than a loaded memory system's latency, and the LDS footprint allows one workgroup per CU
+        f32x4 qn[CB_PD][4];
         {
-            f32x4 q0[4];
-            load_block(0, q0);
-            store_block(0, q0);
+            load_block(0, qn[0]);
+#pragma unroll
+            for (int j = 1; j < CB_PD; ++j)
+                if (j < NT) load_block(j, qn[j]);
+            store_block(0, qn[0]);
             const f32x4 z[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             store_block(2, z);  // rows -31 .. -1 of step 0 (d < 0): zeros
         }
@@ -128,11 +134,9 @@ __global__ __launch_bounds__(CB_NWV * 64) void corr_volume_bwd_mfma_kernel(const
         f32x16 o;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] = 0.0f;
-#pragma unroll 1
+#pragma unroll
         for (int s = 0; s < NT; ++s) {
-            f32x4 qn[4];
-            const bool fill = s + 1 < NT;  // block s+1 is needed by step s+1
-            if (fill) load_block(s + 1, qn);
+            if (s + CB_PD < NT) load_block(s + CB_PD, qn[s % CB_PD]);  // its previous content (block s) is in the sheet
             if (wave_on) {
                 const int sb = s % 3;
                 const float *rp = Sh + lane_base + 32 * sb * CB_RSTR;
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(CB_NWV * 64) void corr_volume_bwd_mfma_kernel(const
                     }
                 }
             }
-            if (fill) store_block((s + 1) % 3, qn);  // slot of block s-2: its last readers passed the previous barrier
+            if (s + 1 < NT) store_block((s + 1) % 3, qn[(s + 1) % CB_PD]);  // slot of block s-2: its last readers passed the previous barrier
             __syncthreads();
         }
         if (wave_on) {
@@ -190,11 +194,18 @@ int launch_cb(const float *G, const float *X, float *dOut, int B, int C, int H, 
 
 }  // namespace
 
+int stereo_corr_volume_bwd_fused(const float *left, const float *right, const float *grad_vol, float *grad_left,
+                                 float *grad_right, int B, int C, int H, int W, int D, hipStream_t st);  // corr_bwd_fused.hip
+
 // grad_vol [B,D,H,W] -> grad_left / grad_right [B,C,H,W] (either may be null).  STEREO_ERR_UNSUPPORTED outside the
 // envelope (the caller then runs the VALU backward).
 int stereo_corr_volume_bwd_mfma(const float *left, const float *right, const float *grad_vol, float *grad_left,
                                 float *grad_right, int B, int C, int H, int W, int D, hipStream_t st)
 {
+    if (grad_left && grad_right && stereo_opt(OPT_CORR_BWD_FUSED)) {
+        const int rc = stereo_corr_volume_bwd_fused(left, right, grad_vol, grad_left, grad_right, B, C, H, W, D, st);
+        if (rc != STEREO_ERR_UNSUPPORTED) return rc;
+    }
     if (C > 32 || D > 192 || D < 1 || W % 4 != 0 || !aligned16(left) || !aligned16(right) || !aligned16(grad_vol))
         return STEREO_ERR_UNSUPPORTED;
     if ((long long)32 * H * W >= (1LL << 31) || (long long)D * H * W >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;

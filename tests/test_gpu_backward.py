@@ -332,6 +332,51 @@ def test_corr_volume_backward_mfma_vs_valu_vs_torch(S, shape):
             close(a, b.cpu().numpy(), rtol=1e-4, atol=5e-5)
 
 
+def _corr_bwd_fp64(L, R, cot):
+    """dL, dR of vol[b, d, h, w] = mean_c L[b, c, h, w] R[b, c, h, w - d] in fp64 (plain shifted products)."""
+    B, C, H, W = L.shape
+    D = cot.shape[1]
+    L, R, cot = L.double(), R.double(), cot.double()
+    dL, dR = torch.zeros_like(L), torch.zeros_like(R)
+    for d in range(min(D, W)):
+        g = cot[:, d:d + 1, :, d:] / C
+        dL[..., d:] += g * R[..., :W - d]
+        dR[..., :W - d] += g * L[..., d:]
+    return dL, dR
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 3, 960, 192), (2, 12, 4, 520, 150), (1, 5, 3, 388, 180), (2, 8, 200, 260, 40),
+                                   (1, 32, 2, 128, 33), (1, 3, 2, 8, 1), (1, 7, 600, 132, 70), (1, 32, 2, 1216, 192)])
+@pytest.mark.parametrize("gscale", [1.0, 3e-9, 2e7])
+def test_corr_volume_backward_single_read_kernel(S, shape, gscale):
+    """Round 3: both A1 feature gradients from ONE pass over the gradient volume (corr_bwd_fused.hip: row-walking
+    workgroups, dR tiles carried across rectangles, split-fp16 products with a per-output-column power-of-two scale on the
+    gradient tile) against fp64 and against the two-launch f32-MFMA kernel, for gradient magnitudes far outside fp16's
+    range (a mean-reduced loss hands over 1e-9-sized gradients).  Shapes: several rectangles per row with a ragged last
+    one, D not a multiple of 32 and at the 192 limit, C < 32, more rows than CUs (workgroups chain rows), tiny W."""
+    B, C, H, W, D = shape
+    torch.manual_seed(33)
+    L0, R0 = torch.randn(B, C, H, W, device="cuda"), torch.randn(B, C, H, W, device="cuda")
+    cot = torch.randn(B, D, H, W, device="cuda") * gscale
+    got = {}
+    for fused in (1, 0):
+        with S._native.test_options(corr_bwd_fused=fused):
+            L, R = L0.clone().requires_grad_(True), R0.clone().requires_grad_(True)
+            vol = S.CostVolume(D)(L, R)
+            got[fused] = [g.double() / gscale for g in torch.autograd.grad(vol, [L, R], cot)]
+    ref = [g / gscale for g in _corr_bwd_fp64(L0, R0, cot)]
+    bound = 0.0
+    for k in (1, 0):
+        for a, b in zip(got[k], ref):
+            err = (a - b).abs().max().item()
+            assert err <= 2e-5, (k, err)      # fp32 accumulation over <= 256 x 32 products of N(0,1) values / C
+            bound = max(bound, err)
+    # the split-fp16 kernel is as close to fp64 as the f32 matrix cores, up to the 2^-22 of a product of two 22-bit operands
+    e1 = max((a - b).abs().max().item() for a, b in zip(got[1], ref))
+    e0 = max((a - b).abs().max().item() for a, b in zip(got[0], ref))
+    assert e1 <= 2.0 * e0 + 5e-7, (e1, e0)
+
+
 # ------------------------------------------------------------------ round 2: A6, A2, A7
 def test_variance_lookup_backward_g15(S, golden):
     """A6 (Variance_Based_Local_Cost_Volume) gradients w.r.t. the volume and the disparity against the reference's own
