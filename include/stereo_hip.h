@@ -213,6 +213,14 @@ int stereo_gru_blend_f16(const void *h, const void *zc, const void *qc, const vo
 int stereo_soft_argmin_bwd_f32(const float *vol, const float *grad_disp, const float *grad_prob,
                                float *grad_vol, int B, int D, int H, int W, int match_similarity, void *stream);
 
+/* the same, with a second cotangent of the SAME volume added on the way out: grad_vol = addend + d disp / d vol * grad_disp
+ * (the volume of estimation.py:14-33 also feeds fixed_local_cost_volume.py:18-80 in the reference's chain, so its gradient
+ * is a sum of two terms; autograd would form it with an extra read-read-write pass).  addend, grad_vol [B,D,H,W] (may alias:
+ * every element is read before it is written by the same lane).  HW % 4 == 0, D <= 192, else STEREO_ERR_UNSUPPORTED and
+ * the caller adds the cotangents itself. */
+int stereo_soft_argmin_bwd_add_f32(const float *vol, const float *grad_disp, const float *addend, float *grad_vol,
+                                   int B, int D, int H, int W, int match_similarity, void *stream);
+
 /* backward of A1/A3 (build_cost_volume.py:39-47, GWC_Cost_Volume.py:14-24): grad_vol [B,G,D,H,W] ->
  * grad_left, grad_right [B,C,H,W] (either may be NULL); G = 1 for the correlation volume */
 int stereo_gwc_volume_bwd_f32(const float *left, const float *right, const float *grad_vol,

@@ -69,13 +69,27 @@ class _GwcWithDisparityFn(torch.autograd.Function):
         dev = left.device
         gm = None
         with torch.cuda.device(dev):
-            if g_disp is not None:  # soft-argmin backward on the mean volume
-                gm = torch.empty_like(mean)
-                N.call("stereo_soft_argmin_bwd_f32", N.ptr(mean), N.ptr(N.dev_f32(g_disp, "fused volume backward: grad_disp")),
-                       N.ptr(None), N.ptr(gm), B, D, H, W, 1 if sim else 0, N.stream_ptr(dev))
             if g_mean is not None:
                 g_mean = N.dev_f32(g_mean, "fused volume backward: grad_mean")
-                gm = g_mean if gm is None else gm + g_mean
+            if g_disp is not None:  # soft-argmin backward on the mean volume
+                g_disp = N.dev_f32(g_disp, "fused volume backward: grad_disp")
+                gm = torch.empty_like(mean)
+                fused_add = False
+                if g_mean is not None:  # both cotangents of the mean volume: summed inside the soft-argmin backward
+                    try:
+                        N.call("stereo_soft_argmin_bwd_add_f32", N.ptr(mean), N.ptr(g_disp), N.ptr(g_mean), N.ptr(gm), B, D, H, W,
+                               1 if sim else 0, N.stream_ptr(dev))
+                        fused_add = True
+                    except N.StereoHipError as e:
+                        if e.code != N.ERR_UNSUPPORTED:
+                            raise
+                if not fused_add:
+                    N.call("stereo_soft_argmin_bwd_f32", N.ptr(mean), N.ptr(g_disp), N.ptr(None), N.ptr(gm), B, D, H, W,
+                           1 if sim else 0, N.stream_ptr(dev))
+                    if g_mean is not None:
+                        gm = gm + g_mean
+            elif g_mean is not None:
+                gm = g_mean
             gl = gr = None
 
             def vol_bwd(gv, groups):

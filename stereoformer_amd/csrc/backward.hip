@@ -68,9 +68,12 @@ __global__ __launch_bounds__(256) void soft_argmin_bwd_kernel(const float *__res
 // 64 / SPLIT pixel quads, the D planes are dealt round-robin to NWV * SPLIT phases, every lane keeps its J planes of one quad
 // with all J loads in flight, max and sums meet in LDS (two barriers):  the volume is read once and the gradient written
 // once (the two-pass kernel above reads it twice: 1.93 ms at cfg-2 against 1.22 ms for the forward with probabilities).
-template <int J, int NWV, int SPLIT>
+// ADD: the gradient is ADDED to a second cotangent of the same volume (`addend`, e.g. what a lookup on the volume sent
+// back) on its way out -- the sum autograd would otherwise form with a separate read-read-write pass over the volume.
+template <int J, int NWV, int SPLIT, bool ADD>
 __global__ __launch_bounds__(NWV * 64) void soft_argmin_bwd_regs_kernel(const float *__restrict__ vol,
                                                                         const float *__restrict__ gdisp,
+                                                                        const float *__restrict__ addend,
                                                                         float *__restrict__ gvol, int D, long long HW, float sgn)
 {
     constexpr int QPW = 64 / SPLIT, NPH = NWV * SPLIT;
@@ -140,9 +143,10 @@ __global__ __launch_bounds__(NWV * 64) void soft_argmin_bwd_regs_kernel(const fl
     for (int j = 0; j < J; ++j) {
         const int d = ph + NPH * j;
         if (d < D) {
-            f32x4 q;
+            f32x4 q = {0.f, 0.f, 0.f, 0.f};
+            if (ADD) q = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(addend + boff + (size_t)d * HW));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) q[i] = x[j][i] * sc[i] * ((float)d - dm[i]);   // sgn p_d g (d - disp)
+            for (int i = 0; i < 4; ++i) q[i] = fmaf(x[j][i] * sc[i], (float)d - dm[i], q[i]);   // sgn p_d g (d - disp)
             st4(o + (size_t)d * HW, q);
         }
     }
@@ -829,9 +833,9 @@ extern "C" int stereo_soft_argmin_bwd_f32(const float *vol, const float *grad_di
     if (vec && !grad_prob && D <= 192 && fits_grid_yz(B) && aligned16(vol) && aligned16(grad_disp) && aligned16(grad_vol) &&
         stereo_opt(OPT_PROB_SINGLE_PASS) != 0) {   // one pass over the volume: the softmax column in registers
 #define SAB_REGS(JV, NWVV, SPL)                                                                                             \
-    hipLaunchKernelGGL((soft_argmin_bwd_regs_kernel<JV, NWVV, SPL>),                                                        \
+    hipLaunchKernelGGL((soft_argmin_bwd_regs_kernel<JV, NWVV, SPL, false>),                                                 \
                        dim3((unsigned)((HW / 4 + 64 / SPL - 1) / (64 / SPL)), (unsigned)B), dim3(NWVV * 64), 0, st, vol,    \
-                       grad_disp, grad_vol, D, HW, sgn)
+                       grad_disp, nullptr, grad_vol, D, HW, sgn)
         if (D <= 48) SAB_REGS(12, 4, 1);
         else if (D <= 96) SAB_REGS(24, 4, 1);
         else SAB_REGS(24, 4, 2);
@@ -841,6 +845,33 @@ extern "C" int stereo_soft_argmin_bwd_f32(const float *vol, const float *grad_di
     else if (grad_prob) SAB(1, true);
     else SAB(1, false);
 #undef SAB
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
+extern "C" int stereo_soft_argmin_bwd_add_f32(const float *vol, const float *grad_disp, const float *addend, float *grad_vol,
+                                              int B, int D, int H, int W, int match_similarity, void *stream)
+{
+    if (B < 0 || D < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || H == 0 || W == 0 || D == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(vol);
+    STEREO_REQUIRE_PTR(grad_disp);
+    STEREO_REQUIRE_PTR(addend);
+    STEREO_REQUIRE_PTR(grad_vol);
+    const long long HW = (long long)H * W;
+    if (HW % 4 != 0 || D > 192 || !fits_grid_yz(B) || !aligned16(vol) || !aligned16(grad_disp) || !aligned16(addend) ||
+        !aligned16(grad_vol))
+        return STEREO_ERR_UNSUPPORTED;  // the caller adds the two cotangents itself
+    const float sgn = match_similarity ? 1.0f : -1.0f;
+    hipStream_t st = as_stream(stream);
+#define SAB_REGS(JV, NWVV, SPL)                                                                                             \
+    hipLaunchKernelGGL((soft_argmin_bwd_regs_kernel<JV, NWVV, SPL, true>),                                                  \
+                       dim3((unsigned)((HW / 4 + 64 / SPL - 1) / (64 / SPL)), (unsigned)B), dim3(NWVV * 64), 0, st, vol,    \
+                       grad_disp, addend, grad_vol, D, HW, sgn)
+    if (D <= 48) SAB_REGS(12, 4, 1);
+    else if (D <= 96) SAB_REGS(24, 4, 1);
+    else SAB_REGS(24, 4, 2);
+#undef SAB_REGS
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }

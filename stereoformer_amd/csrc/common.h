@@ -23,7 +23,8 @@ enum StereoOpt {
     OPT_PROB_SINGLE_PASS,  // 1 (default): softmax column in registers (D <= 192); 0: two-pass kernel
     OPT_CONV_ROWS,       // 0 (default): pixel-tile rows of the split-fp16 convolution by launch size; 2 / 4: forced
     OPT_CORR_F16P,       // 1 (default): split-fp16 matrix phase of the A1 volume kernel; 0: f32 MFMA
-    OPT_CORR_BWD_FUSED,  // 1 (default): A1 backward reads the gradient volume once (corr_bwd_fused.hip); 0: two launches
+    OPT_CORR_BWD_FUSED,  // 1 (default): A1 backward reads the gradient volume once (corr_bwd_fused.hip); 0: two launches;
+                         // 2 / 3: timing ablations of the one-read kernel (no arithmetic / no volume loads)
     OPT_COUNT
 };
 int stereo_opt(int which);

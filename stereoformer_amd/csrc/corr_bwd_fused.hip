@@ -17,19 +17,34 @@
 // is complete and is stored -- no atomics, no partial buffers, a fixed summation order.  R's keys reach 192 columns to the left
 // of the rectangle: they are still in LDS from the rectangles before (ring of 448 keys); L is needed for the rectangle only.
 //
-// Arithmetic.  Split-fp16 on v_mfma_f32_32x32x16_f16 (6 per wave and step instead of 16 v_mfma_f32_32x32x2_f32 of twice the
-// latency): x = hi + lo, products hi hi + hi lo -> acc0, lo' hi -> acc1 (lo' = 2^11 lo on the feature side).  Features are split once per rectangle
-// when they enter LDS (same range contract as the forward's split-fp16 matrix phase: fp32-faithful for 2^-14 <= |x| < 65504).
-// GRADIENTS have no natural scale (a mean-reduced loss gives 1e-7 and below), so each wave scales its 32 x 32 gradient tile per
-// OUTPUT COLUMN by the power of two that puts that column's largest element into [2^14, 2^15) before splitting, runs the six
-// MFMAs from zero accumulators and adds acc0 / sigma + acc1 / (2^11 sigma) to its fp32 totals: a per-column scale commutes with
-// the product, so the result is fp32-faithful for every gradient magnitude in fp32's normal range.
+// Arithmetic.  Split-fp16 on v_mfma_f32_32x32x16_f16 (6 per wave and step): x = hi + lo, products hi hi + hi lo -> acc0,
+// lo' hi -> acc1 with lo' = 2^11 lo on the feature side.  Features are split once per rectangle when they enter LDS (the range
+// contract of the forward's split-fp16 matrix phase: fp32-faithful for 2^-14 <= |x| < 65504).  GRADIENTS have no natural
+// scale (a mean-reduced loss hands over 1e-9), so each wave scales its 32 x 32 gradient tile per OUTPUT COLUMN by the power of
+// two that puts the column's largest element into [2^14, 2^15) before splitting -- a per-column scale commutes with the
+// product -- runs the six MFMAs from zero accumulators and adds acc0 / sigma + acc1 / (2^11 sigma) to its fp32 totals.  The
+// gradient's low piece stays UNSCALED: against a column maximum >= 2^14 its absolute error (fp16's subnormal spacing) is 2^-39
+// of the largest term of the dot product.  Result: as close to fp64 as the f32 matrix cores for gradients from 3e-9 to 2e7
+// (tests/test_gpu_backward.py::test_corr_volume_backward_single_read_kernel).
+// Measured alternatives (cfg-2 size, 8 pairs; this form 1.49 ms): all sixteen v_mfma_f32_32x32x2_f32 per step on the raw values
+// (no operand preparation at all) 1.81 ms, f32 MFMAs for the dR waves only 1.66 ms -- the f32 matrix pipe at 64 cycles per
+// instruction is the slower resource.  This form runs the vector pipe at ~40 % and the matrix pipe at 9 %: its step time
+// (1.5 us for 16 KB of volume per CU) is the dependent chain LDS read -> column maximum -> split -> MFMA -> totals of two waves
+// per SIMD behind one barrier per step (in-kernel cycle stamps: a dR wave needs ~3 000 cycles per step, a dL wave ~2 150).
+// Ablations (test option corr_bwd_fused = 2 / 3): without arithmetic 1.06 ms (5.0 TB/s), without the volume loads 1.16 ms.
 //
-// Latency.  One workgroup per CU (143 KB of LDS); a step's arithmetic is ~0.3 us, a loaded memory system answers in 2-3 us,
-// so the blocks of the next FOUR steps are in flight in registers (the flat item stream continues across rectangles and rows),
-// and the next rectangle's features are loaded at its predecessor's first step and stored at its last.
+// Data movement.  One workgroup per CU (143 KB of LDS).  The dL waves, whose arithmetic is the shorter one, move the data:
+// their two wave pairs take the blocks in turn, block t + 2 is issued at the top of step t into the pair's ONE statically named
+// register set and goes to the sheet at the end of step t + 1 (two steps = ~3 us in flight; the flat stream of blocks
+// continues across rectangles and rows), so every mover wave does one burst per step, loads or stores, and reaches the
+// barrier about when the dR waves do.  Tried and measured slower: all eight waves taking turns with four blocks in flight
+// (1.53 ms: the pair whose turn it was arrived 1 000-1 300 cycles late, every step); every wave moving four rows of every
+// block through four rotating register sets pinned outside the compiler's allocation, loads and waits in inline assembly
+// (1.78 ms: the per-step scalar bookkeeping then sits on all eight waves' critical path).  The next rectangle's features
+// travel with the pairs' own blocks (loaded right before a block's loads, stored with it).
 //
-// C <= 32, D <= 192 (the R ring holds 32 * 6 + 128 keys in use + 128 being filled), W % 4 == 0, both gradients requested; anything else: STEREO_ERR_UNSUPPORTED (two-launch kernel).
+// C <= 32, D <= 192 (the R ring holds 192 + 128 keys in use + 128 being filled), W % 4 == 0, both gradients requested;
+// anything else: STEREO_ERR_UNSUPPORTED (the caller runs the two-launch kernel).
 
 #include "common.h"
 
@@ -86,14 +101,23 @@ __device__ __forceinline__ float fb_gradient_tile(const float *__restrict__ Sh, 
     const float sig = __uint_as_float((unsigned)(268 - ex) << 23);  // column max -> [2^14, 2^15)
     // hi = fp16(x sigma), lo = fp16(x sigma - hi) UNSCALED: lo's absolute error is <= 2^-25 (fp16's subnormal spacing) against
     // a column maximum of >= 2^14, i.e. 2^-39 of the largest term of the dot product -- the features carry the 2^11 instead
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v hv[2], lv[2];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const f32x2 t = (f32x2){raw[2 * q], raw[2 * q + 1]} * sig;
         const f16x2 h = __builtin_convertvector(t, f16x2);
-        const f16x2 l = __builtin_convertvector(t - __builtin_convertvector(h, f32x2), f16x2);
-        bh[q >> 2][2 * (q & 3)] = h[0], bh[q >> 2][2 * (q & 3) + 1] = h[1];
-        bl[q >> 2][2 * (q & 3)] = l[0], bl[q >> 2][2 * (q & 3) + 1] = l[1];
+        const unsigned hu = __builtin_bit_cast(unsigned, h);
+        // x sigma - hi in ONE mixed-precision FMA per element (fp32 arithmetic on an fp16 source, fp16 result into one half
+        // of the destination) -- the compiler's own choice is two conversions back to fp32 and a packed FMA
+        unsigned lu;
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lu) : "v"(raw[2 * q]), "v"(sig), "v"(hu));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lu) : "v"(raw[2 * q + 1]), "v"(sig), "v"(hu));
+        hv[q >> 2][q & 3] = hu;
+        lv[q >> 2][q & 3] = lu;
     }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bh[j] = __builtin_bit_cast(f16x8, hv[j]), bl[j] = __builtin_bit_cast(f16x8, lv[j]);
     return __uint_as_float((unsigned)(ex - 14) << 23);  // 1 / sigma
 }
 
@@ -131,6 +155,8 @@ __global__ __launch_bounds__(FB_NTH) void corr_volume_bwd_fused_kernel(const flo
                                                                        float *__restrict__ dR, int C, int H, int W, int D,
                                                                        float inv_c, int nrows, int rows_per_wg, int dbg)
 {
+    // dbg = the test option corr_bwd_fused: 1 product; 2 / 3 ablations for tools/a1bwd_ab.py (2: no arithmetic, 3: no
+    // volume loads -- results are then meaningless, only the time is read)
     extern __shared__ f32x4 smem4[];
     float *Sh = reinterpret_cast<float *>(smem4);
     unsigned char *Rhi = reinterpret_cast<unsigned char *>(smem4) + FB_SHEET_BYTES;
@@ -144,38 +170,52 @@ __global__ __launch_bounds__(FB_NTH) void corr_volume_bwd_fused_kernel(const flo
     const int wi = wave & (FB_NQ - 1);
     const unsigned HWu = (unsigned)H * (unsigned)W;
     const int nrect = (W + FB_TW - 1) / FB_TW;
-    const int NT = max((D + 31) / 32 + 1, 5);  // blocks per rectangle; blocks at d >= D are zeros (>= 5: see the feature schedule)
+    const int NT = max((D + 31) / 32 + 1, 3);  // blocks per rectangle; blocks at d >= D are zeros
     const int row_begin = blockIdx.x * rows_per_wg;
     const int row_end = min(nrows, row_begin + rows_per_wg);
     if (row_begin >= row_end) return;
     const int nitems = (row_end - row_begin) * nrect * NT;
 
     // ---- gradient blocks: item (row, j, s) = rows 32 s .. + 31 of the volume slice of `row`, columns 128 j .. + 127.
-    //      Item t belongs to the wave PAIR t mod 4 (even wave: rows 0-15, odd wave: rows 16-31; a lane two columns, so one
-    //      512-byte row segment per wave instruction).  The pair issues item t + 4 at the top of step t and stores item t + 1 at
-    //      the end of step t: every wave has ONE statically named register set that is in flight for three steps, and the wait in
-    //      front of its LDS stores is for loads that are three steps old.  (A rotating register set shared by all waves makes the
-    //      compiler wait for everything in flight; so does overwriting a load's destination with zeros first -- hence clamped
-    //      addresses here and the zeroing at store time.)
-    const int my_phase = wave >> 1, my_rows = 16 * (wave & 1);
+    //      The dL waves move the data (their arithmetic is ~800 cycles per step shorter than the dR waves': one accumulator,
+    //      conflict-free sheet reads): item t belongs to the wave PAIR t mod 2 of them (even wave: rows 0-15, odd wave: rows
+    //      16-31; a lane two columns, so one 512-byte row segment per wave instruction).  A pair issues item t + 2 at the top of
+    //      step t and stores it at the end of step t + 1: every mover wave has ONE statically named register set, in flight for
+    //      two steps (~3 us), and does one burst per step -- loads or stores.  (Measured with in-kernel cycle stamps: with
+    //      all eight waves taking turns the pair whose turn it was reached the step's barrier 1 000-1 300 cycles after the
+    //      others every step; a rotating register set shared by all waves makes the compiler wait for everything in flight;
+    //      so does overwriting a load's destination with zeros first -- hence clamped addresses and the zeroing at store time.)
+    const bool mover = wave < FB_NQ;
+    const int my_phase = (wave >> 1) & 1, my_rows = 16 * (wave & 1);
     f32x2 q[16];
     int q_d0 = D;        // first volume row of the registers' content (>= D: a zero block, nothing was loaded)
     bool q_colok = false;
+    bool q_full = false;  // every row and column of the registers' content is inside the volume
     auto load_item = [&](const FbCursor &c) {
         const int b = c.row / H, h = c.row - b * H;
         const int col = FB_TW * c.j + 2 * lane;
         q_d0 = dbg == 3 ? D : 32 * c.s + my_rows;
         q_colok = col < W;
+        q_full = q_d0 + 16 <= D && FB_TW * (c.j + 1) <= W;
         if (q_d0 < D) {
-            const float *gb = G + ((size_t)b * D * HWu + (size_t)h * W) + min(col, W - 2);
+            const float *gb = G + ((size_t)b * D * HWu + (size_t)h * W) + (size_t)q_d0 * HWu;  // wave-uniform
+            const int co = min(col, W - 2);
+            if (q_d0 + 16 <= D) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                q[k] = *reinterpret_cast<const f32x2 *>(gb + (size_t)min(q_d0 + k, D - 1) * HWu);
+                for (int k = 0; k < 16; ++k) q[k] = *reinterpret_cast<const f32x2 *>(gb + (size_t)k * HWu + co);
+            } else {
+                const int kmax = D - 1 - q_d0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) q[k] = *reinterpret_cast<const f32x2 *>(gb + (size_t)min(k, kmax) * HWu + co);
+            }
         }
     };
     auto store_item = [&](int slot) {
         float *sp = Sh + (32 * slot + my_rows) * FB_RS + 2 * lane;
-        if (q_d0 < D) {
+        if (q_full) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x2 *>(sp + k * FB_RS) = q[k];
+        } else if (q_d0 < D) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const bool ok = q_colok && q_d0 + k < D;
@@ -192,58 +232,67 @@ __global__ __launch_bounds__(FB_NTH) void corr_volume_bwd_fused_kernel(const flo
             if (++c.j == nrect) c.j = 0, ++c.row;
         }
     };
-    // ---- features of a rectangle, a quarter (8 channels) per wave pair: lane = (channel, eight columns).  A pair fetches its
-    //      quarter of the NEXT rectangle right before the first gradient item it issues inside the current one (steps 0-3)
-    //      and stores it together with that item three steps later: one wait covers both.
-    const int fc = 8 * my_phase + 4 * (wave & 1) + (lane >> 4), fx = (lane & 15) * 8;
-    f32x4 fl[2], fr[2];
+    // ---- features of a rectangle, 8 channels per mover wave: lane = (channel 8 w + lane / 16 (+ 4), eight columns).  A pair
+    //      fetches its half of the NEXT rectangle right before the first gradient item it issues inside the current one and
+    //      stores it together with that item one step later: one wait covers both.
+    const int fc = 8 * wave + (lane >> 4), fx = (lane & 15) * 8;
+    f32x4 fl[2][2], fr[2][2];   // [channel fc, fc + 4][columns fx .. fx + 3, fx + 4 .. fx + 7]
     int f_col = 0;
     bool f_pending = false;
     auto load_features = [&](int row, int j) {
         const int b = row / H, h = row - b * H;
-        const size_t off = (size_t)b * C * HWu + (size_t)min(fc, C - 1) * HWu + (size_t)h * W;
         f_col = FB_TW * j + fx;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int col = min(f_col + 4 * k, W - 4);
-            fl[k] = ld4(Lf + off + col);
-            fr[k] = ld4(Rf + off + col);
+        for (int u = 0; u < 2; ++u) {
+            const size_t off = (size_t)b * C * HWu + (size_t)min(fc + 4 * u, C - 1) * HWu + (size_t)h * W;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int col = min(f_col + 4 * k, W - 4);
+                fl[u][k] = ld4(Lf + off + col);
+                fr[u][k] = ld4(Rf + off + col);
+            }
         }
     };
     auto store_features = [&](int lb, int rb) {
-        float x[8];
-        f16x8 p[2];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = (fc < C && f_col + 4 * (k >> 2) < W) ? fl[k >> 2][k & 3] : 0.0f;
-        split_oct_f16(x, p);
-        unsigned char *lp = Lhi + lb * 2 * FB_LPLANE + fc * FB_LB + 2 * fx;
-        *reinterpret_cast<f16x8 *>(lp) = p[0];
-        *reinterpret_cast<f16x8 *>(lp + FB_LPLANE) = p[1];
+        for (int u = 0; u < 2; ++u) {
+            const int ch = fc + 4 * u;
+            float x[8];
+            f16x8 p[2];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = (fc < C && f_col + 4 * (k >> 2) < W) ? fr[k >> 2][k & 3] : 0.0f;
-        split_oct_f16(x, p);
-        int pos = rb + fx;
-        pos = pos >= FB_RK ? pos - FB_RK : pos;
-        *reinterpret_cast<f16x8 *>(Rhi + fc * FB_RB + 2 * pos) = p[0];
-        *reinterpret_cast<f16x8 *>(Rlo + fc * FB_RB + 2 * pos) = p[1];
+            for (int k = 0; k < 8; ++k) x[k] = (ch < C && f_col + 4 * (k >> 2) < W) ? fl[u][k >> 2][k & 3] : 0.0f;
+            split_oct_f16(x, p);
+            unsigned char *lp = Lhi + lb * 2 * FB_LPLANE + ch * FB_LB + 2 * fx;
+            *reinterpret_cast<f16x8 *>(lp) = p[0];
+            *reinterpret_cast<f16x8 *>(lp + FB_LPLANE) = p[1];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = (ch < C && f_col + 4 * (k >> 2) < W) ? fr[u][k >> 2][k & 3] : 0.0f;
+            split_oct_f16(x, p);
+            int pos = rb + fx;
+            pos = pos >= FB_RK ? pos - FB_RK : pos;
+            *reinterpret_cast<f16x8 *>(Rhi + ch * FB_RB + 2 * pos) = p[0];
+            *reinterpret_cast<f16x8 *>(Rlo + ch * FB_RB + 2 * pos) = p[1];
+        }
     };
 
     // ---- prologue
     FbCursor lc = {row_begin, 0, 0};  // this wave pair's next item
     int li = my_phase;                // ... and its index in the stream
-    for (int k = 0; k < my_phase; ++k) advance(lc);
-    load_features(row_begin, 0);
-    if (li < nitems) load_item(lc);
-    store_features(0, 0);
-    if (my_phase == 0) {
-        store_item(0);
-        li += 4;
-        for (int k = 0; k < 4; ++k) advance(lc);
+    if (my_phase == 1) advance(lc);
+    if (mover) {
+        load_features(row_begin, 0);
         if (li < nitems) load_item(lc);
-    } else if (my_phase == 1) {
-        // "block -1" of the first step (d < 0): zeros
+        store_features(0, 0);
+        if (my_phase == 0) {
+            store_item(0);
+            li += 2;
+            advance(lc), advance(lc);
+            if (li < nitems) load_item(lc);
+        } else {
+            // "block -1" of the first step (d < 0): zeros
 #pragma unroll
-        for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x2 *>(Sh + (64 + my_rows + k) * FB_RS + 2 * lane) = (f32x2){0.f, 0.f};
+            for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x2 *>(Sh + (64 + my_rows + k) * FB_RS + 2 * lane) = (f32x2){0.f, 0.f};
+        }
     }
     __syncthreads();
 
@@ -263,12 +312,12 @@ __global__ __launch_bounds__(FB_NTH) void corr_volume_bwd_fused_kernel(const flo
         if (nj == nrect) nj = 0, ++nrow;
         const bool has_next = nrow < row_end;
         const bool last_step = cc.s == NT - 1;
-        if ((t & 3) == my_phase) {
-            if (cc.s < 4 && has_next) load_features(nrow, nj), f_pending = true;
-            // item t went to the sheet at the end of step t - 1: fetch item t + 4 into the same registers
+        if (mover && (t & 1) == my_phase) {
+            if (cc.s < 2 && has_next) load_features(nrow, nj), f_pending = true;
+            // item t went to the sheet at the end of step t - 1: fetch item t + 2 into the same registers
             if (t > 0) {
-                li += 4;
-                for (int k = 0; k < 4; ++k) advance(lc);
+                li += 2;
+                advance(lc), advance(lc);
                 if (li < nitems) load_item(lc);
             }
         }
@@ -298,7 +347,7 @@ __global__ __launch_bounds__(FB_NTH) void corr_volume_bwd_fused_kernel(const flo
 
         // -- item t + 1 into the sheet slot of item t - 2 (its last readers passed the previous barrier)
         const int ns = cs == 2 ? 0 : cs + 1;
-        const bool my_store = ((t + 1) & 3) == my_phase;
+        const bool my_store = mover && ((t + 1) & 1) == my_phase;
         if (my_store && t + 1 < nitems) store_item(ns);
         const int nb = rbase + FB_TW >= FB_RK ? rbase + FB_TW - FB_RK : rbase + FB_TW;
         if (f_pending && (my_store || last_step)) store_features(lbuf ^ 1, nb), f_pending = false;

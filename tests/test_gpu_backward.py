@@ -377,6 +377,30 @@ def test_corr_volume_backward_single_read_kernel(S, shape, gscale):
     assert e1 <= 2.0 * e0 + 5e-7, (e1, e0)
 
 
+@pytest.mark.parametrize("D", [7, 48, 96, 150, 192])
+def test_soft_argmin_backward_with_addend(S, D):
+    """stereo_soft_argmin_bwd_add_f32: grad_vol = addend + soft-argmin backward, bit for bit what the plain entry followed by
+    an fp32 add gives up to the one fused multiply-add (<= 1 ulp of the sum); in place (grad_vol == addend) as well."""
+    from stereoformer_amd import _native as N
+    torch.manual_seed(D)
+    B, H, W = 2, 6, 52
+    vol = torch.randn(B, D, H, W, device="cuda") * 3
+    gd = torch.randn(B, H, W, device="cuda")
+    add = torch.randn(B, D, H, W, device="cuda")
+    plain, fused = torch.empty_like(vol), torch.empty_like(vol)
+    N.call("stereo_soft_argmin_bwd_f32", N.ptr(vol), N.ptr(gd), N.ptr(None), N.ptr(plain), B, D, H, W, 0, N.stream_ptr())
+    N.call("stereo_soft_argmin_bwd_add_f32", N.ptr(vol), N.ptr(gd), N.ptr(add), N.ptr(fused), B, D, H, W, 0, N.stream_ptr())
+    ref = plain.double() + add.double()
+    assert (fused.double() - ref).abs().max().item() <= 1e-6 * max(1.0, ref.abs().max().item())
+    inplace = add.clone()
+    N.call("stereo_soft_argmin_bwd_add_f32", N.ptr(vol), N.ptr(gd), N.ptr(inplace), N.ptr(inplace), B, D, H, W, 0, N.stream_ptr())
+    assert torch.equal(inplace, fused)
+    # outside the envelope the entry says so (the autograd node then adds the cotangents itself)
+    with pytest.raises(N.StereoHipError) as ei:
+        N.call("stereo_soft_argmin_bwd_add_f32", N.ptr(vol), N.ptr(gd), N.ptr(add), N.ptr(fused), B, D, 3, 3, 0, N.stream_ptr())
+    assert ei.value.code == N.ERR_UNSUPPORTED
+
+
 # ------------------------------------------------------------------ round 2: A6, A2, A7
 def test_variance_lookup_backward_g15(S, golden):
     """A6 (Variance_Based_Local_Cost_Volume) gradients w.r.t. the volume and the disparity against the reference's own

@@ -1,4 +1,6 @@
-"""dev: A1 backward (dL + dR) at cfg-2 size under the test options given as k=v arguments.  python tools/a1bwd_ab.py corr_bwd_fused=2"""
+"""dev: A1 backward (dL + dR) at cfg-2 size under the test options given as k=v arguments (corr_bwd_fused = 0: round 2's two
+launches, 1: the one-read kernel, 2 / 3: its timing ablations without arithmetic / without volume loads).
+python tools/a1bwd_ab.py corr_bwd_fused=2 [B=2]"""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import stereoformer_amd as S
@@ -30,3 +32,4 @@ with _native.test_options(**opts):
     ms = e0.elapsed_time(e1) / 10
 gb = (B * D * H * W * 4 + 4 * B * C * H * W * 4) / 1e9
 print(f"{opts} B={B}: {ms:.3f} ms  {gb / ms:.2f} TB/s of {gb:.2f} GB (one read of the volume + features in / out)")
+

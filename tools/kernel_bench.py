@@ -287,10 +287,23 @@ def main():
             Lg, Rg = L.detach().requires_grad_(True), R.detach().requires_grad_(True)
             vol_g = S.CostVolume(D)(Lg, Rg)
             cot = torch.randn_like(vol_g)
-            add("bwd A1 corr volume cfg-2 (dL + dR)",
+            from stereoformer_amd import _native as NV
+            gl_, gr_ = torch.empty_like(L), torch.empty_like(R)
+
+            def a1_bwd():
+                NV.call("stereo_gwc_volume_bwd_f32", NV.ptr(L), NV.ptr(R), NV.ptr(cot), NV.ptr(gl_), NV.ptr(gr_), B, C, H, W, D, 1,
+                        NV.stream_ptr())
+            add("bwd A1 corr volume cfg-2 (dL + dR)", timeit(a1_bwd, 10, 3),
+                (N * D * 4 + 4 * N * C * 4) / 1e9, 2 * 2 * B * H * C * (D * W - D * (D - 1) / 2) / 1e9,
+                note="round 3: ONE launch, the gradient volume read once (corr_bwd_fused.hip; split-fp16 MFMA, row-walking "
+                     "workgroups); bytes = one read of the volume + both features in + both gradients out")
+            with NV.test_options(corr_bwd_fused=0):
+                add("bwd A1 [round 2's two launches, for comparison]", timeit(a1_bwd, 5, 2),
+                    (2 * N * D * 4 + 4 * N * C * 4) / 1e9, note="each launch reads the gradient volume; f32 MFMA + LDS sheet")
+            add("bwd A1 through autograd (CostVolume backward incl. its two output allocations)",
                 timeit(lambda: torch.autograd.grad(vol_g, (Lg, Rg), cot, retain_graph=True), 5, 1),
-                (2 * N * D * 4 + 4 * N * C * 4) / 1e9, 2 * 2 * B * H * C * (D * W - D * (D - 1) / 2) / 1e9,
-                note="two launches (dL, dR), each reads the gradient volume once; f32 MFMA + LDS sheet")
+                (N * D * 4 + 4 * N * C * 4) / 1e9)
+            del gl_, gr_
             del vol_g, cot
             vd = S.CostVolume(D)(L, R).detach().requires_grad_(True)
             dsp = S.DisparityEstimation(D)(vd)
