@@ -29,6 +29,7 @@ import torch.distributed as dist
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import stereoformer_amd as S  # noqa: E402
 from stereoformer_amd import shard  # noqa: E402
+from stereoformer_amd import _native as NV  # noqa: E402
 
 MFMA_F32_PEAK = 157.3  # TFLOP/s dense f32 MFMA (MI355X_MICROARCH.md)
 
@@ -323,13 +324,23 @@ def cfg2_train(dev, rank, world, steps, warmup, cpu):
         n = B * H * W
         gb_f = (2 * n * C * 4 + n * G * D * 4 + n * D * 4 + n * 4) / 1e9
         gb_b = (2 * n * D * 4 + n * 4) / 1e9
+        gl_, gr_ = torch.empty_like(L), torch.empty_like(R)
+        gvol_ = torch.randn(B, D, H, W, device=dev)
+        ms_a1 = event_ms(lambda: NV.call("stereo_gwc_volume_bwd_f32", NV.ptr(L), NV.ptr(R), NV.ptr(gvol_), NV.ptr(gl_), NV.ptr(gr_),
+                                         B, C, H, W, D, 1, NV.stream_ptr(dev)))
+        gb_a1 = (n * D * 4 + 4 * n * C * 4) / 1e9
+        del gl_, gr_, gvol_
         roof = {"bound": "hbm", "kernel": "corr_volume_mfma_kernel (the fused volume stage, forward of the step: the group-wise "
                                           "volume is written once and never read back -- its backward runs through the mean volume)",
                 "achieved": round(gb_f / ms_f * 1e3, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gb_f / ms_f * 1e3 / 8000.0, 4),
                 "traffic": None, "avg_launch_ms": round(ms_f, 4), "algorithmic_bytes": int(gb_f * 1e9),
                 "backward_kernels": {"soft_argmin_bwd_regs_kernel (A4 backward, one read + one write of the mean volume)":
                                      {"avg_launch_ms": round(ms_b, 4), "GB/s": round(gb_b / ms_b * 1e3, 1),
-                                      "frac": round(gb_b / ms_b * 1e3 / 8000.0, 4)}}}
+                                      "frac": round(gb_b / ms_b * 1e3 / 8000.0, 4)},
+                                     "corr_volume_bwd_fused_kernel (A1 backward of the mean volume: dL and dR from one read of its "
+                                     "gradient; bytes = that read + both features in + both gradients out)":
+                                     {"avg_launch_ms": round(ms_a1, 4), "GB/s": round(gb_a1 / ms_a1 * 1e3, 1),
+                                      "frac": round(gb_a1 / ms_a1 * 1e3 / 8000.0, 4)}}}
         del vd, dsp, cd
     cb = None
     if cpu and rank == 0:
