@@ -29,7 +29,16 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
     constexpr int Dk = 32 * (NT - 1);
     constexpr int TQW = 32 * NWV;
     constexpr int NK = TQW + Dk;
-    constexpr int RSD = (NK / 2 + 62 + 63) / 64 * 64;   // row slot in dwords: a whole number of bank rows, room for the offset
+    // RING (256-query tiles, long bands): consecutive tiles of an image row share NK - 256 keys, so the key image is a ring of
+    // 512 columns -- a tile that continues its predecessor's row stages only its 256 NEW keys (loads, splits, LDS stores:
+    // -43 % of the staging of such a tile; staging was 0.17-0.2 ms of the 0.8-ms cfg-3 launch) over the oldest 256 columns,
+    // which nobody needs any more; the first tile of a row or of a workgroup stages all NK.  Window start = ring column
+    // `rbase` (0 or 256), key tile k of the window sits at column (rbase + 32 k) mod 512.
+    // (fp32 features only: the fp16-feature instantiation sits at 127 registers = two workgroups per CU, and its staging has
+    // no splits to save)
+    constexpr bool RING = NWV == 8 && NT >= 6 && NP == 2;
+    constexpr int RCOLS = 512;
+    constexpr int RSD = ((RING ? RCOLS : NK) / 2 + 62 + 63) / 64 * 64;   // row slot in dwords: whole bank rows + room for the offset
     constexpr int RSE = 2 * RSD;                        // ... in f16 elements
     constexpr int PSE = 32 * RSE;                       // piece stride
     constexpr int RMAX = (32 + NWV - 1) / NWV;
@@ -46,8 +55,8 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
     // transposed K reads: lane 4 q + p of its 16-lane group supplies row (channel) R0 + q, keys K0 + 4 p .. ; R0 = 8 half + 16 s
     // + 4 tt is a multiple of 4, so the row's offset splits into a lane part and a compile-time (s, tt) part
     const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
-    const int k_off = (8 * half + tq) * RSE + 32 * tq + 8 * half + 32 * wave + 16 * tg1 + 4 * tp;  // + (16 s + 4 tt) RSE + 4 (4 s + tt) + 32 t
-    const int v_off = row_off(l31) + 32 * wave + 4 * half;                                        // + 32 t + 16 s (+ 8 for elements 4..7)
+    const int k_off = (8 * half + tq) * RSE + 32 * tq + 8 * half + 16 * tg1 + 4 * tp;  // + (16 s + 4 tt) RSE + 4 (4 s + tt) + column of the key tile
+    const int v_off = row_off(l31) + 4 * half;                                        // + column of the key tile + 16 s (+ 8 for elements 4..7)
 
     int tile = blockIdx.x * tiles_per_wg;
     const int tile_end = (tile + tiles_per_wg < ntiles) ? tile + tiles_per_wg : ntiles;
@@ -59,21 +68,33 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
     typename Quad<TIN>::raw rk[RMAX][NPASS];
     TIN qn[16];
     constexpr int ES = (int)sizeof(TIN);
-    auto issue = [&](int tl) {
+    bool incr = false;   // the prefetched tile continues the current one's row: only its 256 new keys are in `rk`
+    int rbase = 0;       // ring column of the current image's first key
+    auto issue = [&](int tl, bool first) {
         const int x = tl % nx, bh = tl / nx;
         const int hh = bh % H, bb = bh / H;
         const int w0 = x * TQW, kbase = w0 - Dk;
         const TIN *Rb = R + ((size_t)bb * C * HWu + (size_t)hh * W);
         const TIN *Lb = L + ((size_t)bb * C * HWu + (size_t)hh * W);
+        incr = RING && !first && x > 0;
         int voff[NPASS];
+        if (RING && incr) {
+            voff[0] = (w0 + 4 * lane) * ES;      // keys w0 .. w0 + 255: one quad per lane and row
 #pragma unroll
-        for (int pp = 0; pp < NPASS; ++pp) voff[pp] = (lane + 64 * pp < NK / 4) ? (kbase + 4 * (lane + 64 * pp)) * ES : -1;
+            for (int pp = 1; pp < NPASS; ++pp) voff[pp] = -1;
+        } else {
+#pragma unroll
+            for (int pp = 0; pp < NPASS; ++pp) voff[pp] = (lane + 64 * pp < NK / 4) ? (kbase + 4 * (lane + 64 * pp)) * ES : -1;
+        }
 #pragma unroll
         for (int rr = 0; rr < RMAX; ++rr) {       // one resource per row: the range check sees voffset + soffset on gfx950
             const int row = wave + rr * NWV;
             const __amdgpu_buffer_rsrc_t rs = buffer_rsrc(Rb + (size_t)row * HWu, row < C ? (unsigned)W * ES : 0u);
+            rk[rr][0] = BufLd<TIN>::quad(rs, voff[0], 0);
+            if (!(RING && incr)) {
 #pragma unroll
-            for (int pp = 0; pp < NPASS; ++pp) rk[rr][pp] = BufLd<TIN>::quad(rs, voff[pp], 0);
+                for (int pp = 1; pp < NPASS; ++pp) rk[rr][pp] = BufLd<TIN>::quad(rs, voff[pp], 0);
+            }
         }
         const __amdgpu_buffer_rsrc_t rq = buffer_rsrc(Lb, ((unsigned)(C - 1) * HWu + (unsigned)W) * ES);
         int vq = (int)(((unsigned)(8 * half) * HWu + (unsigned)(w0 + 32 * wave + l31)) * ES);
@@ -84,6 +105,14 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
         }
     };
     auto commit = [&]() {  // registers -> the f16 piece images: one 8-byte store per quad and piece
+        // ring: a continuing tile's 256 keys follow the current window (columns rbase + NK ..., modulo 512) and the window
+        // moves on by 256; a full staging restarts the ring at column 0
+        const bool inc = RING && incr;
+        int c0 = 4 * lane;
+        if constexpr (RING) {
+            if (inc) c0 = (rbase + NK + 4 * lane) & (RCOLS - 1);
+            rbase = inc ? (rbase + 256) & (RCOLS - 1) : 0;
+        }
 #pragma unroll
         for (int rr = 0; rr < RMAX; ++rr) {
             const int row = wave + rr * NWV;
@@ -91,7 +120,8 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
                 const int ro = row_off(row);
 #pragma unroll
                 for (int pp = 0; pp < NPASS; ++pp) {
-                    if (lane + 64 * pp < NK / 4) {
+                    if (lane + 64 * pp < NK / 4 && (pp == 0 || !inc)) {
+                        const int colq = pp == 0 ? c0 : 4 * (lane + 64 * pp);
                         if constexpr (NP == 2) {
                             const f32x4 v = Quad<TIN>::widen(rk[rr][pp]);
                             f16x2 a[2], b[2];
@@ -99,10 +129,10 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
                             split_pair_f16((f32x2){v[2], v[3]}, b);
 #pragma unroll
                             for (int p = 0; p < 2; ++p)
-                                *reinterpret_cast<f16x4 *>(&Im16[p * PSE + ro + 4 * (lane + 64 * pp)]) =
+                                *reinterpret_cast<f16x4 *>(&Im16[p * PSE + ro + colq]) =
                                     __builtin_shufflevector(a[p], b[p], 0, 1, 2, 3);
                         } else {
-                            *reinterpret_cast<typename Quad<TIN>::raw *>(&Im16[ro + 4 * (lane + 64 * pp)]) = rk[rr][pp];
+                            *reinterpret_cast<typename Quad<TIN>::raw *>(&Im16[ro + colq]) = rk[rr][pp];
                         }
                     }
                 }
@@ -110,7 +140,7 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
         }
     };
 
-    issue(tile);
+    issue(tile, true);
     commit();
     f16x8 qf[2][NP];
     // a zero accumulator kept in registers for the whole kernel: the first product of every chain takes it as its C operand
@@ -140,7 +170,7 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
         }
         __syncthreads();  // the image is visible
         const bool more = tile + 1 < tile_end;
-        if (more) issue(tile + 1);
+        if (more) issue(tile + 1, false);
 
         if (w0 + 32 * wave < W) {  // wave-uniform
             const bool neg_left = mask_mode == STEREO_MASK_NEGINF && kbase < 0;
@@ -151,6 +181,8 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
 #pragma unroll 1
             for (int t = NT - 1; t >= 0; --t) {
                 f32x16 ah, al;
+                int ct = 32 * (wave + t);    // column of key tile wave + t of the window (wave-uniform)
+                if constexpr (RING) ct = (ct + rbase) & (RCOLS - 1);
                 // ---- S^T tile = K_t Q^T: A = K through the transposed read, B = Q pieces
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -159,7 +191,7 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
                     for (int p = 0; p < NP; ++p) {
 #pragma unroll
                         for (int tt = 0; tt < 2; ++tt) {
-                            const _Float16 *src = &Im16[p * PSE + k_off + (16 * s + 4 * tt) * RSE + 4 * (4 * s + tt) + 32 * t];
+                            const _Float16 *src = &Im16[p * PSE + k_off + (16 * s + 4 * tt) * RSE + 4 * (4 * s + tt) + ct];
                             const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)src);
                             const short tv[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
@@ -245,8 +277,8 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
                         f16x8 vf[NP];
 #pragma unroll
                         for (int p = 0; p < NP; ++p) {
-                            const f16x4 lo = *reinterpret_cast<const f16x4 *>(&Im16[p * PSE + v_off + 32 * t + 16 * s]);
-                            const f16x4 hi = *reinterpret_cast<const f16x4 *>(&Im16[p * PSE + v_off + 32 * t + 16 * s + 8]);
+                            const f16x4 lo = *reinterpret_cast<const f16x4 *>(&Im16[p * PSE + v_off + ct + 16 * s]);
+                            const f16x4 hi = *reinterpret_cast<const f16x4 *>(&Im16[p * PSE + v_off + ct + 16 * s + 8]);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) vf[p][e] = lo[e], vf[p][4 + e] = hi[e];
                         }
@@ -288,7 +320,7 @@ int launch_split16(const TIN *left, const TIN *right, float *out, float *disp, i
                    float sc, hipStream_t st)
 {
     constexpr int NK = 32 * NWV + 32 * (NT - 1);
-    constexpr int RSD = (NK / 2 + 62 + 63) / 64 * 64;
+    constexpr int RSD = (((NWV == 8 && NT >= 6 && sizeof(TIN) == 4) ? 512 : NK) / 2 + 62 + 63) / 64 * 64;   // (the kernel's RING / RCOLS)
     const size_t lds = (size_t)(sizeof(TIN) == 4 ? 2 : 1) * 32 * RSD * 4;
     auto kern = cross_attention_split16_kernel<NT, NWV, TIN>;
     static std::atomic<unsigned long long> lds_done{0};

@@ -39,6 +39,18 @@ print(f"one pass of RAFTStereoLoop (16 iterations, 8 pairs at 1/4 of 544x960, NH
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:20]:
     print("  %8.3f ms %4d launches  %s" % (v[0], v[1], k))
 PY
+bash tools/a1bwd_pmc.sh corr_bwd_fused=1 full > $O/a1bwd_pmc.log 2>&1
+cp gpurun_out/a1bwd_pmc/pmc_a1bwd.json $P/r03_pmc_a1bwd.json 2>/dev/null
+(for o in corr_bwd_fused=1 corr_bwd_fused=0 corr_bwd_fused=2 corr_bwd_fused=3 "corr_bwd_fused=1 B=2"; do timeout -k 10 120 python3 tools/a1bwd_ab.py $o 2>&1 | tail -1; done) > $P/r03_a1bwd_ab.txt
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/train -o run --output-format csv -- python3 $ROOT/tools/train_trace.py > $O/train_trace.log 2>&1)
+python3 - $O <<'PY' > $P/r03_train_step_kernel_stats.txt
+import csv, sys
+o = sys.argv[1]
+print("rocprofv3 --kernel-trace --stats of tools/train_trace.py: the cfg-2 training step (2 pairs, forward + backward), 13 steps; per kernel")
+print(open(o + "/train_trace.log").read().strip().splitlines()[-1])
+for r in list(csv.DictReader(open(o + "/train/run_kernel_stats.csv")))[:9]:
+    print("  %-90s calls %3s  avg %9.1f us  %5s %%" % (r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:90], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"][:5]))
+PY
 timeout -k 10 900 python3 tools/kernel_bench.py > $O/kernel_bench.log 2>&1 && cp gpurun_out/kernel_bench.json $P/r03_kernel_bench.json
 timeout -k 10 200 python3 tools/conv_audit.py > $P/r03_conv_error_audit.txt 2>&1
 timeout -k 10 200 python3 tools/conv_ab.py 2>&1 | grep -v amdgpu > $P/r03_conv_ab.txt
