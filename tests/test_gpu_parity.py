@@ -495,13 +495,16 @@ def _cross_attention(S, oracle, cfg):
 
 
 @pytest.mark.parametrize("kern", [0, 5])
-@pytest.mark.parametrize("nw,tpw", [(4, 0), (8, 0), (8, 1), (4, 3), (6, 0), (6, 2)])
+@pytest.mark.parametrize("nw,tpw", [(4, 0), (8, 0), (8, 1), (4, 3), (6, 0), (6, 2), (8, 3), (8, 5)])
 def test_cross_attention_online_workgroup_shapes(S, oracle, nw, tpw, kern):
     """Online-softmax kernels (0: split-bf16, 5: fp32) with 4 / 6 / 8 waves (128 / 192 / 256 queries) per workgroup tile (the
     fp32 one has no 6-wave shape and takes its own pick there) and 1 / 2 / 3 / auto tiles per persistent workgroup, incl.
-    partial last tiles, every band size class (NT = 3, 5, 7, 9), both masks, disparity-only mode."""
+    partial last tiles, every band size class (NT = 3, 5, 7, 9), both masks, disparity-only mode.  (8, 3) / (8, 5): runs of
+    256-query tiles that continue along a row, start a new row and start a workgroup mid-row -- the key RING of the default
+    kernel (a continuing tile stages only its 256 new keys) in all its transitions, incl. a ragged last tile."""
     rng = np.random.default_rng(31)
-    for (B, C, H, W, D) in ((1, 32, 2, 960, 192), (2, 16, 3, 200, 40), (1, 8, 2, 516, 100), (1, 32, 1, 300, 256), (1, 5, 2, 36, 7)):
+    for (B, C, H, W, D) in ((1, 32, 2, 960, 192), (2, 16, 3, 200, 40), (1, 8, 2, 516, 100), (1, 32, 1, 300, 256), (1, 5, 2, 36, 7),
+                            (1, 24, 3, 772, 170)):
         L = rng.standard_normal((B, C, H, W), dtype=np.float32)
         R = rng.standard_normal((B, C, H, W), dtype=np.float32)
         for mask in ("zero", "neginf"):
