@@ -272,11 +272,31 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
                     // ---- O^T += V_t^T P: A = V^T rows from the image (accumulator key order), B = P as hi + 2^-11 lo'
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
+                        // P = hi + 2^-11 lo': hi by one packed conversion per pair, lo' = 2^11 p - 2^11 hi by ONE mixed-precision
+                        // FMA per element (fp32 arithmetic on the fp16 source 2^11 hi, fp16 result into one half of the
+                        // destination) -- the compiler's form of split_oct_f16 is two conversions back to fp32, a packed
+                        // subtraction, a packed multiply and a packed conversion per pair: 56 vector instructions per key tile
+                        // instead of 32, in a loop that is bound by its vector instructions
                         f16x8 pq[2];
-                        float xp[8];
+                        {
+                            typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+                            u32x4v hv, lv;
+                            const float c2048 = SPLIT16_LO_SCALE;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) xp[e] = a[8 * s + e];
-                        split_oct_f16(xp, pq);
+                            for (int e = 0; e < 4; ++e) {
+                                const f16x2 h = __builtin_convertvector((f32x2){a[8 * s + 2 * e], a[8 * s + 2 * e + 1]}, f16x2);
+                                const f16x2 h2 = h * (f16x2){(_Float16)2048.0f, (_Float16)2048.0f};
+                                const unsigned h2u = __builtin_bit_cast(unsigned, h2);
+                                unsigned lu;
+                                asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lu) : "v"(a[8 * s + 2 * e]), "v"(c2048), "v"(h2u));
+                                asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                                    : "+v"(lu)
+                                    : "v"(a[8 * s + 2 * e + 1]), "v"(c2048), "v"(h2u));
+                                hv[e] = __builtin_bit_cast(unsigned, h);
+                                lv[e] = lu;
+                            }
+                            pq[0] = __builtin_bit_cast(f16x8, hv), pq[1] = __builtin_bit_cast(f16x8, lv);
+                        }
                         f16x8 vf[NP];
 #pragma unroll
                         for (int p = 0; p < NP; ++p) {
