@@ -30,7 +30,10 @@
 // (no operand preparation at all) 1.81 ms, f32 MFMAs for the dR waves only 1.66 ms -- the f32 matrix pipe at 64 cycles per
 // instruction is the slower resource.  This form runs the vector pipe at ~40 % and the matrix pipe at 9 %: its step time
 // (1.5 us for 16 KB of volume per CU) is the dependent chain LDS read -> column maximum -> split -> MFMA -> totals of two waves
-// per SIMD behind one barrier per step (in-kernel cycle stamps: a dR wave needs ~3 000 cycles per step, a dL wave ~2 150).
+// per SIMD behind one barrier per step (in-kernel cycle stamps: a dR wave needs ~3 000 cycles per step, a dL wave ~2 150
+// plus its mover burst; the dR waves' sheet reads -- columns, 2-way bank-conflicted -- come back after ~440 cycles against
+// ~90 for the dL waves' diagonals, and a mover's store burst still waits ~750 cycles on average for loads issued two steps
+// earlier: a third block in flight would need a second register set per mover wave, and the dR waves set the step anyway).
 // Ablations (test option corr_bwd_fused = 2 / 3): without arithmetic 1.06 ms (5.0 TB/s), without the volume loads 1.16 ms.
 //
 // Data movement.  One workgroup per CU (143 KB of LDS).  The dL waves, whose arithmetic is the shorter one, move the data:
