@@ -433,7 +433,8 @@ __global__ __launch_bounds__(256) void local_lookup_bwd_dense_kernel(const float
             {   // candidates (hence taps) are monotone in k: the first one's lower tap is the window's first plane
                 const float c0 = cand(0);
                 const int ic = (int)clampf(ste_ceil_f(c0), 0.0f, (float)(D - 1)), ifl = (int)clampf(ste_floor_f(c0), 0.0f, (float)(D - 1));
-                base = ifl < ic ? ifl : ic;
+                base = (ifl < ic ? ifl : ic) - 1;   // one plane of slack: the straight-through floor, (floor(x) - x) + x, can land
+                base = base < 0 ? 0 : base;         // one below floor(x) after the int cast
             }
             // every plane a tap of this pixel can touch, fetched ONCE with all loads in flight (the S + 1 candidates sample
             // 2 (S + 1) taps out of these <= 2 radius + 3 planes; fetched tap by tap, candidate after candidate, the rounds
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) void local_lookup_bwd_dense_kernel(const float
             }
             auto tap = [&](int idx) {
                 const int j = idx - base;
-                return (j >= 0 && j < LLB_WIN) ? vwin[tid][j] : 0.0f;   // inside the window by construction (launcher: radius)
+                return (j >= 0 && j < LLB_WIN) ? vwin[tid][j] : v[(size_t)idx * HW];   // inside the window by construction
             };
             float m = -INFINITY, s = 0.0f, e = 0.0f;
             for (int k = 0; k <= S; ++k) {
@@ -990,12 +991,12 @@ extern "C" int stereo_local_lookup_bwd_dense_f32(const float *vol, const float *
     STEREO_REQUIRE_PTR(grad_vol);
     STEREO_REQUIRE_PTR(grad_disp);
     const long long HW = (long long)H * W;
-    // window of touched planes: floor(lower) .. ceil(upper) <= 2 radius + 3 planes
-    if (!(radius >= 0.0f) || 2.0f * radius + 3.0f > (float)LLB_WIN || HW % 4 != 0 || !aligned16(grad_vol) || !fits_grid_yz(B))
+    // window of touched planes: floor(lower) .. ceil(upper) <= 2 radius + 3 planes, plus one of slack below
+    if (!(radius >= 0.0f) || 2.0f * radius + 4.0f > (float)LLB_WIN || HW % 4 != 0 || !aligned16(grad_vol) || !fits_grid_yz(B))
         return STEREO_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(local_lookup_bwd_dense_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)B), dim3(256), 0,
                        as_stream(stream), vol, disp, grad_out, grad_vol, grad_disp, D, HW, radius, S, consider_valid,
-                       (int)fminf(ceilf(2.0f * radius) + 3.0f, (float)LLB_WIN));
+                       (int)fminf(ceilf(2.0f * radius) + 4.0f, (float)LLB_WIN));
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }
