@@ -154,17 +154,36 @@ __global__ __launch_bounds__(256) void shift_volume_bwd_kernel(const float *__re
         const int Cout = CONCAT ? 2 * C : C;
         const float *gl = g + (((size_t)b * Cout + c) * D) * HW + (size_t)h * W;
         const float *gr = g + (((size_t)b * Cout + (CONCAT ? C + c : c)) * D) * HW + (size_t)h * W;
+        // eight planes per round with their loads in flight together and four partial sums (a one-plane-at-a-time loop is a
+        // chain of dependent adds behind one load each: 2.0 TB/s); planes beyond a lane's own limit re-read its last valid
+        // one (a cache hit) and are masked out of the sum
         if (gL) {
-            float acc = 0.0f;
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             const int dmax = w < D - 1 ? w : D - 1;
-            for (int d = 0; d <= dmax; ++d) acc += gl[(size_t)d * HW + w];
-            gL[t] = acc;
+            for (int d0 = 0; d0 <= dmax; d0 += 8) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = gl[(size_t)(d0 + j <= dmax ? d0 + j : dmax) * HW + w];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j & 3] += d0 + j <= dmax ? x[j] : 0.0f;
+            }
+            gL[t] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         }
         if (gR) {
-            float acc = 0.0f;
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             const int dmax = (W - 1 - w) < D - 1 ? (W - 1 - w) : D - 1;
-            for (int d = 0; d <= dmax; ++d) acc += gr[(size_t)d * HW + w + d];
-            gR[t] = CONCAT ? acc : -acc;
+            for (int d0 = 0; d0 <= dmax; d0 += 8) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int d = d0 + j <= dmax ? d0 + j : dmax;
+                    x[j] = gr[(size_t)d * HW + w + d];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j & 3] += d0 + j <= dmax ? x[j] : 0.0f;
+            }
+            const float a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            gR[t] = CONCAT ? a : -a;
         }
     }
 }
