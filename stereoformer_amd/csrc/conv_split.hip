@@ -569,6 +569,11 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const TIN *__restric
     constexpr int ES = (int)sizeof(TIN), QCH = 16 / ES, QPP = 32 / QCH;   // channels per 16-B quad, quads per pixel and chunk
     constexpr int NQ = NPX * QPP, NPASS = (NQ + 255) / 256;
     __shared__ __attribute__((aligned(16))) float tile[NPX * PXS];
+    // the chunk's weights [tap][32 channels][COUT] go through LDS as well: read back as wave-wide broadcasts.  (As scalar loads
+    // -- they are wave-uniform -- they shared the LDS reads' counter, and scalar loads return out of order: every wait in the tap
+    // loop drained both, 288 times per chunk: 0.12 ms for a 0.27-GB read.)
+    constexpr int WCH = 9 * 32 * COUT;
+    __shared__ __attribute__((aligned(16))) float wl[WCH];
     const int tid = threadIdx.x, row = tid >> 5, col = tid & 31;
     int t = blockIdx.x;
     const int tx = t % tiles_x;
@@ -590,11 +595,22 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const TIN *__restric
 #pragma unroll
     for (int o = 0; o < COUT; ++o) acc[o] = bias ? bias[o] : 0.0f;
     const float *tp = tile + (row * HC + col) * PXS;
-    for (int c0 = 0; c0 < Cin; c0 += 32) {
-        u32x4_t rk[NPASS];
+    u32x4_t rk[NPASS];
+    constexpr int WPT = (WCH + 255) / 256;   // weight floats per thread and chunk
+    float wr[WPT];
+    auto issue = [&](int c0) {
 #pragma unroll
         for (int i = 0; i < NPASS; ++i)
             rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], c0 * ES, 0);   // (soffset is range-checked with voffset)
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int e = tid + 256 * i;             // element (tap, channel, output) of the chunk
+            const int tap = e / (32 * COUT), r = e - tap * (32 * COUT);
+            wr[i] = e < WCH ? wt[((size_t)tap * Cin + c0) * COUT + r] : 0.0f;
+        }
+    };
+    issue(0);
+    for (int c0 = 0; c0 < Cin; c0 += 32) {
         __syncthreads();   // the previous chunk has been consumed
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
@@ -611,11 +627,15 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const TIN *__restric
                 }
             }
         }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            if (tid + 256 * i < WCH) wl[tid + 256 * i] = wr[i];
         __syncthreads();
+        if (c0 + 32 < Cin) issue(c0 + 32);   // the next chunk's loads fly under this chunk's arithmetic
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const float *pp = tp + ((tap / 3) * HC + tap % 3) * PXS;
-            const float *wk = wt + ((size_t)tap * Cin + c0) * COUT;   // [tap][channel][COUT]
+            const float *wk = wl + tap * 32 * COUT;   // [tap][channel][COUT]
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(pp + 4 * q);
