@@ -337,6 +337,11 @@ int stereo_instance_norm_relu_nhwc(const void *x, int x_is_f16, const float *gam
 int stereo_relayout_nhwc_to_nchw(const void *x, int x_is_f16, void *out, int out_is_f16, int B, int C, int H, int W,
                                  void *stream);
 
+/* The opposite direction, fp32: x [B,C,H,W] -> out [B][H*W][C] (the memory of a torch.channels_last tensor): the update loops
+ * (raft_stereo.py:150-199) take the hidden states and context tensors the extractors hand over NCHW and run channels-last.
+ * C % 32 == 0, H*W % 4 == 0, else STEREO_ERR_UNSUPPORTED. */
+int stereo_relayout_nchw_to_nhwc_f32(const float *x, float *out, int B, int C, int H, int W, void *stream);
+
 /* A14's convolutions (update/update.py:6-33,66-91,130-178: nn.Conv2d, stride 1, "same" padding, 3x3 or 1x1) over
  * channels-last fp32 activations, on the bf16 matrix cores with split operands (fp32-faithful: every operand is hi + mid + lo
  * exactly, six piece products per fp32 product, fp32 accumulation).

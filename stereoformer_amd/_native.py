@@ -65,6 +65,7 @@ SIGNATURES = {
     "stereo_instance_norm_relu_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "stereo_instance_norm_relu_nhwc": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "stereo_relayout_nhwc_to_nchw": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "stereo_relayout_nchw_to_nhwc_f32": [_vp, _vp, _i, _i, _i, _i, _vp],
     "stereo_conv3x3_small_nhwc_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_conv3x3_small_nhwc_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_conv3x3_small_nhwc_ex": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -203,6 +204,27 @@ def nchw(t: torch.Tensor) -> torch.Tensor:
                     if e.code != ERR_UNSUPPORTED:
                         raise
     return t.contiguous()
+
+
+def nhwc(t: torch.Tensor) -> torch.Tensor:
+    """``torch.channels_last`` version of a 4-D HIP tensor.  An NCHW-contiguous fp32 activation goes through the library's
+    tiled relayout kernel (``stereo_relayout_nchw_to_nhwc_f32``; ``Tensor.contiguous(memory_format=...)`` moves ~1.3 TB/s on
+    this part); anything else takes ``contiguous(memory_format=torch.channels_last)``."""
+    cl = torch.channels_last
+    if t.dim() != 4 or t.is_contiguous(memory_format=cl):
+        return t if t.dim() != 4 else t.contiguous(memory_format=cl)
+    if (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and not (torch.is_grad_enabled() and t.requires_grad)):
+        B, C, H, W = t.shape
+        if C % 32 == 0 and (H * W) % 4 == 0:
+            out = torch.empty((B, C, H, W), device=t.device, dtype=t.dtype, memory_format=cl)
+            with torch.cuda.device(t.device):
+                try:
+                    call("stereo_relayout_nchw_to_nhwc_f32", ptr(t), ptr(out), B, C, H, W, stream_ptr(t.device))
+                    return out
+                except StereoHipError as e:
+                    if e.code != ERR_UNSUPPORTED:
+                        raise
+    return t.contiguous(memory_format=cl)
 
 
 def dev_f32(t: torch.Tensor, name: str, dense_ok: bool = False) -> torch.Tensor:

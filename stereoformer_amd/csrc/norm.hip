@@ -290,6 +290,55 @@ extern "C" int stereo_instance_norm_relu_nhwc(const void *x, int x_is_f16, const
                                                   B, C, HW, eps, relu, st);
 }
 
+// NCHW -> channels-last relayout (the update loops take their hidden states and context tensors channels-last; the
+// reference's extractors hand them over NCHW).  A workgroup transposes 32 channels x 64 pixels through LDS: 16-byte loads
+// along the pixels of a channel plane, 16-byte stores along the channels of a pixel.
+namespace {
+__global__ __launch_bounds__(256) void relayout_nchw_to_nhwc_kernel(const float *__restrict__ x, float *__restrict__ out, int C,
+                                                                    long long HW)
+{
+    __shared__ float tile[32][64 + 1];
+    const int tid = threadIdx.x;
+    const long long p0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 32, b = blockIdx.z;
+    const float *xb = x + ((size_t)b * C + c0) * HW + p0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = tid + 256 * i, c = q >> 4, pq = (q & 15) * 4;   // channel row, pixel quad
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (p0 + pq < HW) v = ld4(xb + (size_t)c * HW + pq);          // HW % 4 == 0: a quad is entirely in or out
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[c][pq + e] = v[e];
+    }
+    __syncthreads();
+    float *ob = out + ((size_t)b * HW + p0) * C + c0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = tid + 256 * i, px = q >> 3, cq = (q & 7) * 4;   // pixel, channel quad
+        if (p0 + px < HW) {
+            const f32x4 v = {tile[cq][px], tile[cq + 1][px], tile[cq + 2][px], tile[cq + 3][px]};
+            st4(ob + (size_t)px * C + cq, v);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int stereo_relayout_nchw_to_nhwc_f32(const float *x, float *out, int B, int C, int H, int W, void *stream)
+{
+    if (B < 0 || C < 0 || H < 0 || W < 0) return STEREO_ERR_BAD_SHAPE;
+    if (B == 0 || C == 0 || H == 0 || W == 0) return STEREO_OK;
+    STEREO_REQUIRE_PTR(x);
+    STEREO_REQUIRE_PTR(out);
+    const long long HW = (long long)H * W;
+    if (C % 32 != 0 || HW % 4 != 0 || !fits_grid_yz(B) || !fits_grid_yz(C / 32) || !aligned16(x) || !aligned16(out) ||
+        (HW + 63) / 64 >= (1LL << 31))
+        return STEREO_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(relayout_nchw_to_nhwc_kernel, dim3((unsigned)((HW + 63) / 64), (unsigned)(C / 32), (unsigned)B), dim3(256), 0,
+                       as_stream(stream), x, out, C, HW);
+    STEREO_LAUNCH_CHECK();
+    return STEREO_OK;
+}
+
 /* NHWC -> NCHW relayout of a feature tensor (the apply pass above with the identity map): what a channels-last extractor
  * output needs in front of the cost-volume loaders when no normalisation closes the stage (raft_stereo's fnet ends in a
  * plain 1x1 convolution). */

@@ -600,3 +600,22 @@ def test_pool2x_pool4x_channels_last(S, shape):
         b = F.avg_pool2d(x, k, stride=st, padding=1)
         assert a.shape == b.shape and a.is_contiguous(memory_format=torch.channels_last)
         assert float((a - b).abs().max()) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 128, 17, 24), (1, 32, 3, 4), (3, 64, 5, 36), (1, 96, 34, 60)])
+def test_relayout_nchw_to_nhwc(shape):
+    """_native.nhwc: the tiled NCHW -> channels-last kernel (what the RAFT loop uses for the hidden states and context
+    tensors the extractors hand over) is a pure permutation: bit-identical to Tensor.contiguous(memory_format=...); shapes it
+    does not take (C % 32, H W % 4) and tensors that are already channels-last go the torch way."""
+    from stereoformer_amd import _native as N
+    torch.manual_seed(5)
+    x = torch.randn(*shape, device="cuda")
+    y = N.nhwc(x)
+    assert y.is_contiguous(memory_format=torch.channels_last) and y.shape == x.shape
+    assert torch.equal(y, x)
+    assert torch.equal(y.permute(0, 2, 3, 1).contiguous(), x.permute(0, 2, 3, 1).contiguous())
+    assert N.nhwc(y) is y or N.nhwc(y).data_ptr() == y.data_ptr()
+    odd = torch.randn(1, 24, 3, 5, device="cuda")
+    z = N.nhwc(odd)
+    assert z.is_contiguous(memory_format=torch.channels_last) and torch.equal(z, odd)
