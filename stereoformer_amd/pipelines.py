@@ -17,7 +17,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from . import _native as N
+from . import _native
 from .corr import CorrBlock1D, coords_grid
 from .update_dlc import DisparityUpdateDLCWithMask
 from .update_raft import BasicMultiUpdateBlock_LZH
@@ -166,8 +166,8 @@ class RAFTStereoLoop(nn.Module):
         if self._nhwc():
             cl = torch.channels_last
             self.update_block.to(memory_format=cl)   # no-op once converted
-            net_list = [N.nhwc(n) for n in net_list]
-            inp_list = [[N.nhwc(t) for t in lvl] for lvl in inp_list]
+            net_list = [_native.nhwc(n) for n in net_list]
+            inp_list = [[_native.nhwc(t) for t in lvl] for lvl in inp_list]
         elif self.channels_last is None:
             self.update_block.to(memory_format=torch.contiguous_format)   # back from an earlier inference call (no-op otherwise)
         preds = []
