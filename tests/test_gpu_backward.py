@@ -377,6 +377,26 @@ def test_corr_volume_backward_single_read_kernel(S, shape, gscale):
     assert e1 <= 2.0 * e0 + 5e-7, (e1, e0)
 
 
+def test_corr_volume_backward_single_read_kernel_random_shapes(S):
+    """Twelve random shapes inside the one-read kernel's envelope (C <= 32, D <= 192, W % 4 == 0; rows per workgroup, ragged
+    rectangles, partial last blocks all vary) against fp64."""
+    rng = np.random.default_rng(2024)
+    for _ in range(12):
+        B = int(rng.integers(1, 3))
+        C = int(rng.integers(1, 33))
+        H = int(rng.integers(1, 400)) if rng.random() < 0.3 else int(rng.integers(1, 9))
+        W = 4 * int(rng.integers(1, 330 if H < 20 else 40))
+        D = int(rng.integers(1, 193))
+        L0, R0 = torch.randn(B, C, H, W, device="cuda"), torch.randn(B, C, H, W, device="cuda")
+        cot = torch.randn(B, D, H, W, device="cuda") * float(10.0 ** rng.integers(-6, 4))
+        L, R = L0.clone().requires_grad_(True), R0.clone().requires_grad_(True)
+        got = torch.autograd.grad(S.CostVolume(D)(L, R), [L, R], cot)
+        ref = _corr_bwd_fp64(L0, R0, cot)
+        for a, b in zip(got, ref):
+            scale = max(b.abs().max().item(), 1e-30)
+            assert (a.double() - b).abs().max().item() <= 2e-5 * scale, (B, C, H, W, D)
+
+
 @pytest.mark.parametrize("D", [7, 48, 96, 150, 192])
 def test_soft_argmin_backward_with_addend(S, D):
     """stereo_soft_argmin_bwd_add_f32: grad_vol = addend + soft-argmin backward, bit for bit what the plain entry followed by
