@@ -189,9 +189,9 @@ class RAFTStereoLoop(nn.Module):
 
 class LowCNNGRULoop(nn.Module):
     def __init__(self, input_channels=24, hidden_dim=32, sample_points=20, channels_last=None):
-        """``channels_last``: keep the updater's weights and activations in NHWC; for inference its 3x3 convolutions (GRU gates
-        with the gate math in their epilogues, offset head, mask head) then run on the library's own convolution kernels
-        (``conv_split``), the two encoder convolutions (24 and 3 input channels) and the 1x1 mask projection stay with MIOpen.
+        """``channels_last``: keep the updater's weights and activations in NHWC; for inference every convolution of the updater
+        (encoder with BatchNorm folded and zero-padded inputs, GRU gates with the gate math in their epilogues, offset head,
+        mask head incl. its 1x1 projection) then runs on this package's own convolution kernels (``conv_split``).
         Same arithmetic to fp32 rounding.  ``None`` (default): NHWC whenever the forward runs without gradients, NCHW + library
         convolutions under autograd."""
         super().__init__()

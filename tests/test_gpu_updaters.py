@@ -314,7 +314,8 @@ def test_cfg5_attention_flow_init_loop_chain(S, oracle):
 
 def test_lowcnn_gru_loop_channels_last_takes_the_split_convolutions(S, monkeypatch):
     """LowCNNGRULoop in NHWC (the inference default): the updater's 3x3 convolutions (guidance encoders with their BatchNorm
-    folded in, GRU gates with the gate math in the epilogues, offset head, mask head) run on conv_split (asserted); same
+    folded in, GRU gates with the gate math in the epilogues, offset head, mask head incl. its 1x1 projection) run on conv_split
+    (asserted); same
     disparities as the NCHW / library-convolution loop to fp32 rounding, eager and graph."""
     import copy
     from stereoformer_amd import conv_split as C
@@ -334,7 +335,7 @@ def test_lowcnn_gru_loop_channels_last_takes_the_split_convolutions(S, monkeypat
         a = ref(vol, disp, left, right, iters=5)
         assert not calls
         b = cl(vol, disp, left, right, iters=5)
-        assert len(calls) == 5 * 6                      # per iteration: 2 encoders, z | b and g gates, offset.conv1, mask[0]
+        assert len(calls) == 5 * 7                      # per iteration: 2 encoders, z | b and g gates, offset.conv1, mask[0], mask[2]
         g = cl(vol, disp, left, right, iters=5, use_graph=True, graph_all_iterates=True)
     for x, y, z in zip(a, b, g):
         assert x.shape == y.shape and float((x - y).abs().max()) < 2e-3 * max(1.0, float(x.abs().max()) / 50), float((x - y).abs().max())
