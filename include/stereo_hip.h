@@ -173,6 +173,11 @@ int stereo_disp_warp_f32(const float *img, const float *disp, float *warped, flo
 int stereo_upsample_convex_f32(const float *disp, const float *mask, float *out,
                                int N, int Cd, int H, int W, int f, void *stream);
 
+/* The same with the mask CHANNELS-LAST, mask [N][H*W][9*f*f] (the memory of a torch.channels_last [N,9*f*f,H,W] tensor: what
+ * the update blocks' mask heads produce on the channels-last convolution kernels); f = 8 or 4, else STEREO_ERR_UNSUPPORTED. */
+int stereo_upsample_convex_nhwc_mask_f32(const float *disp, const float *mask, float *out,
+                                         int N, int Cd, int H, int W, int f, void *stream);
+
 /* F.interpolate(bilinear) to (Ho,Wo): upsample_simple8 / upflow8 / interp / the 1/8 image
  * resize (upsample.py:41-43, utils.py:85-87, update/update.py:125-127, Attempts/update.py:73-77);
  * out = scale * interp(in) */

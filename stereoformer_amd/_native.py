@@ -51,6 +51,7 @@ SIGNATURES = {
     "stereo_bilinear_sampler_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "stereo_disp_warp_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_upsample_convex_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "stereo_upsample_convex_nhwc_mask_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_resize_bilinear_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
     "stereo_resize_bilinear_nhwc_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
     "stereo_cross_attention_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

@@ -53,12 +53,23 @@ def upsample_convex(disp, mask, factor):
             raise RuntimeError("upsample_convex: backward is built for factors 4 and 8 only")
         return _UpsampleConvexFn.apply(disp.contiguous(), mask.contiguous(), int(factor))
     disp = N.dev_f32(disp, "upsample_convex: disp")
-    mask = N.dev_f32(mask, "upsample_convex: mask")
     n, cd, h, w = disp.shape
     if tuple(mask.shape) != (n, 9 * factor * factor, h, w):
         raise RuntimeError(f"upsample_convex: mask shape {tuple(mask.shape)} is not "
                            f"[{n},{9 * factor * factor},{h},{w}]")  # the reference's .view would fail
     out = torch.empty((n, cd, factor * h, factor * w), device=disp.device, dtype=torch.float32)
+    # a channels-last mask (the update blocks' mask heads on the channels-last convolution kernels) is read as it is
+    if (factor in (4, 8) and mask.is_cuda and mask.dtype == torch.float32 and not mask.is_contiguous()
+            and mask.is_contiguous(memory_format=torch.channels_last)):
+        with torch.cuda.device(disp.device):
+            try:
+                N.call("stereo_upsample_convex_nhwc_mask_f32", N.ptr(disp), N.ptr(mask), N.ptr(out), n, cd, h, w, int(factor),
+                       N.stream_ptr(disp.device))
+                return out
+            except N.StereoHipError as e:
+                if e.code != N.ERR_UNSUPPORTED:
+                    raise
+    mask = N.dev_f32(mask, "upsample_convex: mask")
     with torch.cuda.device(disp.device):
         N.call("stereo_upsample_convex_f32", N.ptr(disp), N.ptr(mask), N.ptr(out), n, cd, h, w, int(factor),
                N.stream_ptr(disp.device))

@@ -619,3 +619,18 @@ def test_relayout_nchw_to_nhwc(shape):
     odd = torch.randn(1, 24, 3, 5, device="cuda")
     z = N.nhwc(odd)
     assert z.is_contiguous(memory_format=torch.channels_last) and torch.equal(z, odd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(2, 1, 9, 70, 8), (1, 2, 5, 130, 4), (1, 1, 3, 64, 4), (2, 2, 4, 33, 8)])
+def test_upsample_convex_reads_a_channels_last_mask(cfg):
+    """upsample_convex with the mask channels-last (what the update blocks' mask heads hand over from the channels-last
+    convolution kernels): same values as through the NCHW mask, no copy of the mask in between."""
+    import stereoformer_amd as S
+    n, cd, h, w, f = cfg
+    torch.manual_seed(11)
+    disp = torch.randn(n, cd, h, w, device="cuda") * 5
+    mask = torch.randn(n, 9 * f * f, h, w, device="cuda")
+    ref = S.upsample_convex(disp, mask, f)
+    got = S.upsample_convex(disp, mask.contiguous(memory_format=torch.channels_last), f)
+    assert got.shape == ref.shape and torch.equal(got, ref)
