@@ -340,3 +340,30 @@ def test_lowcnn_gru_loop_channels_last_takes_the_split_convolutions(S, monkeypat
     for x, y, z in zip(a, b, g):
         assert x.shape == y.shape and float((x - y).abs().max()) < 2e-3 * max(1.0, float(x.abs().max()) / 50), float((x - y).abs().max())
         assert float((y - z).abs().max()) < 1e-4
+
+
+def test_captured_raft_loop_does_not_keep_a_motion_buffer_per_iteration(S):
+    """inside a HIP-graph capture the side-stream motion tensor must not be record_stream()ed (that defers every
+    iteration's free to the end of the capture: one [B,128,h,w] buffer per iteration in the graph's private pool).  The
+    pool of a 12-iteration capture may exceed that of a 4-iteration capture by far less than 8 such buffers."""
+    B, Hq, Wq = 2, 64, 96
+    motion_bytes = B * 128 * Hq * Wq * 4
+
+    def graph_pool_bytes(iters):
+        torch.manual_seed(3)
+        loop = S.RAFTStereoLoop([128, 128, 128]).eval().cuda()
+        f1, f2, nets, inps = _loop_inputs(B, Hq, Wq, 77)
+        with torch.no_grad():
+            loop(f1, f2, [n.clone() for n in nets], inps, iters=iters, test_mode=True)     # eager: warms every cache
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            before = torch.cuda.memory_reserved()
+            loop(f1, f2, [n.clone() for n in nets], inps, iters=iters, test_mode=True, use_graph=True)
+            torch.cuda.synchronize()
+            grown = torch.cuda.memory_reserved() - before
+        del loop
+        torch.cuda.empty_cache()
+        return grown
+
+    small, large = graph_pool_bytes(4), graph_pool_bytes(12)
+    assert large - small < 3 * motion_bytes, (small, large, motion_bytes)
