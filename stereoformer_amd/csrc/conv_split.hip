@@ -671,6 +671,10 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(const float *__rest
 {
     constexpr int HC = 32 + K - 1, HR = 8 + K - 1, HALO = K / 2, MAXC = 4;
     __shared__ float tile[MAXC * HR * HC];
+    // the weights of ONE group of 16 output channels, [tap][channel][16], staged through LDS per group and read back as
+    // wave-wide broadcasts.  As scalar loads (they are wave-uniform) every tap's 64 bytes were fetched right before use and
+    // waited for -- ~400 dependent scalar-load round trips per wave: 0.14-0.16 ms for a 25-us arithmetic job.
+    __shared__ __attribute__((aligned(16))) float wsh[K * K * MAXC * 16];
     const int tid = threadIdx.x, row = tid >> 5, col = tid & 31;
     int t = blockIdx.x;
     const int tx = t % tiles_x;
@@ -687,6 +691,12 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(const float *__rest
     const int y = y0 + row, xo = x0 + col;
     float *op = out + (((size_t)b * H + y) * W + xo) * ostride;
     for (int o0 = 0; o0 < Cout; o0 += 16) {
+        __syncthreads();   // the previous group's weights have been consumed (first round: the tile is complete)
+        for (int i = tid; i < K * K * Cin * 4; i += 256) {   // 16-byte quads of [tap][channel][16]
+            const int tc = i >> 2, q4 = (i & 3) * 4;
+            *reinterpret_cast<f32x4 *>(wsh + tc * 16 + q4) = *reinterpret_cast<const f32x4 *>(wt + (size_t)tc * Cout + o0 + q4);
+        }
+        __syncthreads();
         f32x2 acc[8];    // channel pairs: v_pk_fma_f32 does two multiply-adds in the issue slot of one
 #pragma unroll
         for (int o = 0; o < 8; ++o) acc[o] = bias ? (f32x2){bias[o0 + 2 * o], bias[o0 + 2 * o + 1]} : (f32x2){0.0f, 0.0f};
@@ -697,7 +707,7 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(const float *__rest
                 for (int kx = 0; kx < K; ++kx) {
                     const float v = tile[(c * HR + row + ky) * HC + col + kx];
                     const f32x2 vv = {v, v};
-                    const f32x2 *wk = reinterpret_cast<const f32x2 *>(wt + ((size_t)((ky * K + kx) * Cin + c)) * Cout + o0);   // wave-uniform
+                    const f32x2 *wk = reinterpret_cast<const f32x2 *>(wsh + ((ky * K + kx) * Cin + c) * 16);   // wave-uniform
 #pragma unroll
                     for (int o = 0; o < 8; ++o) acc[o] = __builtin_elementwise_fma(vv, wk[o], acc[o]);
                 }
@@ -724,7 +734,8 @@ extern "C" int stereo_conv_small_cin_nhwc_f32(const float *x, const float *weigh
     STEREO_REQUIRE_PTR(x);
     STEREO_REQUIRE_PTR(weight_tco);
     STEREO_REQUIRE_PTR(out);
-    if (Cin > 4 || Cout % 16 != 0 || Cout > 64 || out_stride % 4 != 0 || !aligned16(out) || (ksize != 3 && ksize != 5 && ksize != 7))
+    if (Cin > 4 || Cout % 16 != 0 || Cout > 64 || out_stride % 4 != 0 || !aligned16(out) || !aligned16(weight_tco) ||
+        (ksize != 3 && ksize != 5 && ksize != 7))
         return STEREO_ERR_UNSUPPORTED;
     const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
     const long long nt = (long long)tiles_x * tiles_y * B;
