@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void guidance_inputs_nhwc_kernel(const float *
             const bool y0 = iy >= 0 && iy <= H - 1, y1 = iy + 1 >= 0 && iy + 1 <= H - 1;
             const float w00 = (1.0f - ax) * (1.0f - ay), w01 = ax * (1.0f - ay), w10 = (1.0f - ax) * ay, w11 = ax * ay;
             float *eo = err + (size_t)t * CE;
-            for (int c = 0; c < CE; ++c) {
+            auto err_c = [&](int c) {
                 float v = 0.0f;
                 if (c < Ci) {
                     const float *im = right + ((size_t)b * Ci + c) * HW;
@@ -229,24 +229,61 @@ __global__ __launch_bounds__(256) void guidance_inputs_nhwc_kernel(const float *
                     if (y1 && x1) s += im[(size_t)(iy + 1) * W + ix + 1] * w11;
                     v = s - left[((size_t)b * Ci + c) * HW + p];
                 }
-                eo[c] = v;
+                return v;
+            };
+            if ((CE & 3) == 0) {
+                for (int c = 0; c < CE; c += 4) st4(eo + c, (f32x4){err_c(c), err_c(c + 1), err_c(c + 2), err_c(c + 3)});
+            } else {
+                for (int c = 0; c < CE; ++c) eo[c] = err_c(c);
             }
         }
         {   // ---- uncertainty volume
             const float *v = vol + (size_t)b * D * HW + p;
             float *uo = unc + (size_t)t * CU;
-            Softmax1 sm;
-            sm.init();
-            for (int d = 0; d < D; ++d) sm.push(v[(size_t)d * HW]);
-            const float inv = 1.0f / sm.s;
-            for (int d = 0; d < CU; ++d) {
-                float o = 0.0f;
-                if (d < D) {
-                    const float pd = fast_exp(v[(size_t)d * HW] - sm.m) * inv;
-                    const float e = (float)d - cur;
-                    o = pd * (float)d * e * e;
+            if (D <= 32 && CU <= 32 && (CU & 3) == 0) {
+                // the column in registers: every plane loaded once, all loads in flight (the two-pass loop below is 2 D dependent
+                // rounds), the 32 padded channels leave as eight 16-byte stores instead of 32 scattered dwords
+                float xs[32];
+#pragma unroll
+                for (int d = 0; d < 32; ++d) xs[d] = d < D ? v[(size_t)d * HW] : -INFINITY;
+                Softmax1 sm;   // (the same online recurrence as the generic path and uncertainty_kernel: bit-identical sums)
+                sm.init();
+#pragma unroll
+                for (int d = 0; d < 32; ++d)
+                    if (d < D) sm.push(xs[d]);
+                const float inv = 1.0f / sm.s;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (4 * q < CU) {
+                        f32x4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int d = 4 * q + i;
+                            const float e = (float)d - cur;
+                            float val = 0.0f;
+                            if (d < D) {
+                                const float pd = fast_exp(xs[d] - sm.m) * inv;
+                                val = pd * (float)d * e * e;
+                            }
+                            o[i] = val;
+                        }
+                        st4(uo + 4 * q, o);
+                    }
                 }
-                uo[d] = o;
+            } else {
+                Softmax1 sm;
+                sm.init();
+                for (int d = 0; d < D; ++d) sm.push(v[(size_t)d * HW]);
+                const float inv = 1.0f / sm.s;
+                for (int d = 0; d < CU; ++d) {
+                    float o = 0.0f;
+                    if (d < D) {
+                        const float pd = fast_exp(v[(size_t)d * HW] - sm.m) * inv;
+                        const float e = (float)d - cur;
+                        o = pd * (float)d * e * e;
+                    }
+                    uo[d] = o;
+                }
             }
         }
     }
