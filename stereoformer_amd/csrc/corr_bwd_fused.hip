@@ -411,6 +411,7 @@ int stereo_corr_volume_bwd_fused(const float *left, const float *right, const fl
     const int nrows = B * H;
     const int rpw = (nrows + ncu - 1) / ncu;  // one resident workgroup per CU, contiguous rows each
     const int nwg = (nrows + rpw - 1) / rpw;
+    if ((long long)rpw * ((W + FB_TW - 1) / FB_TW) * ((D + 31) / 32 + 3) >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;  // item counter
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(FB_NTH), FB_LDS, st, grad_vol, left, right, grad_left, grad_right, C, H, W, D,
                        1.0f / (float)C, nrows, rpw, stereo_opt(OPT_CORR_BWD_FUSED));
     STEREO_LAUNCH_CHECK();
