@@ -918,8 +918,11 @@ extern "C" int stereo_gwc_volume_bwd_f32(const float *left, const float *right, 
     if (D > 0) STEREO_REQUIRE_PTR(grad_vol);
     if (grad_left == nullptr && grad_right == nullptr) return STEREO_OK;
     {
-        if (G == 1 && D > 0 && stereo_opt(OPT_CORR_MFMA) != 0) {
-            const int rc = stereo_corr_volume_bwd_mfma(left, right, grad_vol, grad_left, grad_right, B, C, H, W, D,
+        // Group g of batch b uses channels g CPG .. of the features and slab (b G + g) of the gradient volume: with the channels
+        // of a group contiguous, the group-wise backward IS the correlation backward of B G "pairs" with CPG channels each
+        // (mean over CPG) -- the same pointers, reinterpreted.  So the one-read kernel serves A3 as well.
+        if (D > 0 && G >= 1 && C % G == 0 && (long long)B * G < (1LL << 30) && stereo_opt(OPT_CORR_MFMA) != 0) {
+            const int rc = stereo_corr_volume_bwd_mfma(left, right, grad_vol, grad_left, grad_right, B * G, C / G, H, W, D,
                                                        as_stream(stream));
             if (rc != STEREO_ERR_UNSUPPORTED) return rc;
         }

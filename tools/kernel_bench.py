@@ -323,7 +323,9 @@ def main():
             n2 = 2 * H * W
             add("bwd A3 gwc volume B=2 G=8 (dL + dR)",
                 timeit(lambda: torch.autograd.grad(vg, (L1g, R1g), cg, retain_graph=True), 3, 1),
-                (2 * n2 * G * D * 4 + 4 * n2 * C * 4) / 1e9)
+                (n2 * G * D * 4 + 4 * n2 * C * 4) / 1e9,
+                note="round 3: the one-read A1 backward on B G pairs of C / G channels (the same pointers reinterpreted); bytes = ONE "
+                     "read of the gradient volume + features in / gradients out (round 2: two reads, 3.5 ms)")
             del vg, cg
             # the backward paths added in round 2 (A6, A2, A7 by composition), one pair
             v1 = S.CostVolume(D)(L[:1], R[:1]).detach().requires_grad_(True)
