@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import stereoformer_amd as S
 from stereoformer_amd import _native as N
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-rng = np.random.default_rng(12345)
+rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "12345")))
 dev = "cuda"
 worst = {}
 
