@@ -454,6 +454,18 @@ int stereo_conv_small_cin_nhwc_f32(const float *x, const float *weight_tco, cons
 int stereo_conv3x3_small_nhwc_ex(const void *x, int x_is_f16, const float *weight_tco, const float *bias, float *out_nchw, int B,
                                  int Cin, int Cout, int H, int W, int relu, void *stream);
 
+/* HBM arena of separately mapped physical chunks (HIP virtual-memory management), for placing the volume stage's 25.5-GB output
+ * where the memory system takes its stores fastest (the reference leaves the placement of
+ * build_gwc_volume's output, utils/build_cost_volume.py:5-54, to torch's allocator).  `nchunks` allocations of `chunk_bytes` (a
+ * multiple of stereo_hbm_arena_granularity) are mapped back to back at *base_out; after the caller has timed its windows,
+ * stereo_hbm_arena_keep unmaps and releases every chunk outside [first, first + count) -- addresses inside stay valid, any
+ * access outside faults.  keep / destroy synchronise the device first.  STEREO_ERR_UNSUPPORTED without VMM support,
+ * STEREO_ERR_LAUNCH when the driver refuses (out of memory); nothing stays allocated on error. */
+int stereo_hbm_arena_granularity(long long *bytes);
+int stereo_hbm_arena_create(long long chunk_bytes, int nchunks, void **arena_out, void **base_out);
+int stereo_hbm_arena_keep(void *arena, int first, int count);
+int stereo_hbm_arena_destroy(void *arena);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,10 @@ SIGNATURES = {
     "stereo_instance_norm_relu_nhwc": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "stereo_relayout_nhwc_to_nchw": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_relayout_nchw_to_nhwc_f32": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "stereo_hbm_arena_granularity": [ctypes.POINTER(_ll)],
+    "stereo_hbm_arena_create": [_ll, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp)],
+    "stereo_hbm_arena_keep": [_vp, _i, _i],
+    "stereo_hbm_arena_destroy": [_vp],
     "stereo_conv3x3_small_nhwc_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_conv3x3_small_nhwc_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_conv3x3_small_nhwc_ex": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

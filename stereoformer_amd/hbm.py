@@ -1,5 +1,14 @@
 """HBM placement of large, long-lived output buffers.
 
+Round 3 addendum (``tools/place_window_probe.py``, ``tools/place_mapped_probe.py``): the speed is not a property of "an
+allocation" but of WHERE inside the device's memory the 25.5-GB volume lies: slid through one large allocation in 2-GB steps,
+the launch time moves smoothly and repeatably between 4.65 and 5.9 ms (plateaus 10-40 GB wide), and a window re-created as its
+own allocation lands elsewhere.  ``place_in_mapped_arena`` therefore builds the search arena from 1-GB physical chunks mapped
+back to back (``MappedArena``, HIP virtual-memory management in ``csrc/hbm_arena.hip``), times windows across up to 160 GB of
+it, and then releases every chunk outside the fastest window: the buffer keeps its addresses and its pages -- hence its speed
+-- and nothing else stays allocated.  ``place_in_arena`` is the same search over one ordinary allocation (buffer + slack) that
+has to stay allocated, for devices without virtual-memory management; ``place`` (whole candidate allocations) is round 2's form.
+
 Measured on MI355X (``tools/alloc_probe.py``): the fused volume-stage launch, which streams 28.7 GB of
 row-contiguous 1-KiB stores into ~8 000 concurrent output rows, runs at one of two stable speeds depending on WHICH physical
 memory its output buffers were given by the driver -- 4.65-4.9 ms (6.1-6.4 TB/s, the rate of a plain linear fill) or
@@ -68,9 +77,183 @@ def _event_ms(fn, reps):
     return best
 
 
-def place_volume_stage_outputs(left, right, maxdisp, num_groups, max_tries=6, probe_reps=2, good_enough_tbs=6.3):
+def _search_windows(nsteps, coarse_steps, measure, good_enough_ms):
+    """Window indices 0..nsteps: every ``coarse_steps``-th first, then the neighbours of the fastest of those.  ``measure(k)``
+    returns (and the caller caches) the time of window k; stops at the first window within ``good_enough_ms``."""
+    coarse_steps = max(1, int(coarse_steps))
+    seen = {}
+    for k in range(0, nsteps + 1, coarse_steps):
+        seen[k] = measure(k)
+        if good_enough_ms is not None and seen[k] <= good_enough_ms:
+            return seen
+    k0 = min(seen, key=seen.get)
+    for k in range(max(0, k0 - coarse_steps + 1), min(nsteps, k0 + coarse_steps - 1) + 1):
+        if k not in seen:
+            seen[k] = measure(k)
+            if good_enough_ms is not None and seen[k] <= good_enough_ms:
+                break
+    return seen
+
+
+def place_in_arena(nbytes, probe, slack_bytes=64 << 30, step_bytes=2 << 30, coarse_steps=4, good_enough_ms=None, device=None,
+                   dtype=torch.float32, reserve_bytes=8 << 30):
+    """One allocation of ``nbytes + slack_bytes``; ``probe(window) -> ms`` is called with 1-D ``dtype`` views of ``nbytes`` at
+    offsets ``0, coarse_steps * step_bytes, ...`` across the slack, then at the ``step_bytes`` offsets around the fastest of
+    those, and the fastest window is returned (it keeps the arena alive).  Stops early at a window within ``good_enough_ms``.
+    Returns ``(window, report)``; raises ``RuntimeError`` when the device lacks the memory (callers fall back to ``place``)."""
+    dev = torch.device(device) if device is not None else torch.device("cuda")
+    es = torch.empty((), dtype=dtype).element_size()
+    nbytes, step_bytes = int(nbytes), int(step_bytes)
+    if step_bytes % 256 or nbytes % es:
+        raise ValueError("place_in_arena: step_bytes must be a multiple of 256 and nbytes of the element size")
+    free, _total = torch.cuda.mem_get_info(dev)
+    slack = (min(int(slack_bytes), free - nbytes - int(reserve_bytes)) // step_bytes) * step_bytes
+    if slack < step_bytes:
+        raise RuntimeError("place_in_arena: not enough free device memory for an arena with slack")
+    arena = torch.empty((nbytes + slack) // es, device=dev, dtype=dtype)
+
+    def measure(k):
+        return float(probe(arena[k * step_bytes // es: (k * step_bytes + nbytes) // es]))
+
+    times = _search_windows(slack // step_bytes, coarse_steps, measure, good_enough_ms)
+    best = min(times, key=times.get)
+    off = best * step_bytes
+    report = {"mode": "arena", "arena_bytes": nbytes + slack, "held_beyond_the_buffer_bytes": slack, "step_bytes": step_bytes,
+              "probe_ms_by_offset_GiB": {("%g" % (k * step_bytes / 2**30)): round(v, 4) for k, v in sorted(times.items())},
+              "chosen_offset_bytes": off, "chosen_ms": round(times[best], 4), "first_window_ms": round(times[0], 4)}
+    return arena[off // es: (off + nbytes) // es], report
+
+
+class MappedArena:
+    """``nchunks`` physical allocations of ``chunk_bytes`` mapped back to back into one address range
+    (``csrc/hbm_arena.hip``: HIP virtual-memory management, outside torch's caching allocator).  ``window`` hands out tensors over
+    chunk-aligned pieces; ``keep`` returns every other chunk to the driver while the kept pieces stay where they are --
+    addresses AND pages.  A window tensor holds a reference to the arena; the arena is unmapped when the last one dies."""
+
+    def __init__(self, chunk_bytes, nchunks, device=None):
+        import ctypes
+
+        from . import _native
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.chunk_bytes, self.nchunks = int(chunk_bytes), int(nchunks)
+        self._handle, self._base, self._kept = None, None, (0, self.nchunks)
+        arena, base = ctypes.c_void_p(), ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            try:
+                _native.call("stereo_hbm_arena_create", self.chunk_bytes, self.nchunks, ctypes.byref(arena), ctypes.byref(base))
+            except _native.StereoHipError as e:
+                raise RuntimeError("MappedArena: the driver refused %d chunks of %d bytes (%s)"
+                                   % (self.nchunks, self.chunk_bytes, e)) from e
+        self._handle, self._base = arena.value, base.value
+
+    @staticmethod
+    def granularity(device=None):
+        import ctypes
+
+        from . import _native
+        g = ctypes.c_longlong()
+        with torch.cuda.device(torch.device(device) if device is not None else torch.cuda.current_device()):
+            _native.call("stereo_hbm_arena_granularity", ctypes.byref(g))
+        return int(g.value)
+
+    def window(self, first_chunk, nbytes, dtype=torch.float32):
+        """1-D ``dtype`` tensor of ``nbytes`` starting at chunk ``first_chunk``; must lie inside the kept chunks."""
+        lo, n = self._kept
+        first_chunk, nbytes = int(first_chunk), int(nbytes)
+        es = torch.empty((), dtype=dtype).element_size()
+        if self._handle is None or nbytes <= 0 or nbytes % es or first_chunk < lo or \
+                first_chunk * self.chunk_bytes + nbytes > (lo + n) * self.chunk_bytes:
+            raise ValueError("MappedArena.window: outside the mapped chunks")
+        return torch.as_tensor(_MappedView(self, self._base + first_chunk * self.chunk_bytes, nbytes // es, dtype),
+                               device=self.device)
+
+    def keep(self, first_chunk, count):
+        """Unmap and release every chunk outside ``[first_chunk, first_chunk + count)`` (device synchronised first).  Windows
+        handed out earlier that reach outside must not be used again."""
+        from . import _native
+        lo, n = self._kept
+        first_chunk, count = int(first_chunk), int(count)
+        if first_chunk < lo or first_chunk + count > lo + n or count < 0:
+            raise ValueError("MappedArena.keep: outside the mapped chunks")
+        _native.call("stereo_hbm_arena_keep", self._handle, first_chunk, count)
+        self._kept = (first_chunk, count)
+
+    def close(self):
+        if self._handle is not None:
+            from . import _native
+            h, self._handle = self._handle, None
+            _native.call("stereo_hbm_arena_destroy", h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _MappedView:
+    """What ``torch.as_tensor`` consumes: the tensor built from it keeps this object -- and with it the arena -- alive."""
+    _TYPESTR = {torch.float32: "<f4", torch.float16: "<f2", torch.uint8: "|u1", torch.int32: "<i4"}
+
+    def __init__(self, arena, ptr, nelem, dtype):
+        self._arena = arena
+        self.__cuda_array_interface__ = {"shape": (int(nelem),), "typestr": self._TYPESTR[dtype], "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def place_in_mapped_arena(nbytes, probe, span_bytes=160 << 30, chunk_bytes=1 << 30, step_chunks=2, coarse_steps=4,
+                          good_enough_ms=None, device=None, dtype=torch.float32, reserve_bytes=12 << 30):
+    """``place_in_arena`` without the held slack: the arena is a ``MappedArena`` of ``nbytes`` (rounded up to chunks) +
+    ``span_bytes`` (clipped to the device's free memory less ``reserve_bytes``), the windows start every ``step_chunks`` chunks,
+    and once the fastest one is known every chunk outside it is released -- the window keeps its pages, so it keeps its speed
+    (the report's ``after_release_ms`` is a re-timing).  Returns ``(window, report)``; ``RuntimeError`` when the device has no
+    virtual-memory management or too little free memory."""
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    nbytes, chunk_bytes, step_chunks = int(nbytes), int(chunk_bytes), max(1, int(step_chunks))
+    from . import _native
+    try:
+        gran = MappedArena.granularity(dev)
+    except _native.StereoHipError as e:
+        raise RuntimeError("place_in_mapped_arena: no virtual-memory management on this device (%s)" % e) from e
+    if chunk_bytes % gran:
+        raise ValueError("place_in_mapped_arena: chunk_bytes must be a multiple of %d" % gran)
+    own = -(-nbytes // chunk_bytes)
+    free, _total = torch.cuda.mem_get_info(dev)
+    span = min(int(span_bytes), free - own * chunk_bytes - int(reserve_bytes)) // (chunk_bytes * step_chunks) * step_chunks
+    if span < step_chunks:
+        raise RuntimeError("place_in_mapped_arena: not enough free device memory for an arena with a span")
+    arena = MappedArena(chunk_bytes, own + span, dev)
+
+    def measure(k):
+        w = arena.window(k * step_chunks, nbytes, dtype)
+        ms = float(probe(w))
+        del w
+        return ms
+
+    times = _search_windows(span // step_chunks, coarse_steps, measure, good_enough_ms)
+    best = min(times, key=times.get)
+    arena.keep(best * step_chunks, own)
+    window = arena.window(best * step_chunks, nbytes, dtype)
+    after = min(float(probe(window)), float(probe(window)))   # the first launches after the unmapping run a few percent slow
+    gib = chunk_bytes * step_chunks / 2**30
+    report = {"mode": "mapped arena", "searched_bytes": (own + span) * chunk_bytes, "held_beyond_the_buffer_bytes":
+              own * chunk_bytes - nbytes, "chunk_bytes": chunk_bytes, "step_bytes": chunk_bytes * step_chunks,
+              "probe_ms_by_offset_GiB": {("%g" % (k * gib)): round(v, 4) for k, v in sorted(times.items())},
+              "chosen_offset_bytes": best * step_chunks * chunk_bytes, "chosen_ms": round(times[best], 4),
+              "after_release_ms": round(after, 4), "first_window_ms": round(times[0], 4)}
+    return window, report
+
+
+def place_volume_stage_outputs(left, right, maxdisp, num_groups, max_tries=6, probe_reps=2, good_enough_tbs=6.3, arena=True,
+                               arena_slack_bytes=64 << 30, arena_step_bytes=2 << 30, mapped=True, mapped_span_bytes=160 << 30,
+                               mapped_chunk_bytes=1 << 30):
     """Output buffers ``(vol [B,G,D,H,W], disp [B,H,W], mean [B,D,H,W])`` for ``build_gwc_volume_with_disparity(..., out=...)``
-    placed by timing that very launch on each candidate (``left`` / ``right`` are only read).  ``good_enough_tbs``: stop at the
+    placed by timing that very launch on each candidate (``left`` / ``right`` are only read).  ``arena=True`` (default): the
+    volume -- the buffer whose location decides the launch's speed -- becomes the fastest window of ONE arena (module
+    docstring): with ``mapped=True`` a chunk-mapped arena spanning up to ``mapped_span_bytes`` whose other chunks are released
+    once the window is chosen (nothing held beyond the buffer); without virtual-memory management, or with ``mapped=False``,
+    one plain allocation of the volume's size + ``arena_slack_bytes`` that stays allocated; whole candidate allocations
+    (``arena=False``) when the device lacks the memory for either.  ``good_enough_tbs``: stop at the
     first candidate that streams the algorithmic bytes faster than this (TB/s): 6.3 is the fast level itself (4.64-4.72 ms at
     cfg-2); probe times taken while the other candidates are still held run a few percent above the steady state, so a looser
     threshold would stop at a middling arena."""
@@ -80,6 +263,40 @@ def place_volume_stage_outputs(left, right, maxdisp, num_groups, max_tries=6, pr
     dev = left.device
     n_bytes = 4 * (B * G * D * H * W + B * D * H * W + B * H * W)
     algorithmic = n_bytes + 2 * B * C * H * W * left.element_size()
+
+    if arena:
+        disp_b = torch.empty((B, H, W), device=dev, dtype=torch.float32)
+        mean_b = torch.empty((B, D, H, W), device=dev, dtype=torch.float32)
+        enough_ms = algorithmic / (max(good_enough_tbs, 6.4) * 1e12) * 1e3
+
+        def probe_window(win):
+            bufs = (win.view(B, G, D, H, W), disp_b, mean_b)
+            with torch.no_grad():
+                return _event_ms(lambda: build_gwc_volume_with_disparity(left, right, D, G, return_mean=True, out=bufs), probe_reps)
+
+        win = report = None
+        if mapped:
+            try:
+                win, report = place_in_mapped_arena(4 * B * G * D * H * W, probe_window, span_bytes=mapped_span_bytes,
+                                                    chunk_bytes=mapped_chunk_bytes, good_enough_ms=enough_ms, device=dev)
+                report["policy"] = ("the volume is the fastest window (%g-GB steps) of a chunk-mapped arena of %.0f GB; every "
+                                    "chunk outside the window released afterwards; stop at >= %.1f TB/s"
+                                    % (report["step_bytes"] / 2**30, report["searched_bytes"] / 2**30, max(good_enough_tbs, 6.4)))
+            except RuntimeError:
+                win = None
+        if win is None:
+            try:
+                win, report = place_in_arena(4 * B * G * D * H * W, probe_window, slack_bytes=arena_slack_bytes,
+                                             step_bytes=arena_step_bytes, good_enough_ms=enough_ms, device=dev)
+                report["policy"] = ("the volume is the fastest window (2-GB steps) of one arena of its size + %.0f GB; the arena "
+                                    "stays allocated with it; stop at >= %.1f TB/s"
+                                    % (report["held_beyond_the_buffer_bytes"] / 2**30, max(good_enough_tbs, 6.4)))
+            except RuntimeError:
+                win = None
+        if win is not None:
+            report["bytes_per_candidate"] = n_bytes
+            return (win.view(B, G, D, H, W), disp_b, mean_b), report
+        del disp_b, mean_b
 
     def alloc():
         return (torch.empty((B, G, D, H, W), device=dev, dtype=torch.float32),

@@ -778,12 +778,38 @@ def test_out_buffers_and_placement(S, oracle):
     B, C, H, W, D, G = 1, 16, 3, 64, 20, 4
     L, R = dev(rng.standard_normal((B, C, H, W), dtype=np.float32)), dev(rng.standard_normal((B, C, H, W), dtype=np.float32))
     want = S.build_gwc_volume_with_disparity(L, R, D, G, return_mean=True)
-    bufs, rep = S.hbm.place_volume_stage_outputs(L, R, D, G, max_tries=3, good_enough_tbs=1e9)
+    bufs, rep = S.hbm.place_volume_stage_outputs(L, R, D, G, max_tries=3, good_enough_tbs=1e9, arena=False)
     assert len(rep["probe_ms"]) == 3 and rep["chosen_ms"] == min(rep["probe_ms"])
     for b_ in bufs:
         b_.fill_(float("nan"))
     got = S.build_gwc_volume_with_disparity(L, R, D, G, return_mean=True, out=bufs)
     for a, b_, w in zip(got, bufs, want):
+        assert a.data_ptr() == b_.data_ptr() and torch.equal(a, w)
+    # mapped-arena mode (the default): the volume is a window of a chunk-mapped arena whose other chunks are released afterwards
+    free0 = torch.cuda.mem_get_info()[0]
+    mbufs, mrep = S.hbm.place_volume_stage_outputs(L, R, D, G, good_enough_tbs=1e9, mapped_span_bytes=32 << 20, mapped_chunk_bytes=1 << 20)
+    assert mrep["mode"] == "mapped arena" and mrep["searched_bytes"] == 33 << 20 and mrep["held_beyond_the_buffer_bytes"] < 1 << 20
+    assert len(mrep["probe_ms_by_offset_GiB"]) >= 5 and mrep["chosen_offset_bytes"] % (2 << 20) == 0
+    assert free0 - torch.cuda.mem_get_info()[0] < 24 << 20          # the other 32 chunks went back to the driver
+    for b_ in mbufs:
+        b_.fill_(float("nan"))
+    got = S.build_gwc_volume_with_disparity(L, R, D, G, return_mean=True, out=mbufs)
+    for a, b_, w in zip(got, mbufs, want):
+        assert a.data_ptr() == b_.data_ptr() and torch.equal(a, w)
+    keep = mbufs[0].clone()
+    del mbufs, got, a, b_                                             # the last window tensor unmaps the arena
+    torch.cuda.synchronize()
+    assert torch.equal(keep, want[0])
+    # plain-arena mode: a window of one ordinary allocation (volume + slack) that stays allocated; same results
+    abufs, arep = S.hbm.place_volume_stage_outputs(L, R, D, G, good_enough_tbs=1e9, arena_slack_bytes=16 << 20, arena_step_bytes=1 << 20,
+                                                   mapped=False)
+    assert arep["mode"] == "arena" and arep["held_beyond_the_buffer_bytes"] == 16 << 20
+    assert arep["chosen_ms"] == min(arep["probe_ms_by_offset_GiB"].values()) or len(arep["probe_ms_by_offset_GiB"]) >= 5
+    assert arep["chosen_offset_bytes"] % (1 << 20) == 0 and abufs[0].is_contiguous()
+    for b_ in abufs:
+        b_.fill_(float("nan"))
+    got = S.build_gwc_volume_with_disparity(L, R, D, G, return_mean=True, out=abufs)
+    for a, b_, w in zip(got, abufs, want):
         assert a.data_ptr() == b_.data_ptr() and torch.equal(a, w)
     with pytest.raises(ValueError, match="out"):
         S.build_gwc_volume_with_disparity(L, R, D, G, out=(bufs[0], bufs[1], bufs[2][:, :-1]))
