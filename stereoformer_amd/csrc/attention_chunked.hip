@@ -570,6 +570,12 @@ int stereo_cross_attention_chunked(const TIN *L, const TIN *R, const TIN *V, flo
         (long long)32 * H * W >= (1LL << 31))
         return STEREO_ERR_UNSUPPORTED;
     const int nt = (D + 31) / 32 + 1;
+    // disparity only, bands of <= 128: the split-fp16 form with 16-channel items (attention_chunked16.hip); hook 8 keeps the
+    // split-bf16 form below
+    if (out == nullptr && disp != nullptr && split_bf16_form && stereo_opt(OPT_ATT_KERNEL) != 8) {
+        const int rc16 = stereo_cross_attention_disp_chunked16<TIN>(L, R, disp, B, C, H, W, D, mask_mode, sc, st);
+        if (rc16 != STEREO_ERR_UNSUPPORTED) return rc16;
+    }
     // waves (32 queries each) per workgroup: the shape that wastes the fewest 32-query slots of a row -- 8 (256 queries),
     // 5 (160) or 4 (128); ties go to the wider tile (less halo re-read).  W = 240 -> 8 (one tile per row), 312 -> 5.
     const int qt = (W + 31) / 32;

@@ -266,6 +266,11 @@ int stereo_corr_volume_chunked(const TIN *L, const TIN *R, float *vol, float *di
                                float sgn, hipStream_t st);
 // attention_f16.hip: A7 for C <= 32, value = right features, on the fp16 matrix cores with two-piece operands (hi + 2^-11 lo'),
 // three products, two accumulators: the default there.
+// attention_chunked16.hip: disparity-only A7 for any channel count on the fp16 matrix cores with split operands (16-channel
+// items); STEREO_ERR_UNSUPPORTED outside its envelope (D <= 128, W % 4 == 0, quad-aligned, 32 H W < 2^30).
+template <typename TIN>
+int stereo_cross_attention_disp_chunked16(const TIN *L, const TIN *R, float *disp, int B, int C, int H, int W, int D,
+                                          int mask_mode, float sc, hipStream_t st);
 template <typename TIN>
 int stereo_cross_attention_split16(const TIN *left, const TIN *right, float *out, float *disp, int B, int C, int H, int W, int D,
                                    int mask_mode, float sc, hipStream_t st);

@@ -141,6 +141,40 @@ def test_cross_attention_chunked_kernel_fp32(S, oracle, cfg, waves, kern):
             disp_close(d2, od, D)
 
 
+@pytest.mark.parametrize("cfg", [(1, 256, 2, 312, 64), (2, 64, 3, 240, 48), (1, 40, 2, 128, 100), (1, 33, 1, 96, 20), (1, 100, 2, 516, 128),
+                                 (2, 48, 5, 36, 7), (1, 17, 3, 644, 33), (1, 272, 1, 160, 96)])
+@pytest.mark.parametrize("waves", [0, 4, 5, 8])
+@pytest.mark.parametrize("half", [False, True])
+def test_cross_attention_disparity_only_chunked16(S, oracle, cfg, waves, half):
+    """A7 without a value tensor at C > 32 (default route: attention_chunked16.hip, split-fp16 operands, 16-channel items) against
+    the oracle: every workgroup shape, 1 / 2 / auto tiles per persistent workgroup (item pipeline across tile and row ends), both
+    masks and scales, channel counts that are no multiple of 16, bands up to 128, fp32 and fp16 features; features of magnitude
+    ~30 (the split must hold fp32-level accuracy on peaked softmaxes); and agreement with the split-bf16 form (hook 8)."""
+    B, C, H, W, D = cfg
+    rng = np.random.default_rng(79)
+    L = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    R = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    if half:
+        (Ld, L), (Rd, R) = h16(L), h16(R)
+    else:
+        Ld, Rd = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    for mask, scale in (("zero", "sqrt_c"), ("neginf", "mean"), ("neginf", "sqrt_c")):
+        _, od = oracle.cross_attention(L, R, None, D, mask, scale)
+        for tpw in (0, 1, 2):
+            with S._native.test_options(att_waves=waves, tiles_per_wg=tpw):
+                _, d = S.CrossAttentionCostVolume(D, mask, scale)(Ld, Rd, need_out=False)
+            disp_close(d, od, D)
+        with S._native.test_options(att_kernel=8, att_waves=waves):
+            _, d8 = S.CrossAttentionCostVolume(D, mask, scale)(Ld, Rd, need_out=False)
+        disp_close(d, d8.cpu().numpy(), D)
+    if not half:
+        L30, R30 = (L * 6).astype(np.float32), (R * 5).astype(np.float32)
+        _, od = oracle.cross_attention(L30, R30, None, D, "neginf", "mean")
+        with S._native.test_options(att_waves=waves):
+            _, d = S.CrossAttentionCostVolume(D, "neginf", "mean")(torch.from_numpy(L30).cuda(), torch.from_numpy(R30).cuda(), need_out=False)
+        disp_close(d, od, D)
+
+
 @pytest.mark.parametrize("shape", [(1, 256, 3, 240), (2, 32, 2, 152), (1, 64, 1, 36), (1, 40, 2, 312), (1, 8, 1, 128)])
 def test_allpairs_fp16_features(S, oracle, shape):
     """A8 on fp16 feature maps (what the fnet hands over under autocast; the reference widens with .float()): pyramid == oracle

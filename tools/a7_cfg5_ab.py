@@ -8,9 +8,16 @@ B, C, H, W, D = 4, 256, 96, 312, 64
 L = torch.randn(B, C, H, W, device="cuda"); R = torch.randn(B, C, H, W, device="cuda")
 att = S.CrossAttentionCostVolume(D, "neginf", "sqrt_c")
 gb = (2 * B * C * H * W * 4 + B * H * W * 4) / 1e9
-for opts in ({}, {"att_waves": 4}, {"att_waves": 6}, {"att_waves": 8}, {"tiles_per_wg": 1}, {"tiles_per_wg": 2}, {"tiles_per_wg": 3},
-             {"att_waves": 8, "tiles_per_wg": 1}, {"att_waves": 6, "tiles_per_wg": 1}):
+with torch.no_grad():
+    ref = att(L, R, need_out=False)
+for opts in ({}, {"att_waves": 4}, {"att_waves": 5}, {"att_waves": 8}, {"att_kernel": 17}, {"att_kernel": 17, "att_waves": 4},
+             {"att_kernel": 17, "att_waves": 5}, {"att_kernel": 17, "att_waves": 8}, {"att_waves": 4, "tiles_per_wg": 1},
+             {"att_kernel": 17, "att_waves": 4, "tiles_per_wg": 1}, {"att_kernel": 17, "att_waves": 5, "tiles_per_wg": 1}):
     with N.test_options(**opts), torch.no_grad():
+        got = att(L, R, need_out=False)
+        got = got[1] if isinstance(got, tuple) else got
+        r_ = ref[1] if isinstance(ref, tuple) else ref
+        print("max |diff to default| %.2e" % float((got - r_).abs().max()), end="  ")
         for _ in range(30): att(L, R, need_out=False)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
