@@ -5,21 +5,27 @@
 // coarse-to-fine start) is 245 MB = 31 us at 8 TB/s -- and the split-bf16 chunked kernel spent 79-85 us on it: three bf16
 // pieces per value to split, six piece products per k-step, 124 KB of LDS per 8-wave workgroup (one per CU), and at W = 312
 // its 256-query tiles leave 39 % of the query slots of a row empty.  The SIMDs, not the memory system, were the bound.  Here
-//   * a value is TWO fp16 pieces, x = hi + 2^-11 lo' (common.h; 22-23 significant bits, exact piece products), three piece
-//     products per k-step: hi hi into one fp32 accumulator, hi lo' + lo' hi into a second, scores = acc0 + 2^-11 acc1 -- a
-//     third of the splitting work and half the matrix instructions; fp16 features are their own single piece;
+//   * a value is TWO fp16 pieces of 16 x: 16 x = hi + lo, hi = fp16(16 x), lo = fp16(16 x - hi) -- UNSCALED low piece, so
+//     the three leading products hi hi + hi lo + lo hi accumulate in ONE fp32 accumulator (scores = acc / 256): a third of
+//     the splitting work (two v_fma_mix per value), half the matrix instructions, no second accumulator and no per-item
+//     fold of one (attention_f16.hip's scaled low piece lo' = 2^11 lo needs one: 30 vector instructions and a dependent
+//     matrix chain per item here, 23 of this launch's 62 us).  The price is in the small values: lo is a normal fp16 number
+//     for |x| >= 2^-7 (22 significant bits, as before); below that it rounds on the subnormal grid, an ABSOLUTE error of
+//     <= 2^-29 in x (the factor 16 buys four more binades of full precision) -- a score moves by <= C max|feature| 2^-28
+//     scale, far below what the softmax resolves.  fp16 features are their own single piece, exactly;
 //   * an item is 16 channels (one k-step of v_mfma_f32_32x32x16_f16) x all keys of the tile: two item buffers of a 5-wave
 //     workgroup are 49 KB, so THREE workgroups share a CU (15 waves instead of 8) and 160-query tiles fit W = 312 exactly;
 //   * item i + 1 is committed right behind the barrier that opens item i and item i + 2's loads are issued before item i's
 //     matrix work: a load has a whole iteration to land.
 // Softmax, masks and the disparity expectation are the chunked kernel's (two-pass over the band's score registers).
-// Range: |feature| < 65 504 (fp16), beyond it inf / NaN, never silently wrong (test hook att_kernel = 8: the bf16 form).
+// Range: |feature| < 4 094 for fp32 features (16 x in fp16), < 65 504 for fp16 ones; beyond it inf / NaN, never silently wrong
+// (test hook att_kernel = 8: the split-bf16 form, fp32's whole range).
 // Reference: the empty CrossAttentionCostVolume module's contract as SURVEY.md section 8 rows A7 / A8 fix it.
 #include "common.h"
 
 namespace {
 
-template <int NT, int NWV, typename TIN>
+template <int NT, int NWV, typename TIN, int DBG = 0>
 __global__ __launch_bounds__(NWV * 64, (NT <= 3 ? 4 : 2)) void cross_attention_disp_chunked16_kernel(
     const TIN *__restrict__ L, const TIN *__restrict__ R, float *__restrict__ disp, int C, int H, int W, int D, int mask_mode,
     float scale, int tiles_per_wg, int ntiles)
@@ -36,7 +42,7 @@ __global__ __launch_bounds__(NWV * 64, (NT <= 3 ? 4 : 2)) void cross_attention_d
     constexpr int QPR = NK / 4;                   // 16-byte quads per channel row of an item
     constexpr int NQ = (CH * QPR + NWV * 64 - 1) / (NWV * 64);   // quads per lane: the item's quads dealt over ALL lanes (every
                                                   // wave runs the same code: no wave-dependent row count, no branch around a load)
-    constexpr bool FOLD = true;                   // the cross-term accumulator is folded into acc0 per item (48 registers at NT = 3)
+    constexpr float PRE = NP == 2 ? 16.0f : 1.0f; // fp32 features are split as PRE x
     typedef typename Quad<TIN>::raw raw_t;
     extern __shared__ __attribute__((aligned(16))) _Float16 Im16c[];   // [2][NP][CH][RSE]
 
@@ -45,13 +51,29 @@ __global__ __launch_bounds__(NWV * 64, (NT <= 3 ? 4 : 2)) void cross_attention_d
     const unsigned HWu = (unsigned)H * (unsigned)W;  // launcher: 32 * H * W < 2^30 (32-bit byte offsets)
     const int nx = (W + TQW - 1) / TQW;
     const float sc2 = scale * 1.44269504088896340736f;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // two fp32 values -> packed fp16 pieces of PRE x: hi = fp16(PRE x), lo = fp16(PRE x - hi), each ONE mixed-precision FMA
+    // (fp32 arithmetic on the fp16 source hi, fp16 result into one half of the destination)
+    float pre = PRE;
+    asm volatile("" : "+v"(pre));
+    auto split2 = [&](float x0, float x1, unsigned &h, unsigned &l) {
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(pre));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(pre));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(pre), "v"(h));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(pre), "v"(h));
+    };
     // attention_f16.hip's image: channel row r starts 16 (r & 3) + 2 (r >> 2) dwords into its slot, so that the transposed
     // read of a 32-lane group (4 rows x 16 dwords) tiles the 64 banks
     auto row_off = [](int row) { return row * RSE + 32 * (row & 3) + 4 * (row >> 2); };
     const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
     const int k_off = (8 * half + tq) * RSE + 32 * tq + 8 * half + 16 * tg1 + 4 * tp;   // + 4 tt RSE + 4 tt + key-tile column
 
-    const int tile0 = blockIdx.x * tiles_per_wg;
+    // workgroups go to the 8 XCDs round-robin; XCD k takes the k-th eighth of the tiles, so the tiles of an image row (which
+    // share Dk of their keys) and of neighbouring rows meet in ONE L2
+    int wg = blockIdx.x;
+    if ((gridDim.x & 7) == 0) wg = (wg & 7) * (int)(gridDim.x >> 3) + (wg >> 3);
+    const int tile0 = wg * tiles_per_wg;
     const int tile_end = (tile0 + tiles_per_wg < ntiles) ? tile0 + tiles_per_wg : ntiles;
     if (tile0 >= tile_end) return;
     const int nck = (C + CH - 1) / CH;            // items per tile
@@ -71,15 +93,22 @@ __global__ __launch_bounds__(NWV * 64, (NT <= 3 ? 4 : 2)) void cross_attention_d
         g_off[k] = (int)(((unsigned)row * HWu + 4u * (unsigned)cq) * ES);
         g_kr[k] = 4 * cq | ((row < 31 ? row : 31) << 10) | ((row_off(row < CH ? row : 0) + 4 * cq) << 16);   // row >= CH: no quad
     }
-    int is_t = tile0, is_j = 0;
+    // Running item cursors, all scalar: the tile index is taken apart (two divisions) only when a tile BEGINS -- done per item,
+    // for the keys, the Q values and the tile being computed, that arithmetic was 230 scalar instructions per wave and item,
+    // and the CU's one scalar unit serves all its waves (15 here).
+    auto tile_row = [&](const TIN *T, int tl, int &x) -> const TIN * {
+        const int bh = tl / nx;
+        x = tl - bh * nx;
+        const int bb = bh / H, hh = bh - bb * H;
+        return T + ((size_t)bb * C * HWu + (size_t)hh * W);
+    };
+    int kx, qx;
+    const TIN *kp = tile_row(R, tile0, kx), *qp = tile_row(L, tile0, qx);
+    int kt = tile0, kj = 0, krows = C, qt = tile0, qj = 0, qrows = C;
     auto issue = [&](bool live) {
-        const int x = is_t % nx, bh = is_t / nx;
-        const int hh = bh % H, bb = bh / H;
-        const int kbase = x * TQW - Dk;
-        const int c0 = CH * is_j;
-        const int nrow = C - c0 < CH ? C - c0 : CH;
-        const TIN *base = R + (((size_t)bb * C + c0) * HWu + (size_t)hh * W);
-        const __amdgpu_buffer_rsrc_t rs = buffer_rsrc(base, live ? ((unsigned)(nrow - 1) * HWu + (unsigned)W) * ES : 0u);
+        const int kbase = kx * TQW - Dk;
+        const int nrow = krows < CH ? krows : CH;
+        const __amdgpu_buffer_rsrc_t rs = buffer_rsrc(kp, live ? ((unsigned)(nrow - 1) * HWu + (unsigned)W) * ES : 0u);
 #pragma unroll
         for (int k = 0; k < NQ; ++k) {
             int kr = g_kr[k];
@@ -87,24 +116,21 @@ __global__ __launch_bounds__(NWV * 64, (NT <= 3 ? 4 : 2)) void cross_attention_d
             const bool ok = (unsigned)(kbase + (kr & 0x3ff)) < (unsigned)W && ((kr >> 10) & 31) < nrow;
             rk[k] = BufLd<TIN>::quad(rs, ok ? g_off[k] + kbase * ES : -1, 0);
         }
-        if (++is_j == nck) is_j = 0, ++is_t;
+        kp += (size_t)CH * HWu, krows -= CH;
+        if (++kj == nck) kj = 0, krows = C, kp = tile_row(R, ++kt, kx);
     };
-    int iq_t = tile0, iq_j = 0;                   // the Q values of an item are issued one iteration later than its keys (below)
-    auto issue_q = [&](bool live) {
-        const int x = iq_t % nx, bh = iq_t / nx;
-        const int hh = bh % H, bb = bh / H;
-        const int w0 = x * TQW;
-        const int c0 = CH * iq_j;
-        const int nrow = C - c0 < CH ? C - c0 : CH;
-        const TIN *Lb = L + (((size_t)bb * C + c0) * HWu + (size_t)hh * W);
-        const __amdgpu_buffer_rsrc_t rq = buffer_rsrc(Lb, live ? ((unsigned)(nrow - 1) * HWu + (unsigned)W) * ES : 0u);
-        int vq = (int)(((unsigned)(8 * half) * HWu + (unsigned)(w0 + 32 * wave + l31)) * ES);
+    const int vq0 = (int)(((unsigned)(8 * half) * HWu + (unsigned)(32 * wave + l31)) * ES);
+    auto issue_q = [&](bool live) {               // the Q values of an item are issued one iteration later than its keys (below)
+        const int nrow = qrows < CH ? qrows : CH;
+        const __amdgpu_buffer_rsrc_t rq = buffer_rsrc(qp, live ? ((unsigned)(nrow - 1) * HWu + (unsigned)W) * ES : 0u);
+        int vq = vq0 + qx * TQW * ES;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {             // B operand: element i -> channel c0 + 8 half + i, query l31 of the wave
             qn[i] = BufLd<TIN>::one(rq, vq, 0);
             vq += (int)(HWu * ES);
         }
-        if (++iq_j == nck) iq_j = 0, ++iq_t;
+        qp += (size_t)CH * HWu, qrows -= CH;
+        if (++qj == nck) qj = 0, qrows = C, qp = tile_row(L, ++qt, qx);
     };
     auto commit = [&](int buf) {                  // registers -> piece images of buffer `buf`: one 8-byte store per quad, piece
         _Float16 *img = Im16c + buf * BSE;
@@ -116,12 +142,11 @@ __global__ __launch_bounds__(NWV * 64, (NT <= 3 ? 4 : 2)) void cross_attention_d
                 const int lo = (int)((unsigned)kr >> 16);
                 if constexpr (NP == 2) {
                     const f32x4 v = Quad<TIN>::widen(rk[k]);
-                    f16x2 a[2], b[2];
-                    split_pair_f16((f32x2){v[0], v[1]}, a);
-                    split_pair_f16((f32x2){v[2], v[3]}, b);
-#pragma unroll
-                    for (int p = 0; p < 2; ++p)
-                        *reinterpret_cast<f16x4 *>(&img[p * PSE + lo]) = __builtin_shufflevector(a[p], b[p], 0, 1, 2, 3);
+                    unsigned h0, l0, h1, l1;
+                    split2(v[0], v[1], h0, l0);
+                    split2(v[2], v[3], h1, l1);
+                    *reinterpret_cast<u32x2 *>(&img[lo]) = (u32x2){h0, h1};
+                    *reinterpret_cast<u32x2 *>(&img[PSE + lo]) = (u32x2){l0, l1};
                 } else {
                     *reinterpret_cast<raw_t *>(&img[lo]) = rk[k];
                 }
@@ -131,24 +156,22 @@ __global__ __launch_bounds__(NWV * 64, (NT <= 3 ? 4 : 2)) void cross_attention_d
     f16x8 qf[NP];
     auto take_q = [&]() {                         // the loaded Q values become the B operand (unscaled: the scale is on the scores)
         if constexpr (NP == 2) {
-            float xq[8];
+            unsigned hq[4], lq[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xq[j] = (float)qn[j];
-            split_oct_f16(xq, qf);
+            for (int j = 0; j < 4; ++j) split2((float)qn[2 * j], (float)qn[2 * j + 1], hq[j], lq[j]);
+            qf[0] = __builtin_bit_cast(f16x8, (u32x4){hq[0], hq[1], hq[2], hq[3]});
+            qf[NP - 1] = __builtin_bit_cast(f16x8, (u32x4){lq[0], lq[1], lq[2], lq[3]});
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) qf[0][j] = (_Float16)qn[j];
         }
     };
 
-    f32x16 ah[NT], al[FOLD ? 1 : NT];             // cleared here and at the end of every tile (not by a select per item)
+    f32x16 ah[NT];                                // cleared here and at the end of every tile (not by a select per item)
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            ah[t][r] = 0.0f;
-            if (!FOLD) al[t][r] = 0.0f;
-        }
+        for (int r = 0; r < 16; ++r) ah[t][r] = 0.0f;
     // One loop, no prologue copy of it: iteration -1 commits item 0, issues item 1 and takes item 0's Q values; keys are
     // always issued BEFORE the Q values of the same item (the wait counts of the loop are merged over every way into it).
     issue(true);
@@ -157,9 +180,8 @@ __global__ __launch_bounds__(NWV * 64, (NT <= 3 ? 4 : 2)) void cross_attention_d
     __builtin_amdgcn_sched_barrier(0);
 
     int ct = tile0, cj = 0;
+    int bh = tile0 / nx, w0 = (tile0 - bh * nx) * TQW;
     for (int it = -1; it < total; ++it) {
-        const int x = ct % nx, bh = ct / nx;
-        const int w0 = x * TQW;
         const int q = w0 + 32 * wave + l31;
         const bool wave_on = w0 + 32 * wave < W;  // wave-uniform
         const _Float16 *cur = Im16c + (it & 1) * BSE;
@@ -169,11 +191,11 @@ __global__ __launch_bounds__(NWV * 64, (NT <= 3 ? 4 : 2)) void cross_attention_d
         // values in front of the conversion of the previous ones, into other registers, and copied them into the loop-carried
         // ones behind a wait for everything in flight
         commit((it + 1) & 1);
-        issue(it + 2 < total);
-        if (wave_on && it >= 0) {   // ---------------- S^T += K_item Q_item^T: A = K through the transposed read, B = Q pieces
-#pragma unroll
+        issue(it + 2 < total && DBG != 3);
+        if (wave_on && it >= 0 && DBG != 1) {   // ---------------- S^T += K_item Q_item^T: A = K through the transposed read, B = Q pieces
+            f16x8 kf[NT][NP];                     // all fragments first, then the products tile-interleaved: three independent
+#pragma unroll                                    // accumulation chains instead of three dependent instructions per tile
             for (int t = 0; t < NT; ++t) {
-                f16x8 kf[NP];
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
 #pragma unroll
@@ -182,27 +204,17 @@ __global__ __launch_bounds__(NWV * 64, (NT <= 3 ? 4 : 2)) void cross_attention_d
                         const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)src);
                         const short tv[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) kf[p][4 * tt + e] = __builtin_bit_cast(_Float16, tv[e]);
+                        for (int e = 0; e < 4; ++e) kf[t][p][4 * tt + e] = __builtin_bit_cast(_Float16, tv[e]);
                     }
                 }
-                if constexpr (NP == 2) {
-                    if constexpr (FOLD) {
-                        f32x16 z;
+            }
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-                        f32x16 c = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[1], z, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qf[0], c, 0, 0, 0);
-                        ah[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[0], ah[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) ah[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t][0], qf[0], ah[t], 0, 0, 0);
+            if constexpr (NP == 2) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) ah[t][r] = fmaf(c[r], SPLIT16_LO_UNSCALE, ah[t][r]);
-                    } else {
-                        al[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[1], al[t], 0, 0, 0);
-                        ah[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[0], ah[t], 0, 0, 0);
-                        al[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qf[0], al[t], 0, 0, 0);
-                    }
-                } else {
-                    ah[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[0], ah[t], 0, 0, 0);
-                }
+                for (int t = 0; t < NT; ++t) ah[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t][0], qf[1], ah[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) ah[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[t][1], qf[0], ah[t], 0, 0, 0);
             }
         }
         if (cj == nck - 1 && wave_on && it >= 0) {  // ---- scores in exp2 units, masked softmax over the band, disparity expectation
@@ -213,9 +225,7 @@ __global__ __launch_bounds__(NWV * 64, (NT <= 3 ? 4 : 2)) void cross_attention_d
             for (int t = 0; t < NT; ++t) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float v = ah[t][r] * sc2;
-                    if constexpr (NP == 2 && !FOLD) v = fmaf(al[t][r], sc2 * SPLIT16_LO_UNSCALE, v);
-                    ah[t][r] = v;
+                    ah[t][r] *= sc2 * (1.0f / (PRE * PRE));
                 }
                 // element r of tile t: key row i_r + 4 half with i_r = (r & 3) + 8 (r >> 2), disparity d = cb - i_r
                 const int cb = Dk - 32 * t + l31 - 4 * half;
@@ -259,19 +269,19 @@ __global__ __launch_bounds__(NWV * 64, (NT <= 3 ? 4 : 2)) void cross_attention_d
 #pragma unroll
             for (int t = 0; t < NT; ++t)   // the next tile starts from zero (a wave that is off never accumulates)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    ah[t][r] = 0.0f;
-                    if (!FOLD) al[t][r] = 0.0f;
-                }
+                for (int r = 0; r < 16; ++r) ah[t][r] = 0.0f;
         }
         take_q();               // item it + 1's Q values (issued an iteration ago) -> B operand; item it + 2's take their registers
         __builtin_amdgcn_sched_barrier(0);
-        issue_q(it + 2 < total);
-        if (it >= 0 && ++cj == nck) cj = 0, ++ct;
+        issue_q(it + 2 < total && DBG != 3);
+        if (it >= 0 && ++cj == nck) {
+            cj = 0, ++ct;
+            bh = ct / nx, w0 = (ct - bh * nx) * TQW;
+        }
     }
 }
 
-template <int NT, int NWV, typename TIN>
+template <int NT, int NWV, typename TIN, int DBG = 0>
 int launch_disp_chunked16(const TIN *L, const TIN *R, float *disp, int B, int C, int H, int W, int D, int mask_mode, float sc,
                           hipStream_t st)
 {
@@ -279,7 +289,7 @@ int launch_disp_chunked16(const TIN *L, const TIN *R, float *disp, int B, int C,
     constexpr int NK = 32 * NWV + 32 * (NT - 1);
     constexpr int RSD = (NK / 2 + 54 + 63) / 64 * 64;
     const size_t lds = (size_t)2 * NP * 16 * (2 * RSD) * 2;
-    auto kern = cross_attention_disp_chunked16_kernel<NT, NWV, TIN>;
+    auto kern = cross_attention_disp_chunked16_kernel<NT, NWV, TIN, DBG>;
     static std::atomic<unsigned long long> lds_done{0};
     if (lds > 160 * 1024 || !lds_opt_in(kern, lds, lds_done)) return STEREO_ERR_UNSUPPORTED;
     const long long ntl = (long long)((W + 32 * NWV - 1) / (32 * NWV)) * H * B;
@@ -318,6 +328,10 @@ int stereo_cross_attention_disp_chunked16(const TIN *L, const TIN *R, float *dis
     (nwv == 8   ? launch_disp_chunked16<NTV, 8, TIN>(L, R, disp, B, C, H, W, D, mask_mode, sc, st)               \
      : nwv == 5 ? launch_disp_chunked16<NTV, 5, TIN>(L, R, disp, B, C, H, W, D, mask_mode, sc, st)               \
                 : launch_disp_chunked16<NTV, 4, TIN>(L, R, disp, B, C, H, W, D, mask_mode, sc, st))
+    if (nt <= 3 && nwv == 5 && sizeof(TIN) == 4 && stereo_opt(OPT_ATT_KERNEL) == 21)   // dev ablations (tools/a7_cfg5_trace.py)
+        return launch_disp_chunked16<3, 5, TIN, 1>(L, R, disp, B, C, H, W, D, mask_mode, sc, st);
+    if (nt <= 3 && nwv == 5 && sizeof(TIN) == 4 && stereo_opt(OPT_ATT_KERNEL) == 23)
+        return launch_disp_chunked16<3, 5, TIN, 3>(L, R, disp, B, C, H, W, D, mask_mode, sc, st);
     return nt <= 3 ? DC(3) : DC(5);
 #undef DC
 }

@@ -149,7 +149,8 @@ def test_cross_attention_disparity_only_chunked16(S, oracle, cfg, waves, half):
     """A7 without a value tensor at C > 32 (default route: attention_chunked16.hip, split-fp16 operands, 16-channel items) against
     the oracle: every workgroup shape, 1 / 2 / auto tiles per persistent workgroup (item pipeline across tile and row ends), both
     masks and scales, channel counts that are no multiple of 16, bands up to 128, fp32 and fp16 features; features of magnitude
-    ~30 (the split must hold fp32-level accuracy on peaked softmaxes); and agreement with the split-bf16 form (hook 8)."""
+    ~30 (the split must hold fp32-level accuracy on peaked softmaxes) and of very different magnitude left and right; and
+    agreement with the split-bf16 form (hook 8)."""
     B, C, H, W, D = cfg
     rng = np.random.default_rng(79)
     L = rng.standard_normal((B, C, H, W), dtype=np.float32)
@@ -172,6 +173,13 @@ def test_cross_attention_disparity_only_chunked16(S, oracle, cfg, waves, half):
         _, od = oracle.cross_attention(L30, R30, None, D, "neginf", "mean")
         with S._native.test_options(att_waves=waves):
             _, d = S.CrossAttentionCostVolume(D, "neginf", "mean")(torch.from_numpy(L30).cuda(), torch.from_numpy(R30).cuda(), need_out=False)
+        disp_close(d, od, D)
+        # small values on one side, large ones on the other (the low fp16 piece of a value below 2^-7 is subnormal: absolute, not
+        # relative, accuracy -- the scores must not notice)
+        Ls, Rb = (L * 0.004).astype(np.float32), (R * 250).astype(np.float32)
+        _, od = oracle.cross_attention(Ls, Rb, None, D, "neginf", "sqrt_c")
+        with S._native.test_options(att_waves=waves):
+            _, d = S.CrossAttentionCostVolume(D, "neginf", "sqrt_c")(torch.from_numpy(Ls).cuda(), torch.from_numpy(Rb).cuda(), need_out=False)
         disp_close(d, od, D)
 
 
