@@ -71,8 +71,9 @@ __global__ __launch_bounds__(NWV * 64, (NT <= 3 ? 4 : 2)) void cross_attention_d
 
     // workgroups go to the 8 XCDs round-robin; XCD k takes the k-th eighth of the tiles, so the tiles of an image row (which
     // share Dk of their keys) and of neighbouring rows meet in ONE L2
-    int wg = blockIdx.x;
-    if ((gridDim.x & 7) == 0) wg = (wg & 7) * (int)(gridDim.x >> 3) + (wg >> 3);
+    // (any grid size: XCD k owns ceil((G - k) / 8) workgroups, as one contiguous run)
+    const int gq = (int)(gridDim.x >> 3), gr = (int)(gridDim.x & 7), xcd = (int)(blockIdx.x & 7);
+    const int wg = xcd * gq + (xcd < gr ? xcd : gr) + (int)(blockIdx.x >> 3);
     const int tile0 = wg * tiles_per_wg;
     const int tile_end = (tile0 + tiles_per_wg < ntiles) ? tile0 + tiles_per_wg : ntiles;
     if (tile0 >= tile_end) return;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(NWV * 64, (NT <= 3 ? 4 : 2)) void cross_attention_d
 
 template <int NT, int NWV, typename TIN, int DBG = 0>
 int launch_disp_chunked16(const TIN *L, const TIN *R, float *disp, int B, int C, int H, int W, int D, int mask_mode, float sc,
-                          hipStream_t st)
+                          hipStream_t st, long long *cost = nullptr)
 {
     constexpr int NP = sizeof(TIN) == 4 ? 2 : 1;
     constexpr int NK = 32 * NWV + 32 * (NT - 1);
@@ -297,6 +298,10 @@ int launch_disp_chunked16(const TIN *L, const TIN *R, float *disp, int B, int C,
     static std::atomic<int> per_cu{0};
     const int resident = 256 * workgroups_per_cu(kern, NWV * 64, lds, per_cu);
     int tpw = (int)((ntl + resident - 1) / resident);
+    if (cost) {   // plan only: rounds of resident workgroups x workgroups sharing a CU x columns a tile stages (keys + queries)
+        *cost = (long long)tpw * (resident / 256) * (NK + 32 * NWV);
+        return STEREO_OK;
+    }
     if (stereo_opt(OPT_TILES_PER_WG) > 0) tpw = stereo_opt(OPT_TILES_PER_WG);
     const int nwg = (int)((ntl + tpw - 1) / tpw);
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(NWV * 64), lds, st, L, R, disp, C, H, W, D, mask_mode, sc, tpw, (int)ntl);
@@ -316,12 +321,24 @@ int stereo_cross_attention_disp_chunked16(const TIN *L, const TIN *R, float *dis
         (long long)32 * H * W >= (1LL << 30))
         return STEREO_ERR_UNSUPPORTED;
     const int nt = (D + 31) / 32 + 1;
-    // waves (32 queries each) per workgroup: the shape that wastes the fewest 32-query slots of a row -- 8, 5 or 4; ties go
-    // to the wider tile (less halo).  W = 312 -> 5 (160-query tiles), 240 -> 8.
-    const int qt = (W + 31) / 32;
-    int nwv = 8, best = ((qt + 7) / 8) * 8;
-    if (((qt + 4) / 5) * 5 < best) nwv = 5, best = ((qt + 4) / 5) * 5;
-    if (((qt + 3) / 4) * 4 < best) nwv = 4, best = ((qt + 3) / 4) * 4;
+    // waves (32 queries each) per workgroup -- 8, 5 or 4: the shape with the least staged columns per CU over the launch,
+    // rounds of resident workgroups x workgroups per CU x (keys + queries of a tile): that prices empty query slots of a
+    // row's last tile, the halo, and a last round that leaves CUs idle.  [4,256,96,312] D = 64 -> 5 (768 tiles = one round of
+    // 3 x 256 workgroups); [8,256,136,240] D = 48 -> 4.
+    int nwv = 0;
+    {
+        long long best = -1;
+        const int cand[3] = {8, 5, 4};
+        for (int i = 0; i < 3; ++i) {
+            long long c = -1;
+#define PLAN(NTV, NWVV) launch_disp_chunked16<NTV, NWVV, TIN>(L, R, disp, B, C, H, W, D, mask_mode, sc, st, &c)
+            const int rc = nt <= 3 ? (cand[i] == 8 ? PLAN(3, 8) : cand[i] == 5 ? PLAN(3, 5) : PLAN(3, 4))
+                                   : (cand[i] == 8 ? PLAN(5, 8) : cand[i] == 5 ? PLAN(5, 5) : PLAN(5, 4));
+#undef PLAN
+            if (rc == STEREO_OK && (best < 0 || c < best)) best = c, nwv = cand[i];
+        }
+        if (nwv == 0) return STEREO_ERR_UNSUPPORTED;
+    }
     if (stereo_opt(OPT_ATT_WAVES) == 4 || stereo_opt(OPT_ATT_WAVES) == 5 || stereo_opt(OPT_ATT_WAVES) == 8)
         nwv = stereo_opt(OPT_ATT_WAVES);  // test hook
 #define DC(NTV)                                                                                                  \

@@ -30,11 +30,43 @@ def timeit(fn, reps=10, warm=2):
     return e0.elapsed_time(e1) / reps
 
 
+def timeit_graph(fn, n=20, replays=10):
+    """For launches of < 0.1 ms: n calls captured in a graph and replayed (the Python loop of `timeit` cannot feed the queue that
+    fast and would report the host).  Not under rocprofv3 (graph capture under the profiler hung): --no-graph there."""
+    if NO_GRAPH:
+        return timeit(fn, 50, 10)
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    g, st = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        fn()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(n):
+                fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(replays):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (n * replays)
+
+
+NO_GRAPH = False
+
+
 def main():
+    global NO_GRAPH
     ap = argparse.ArgumentParser()
+    ap.add_argument("--no-graph", action="store_true", help="time small launches in a host loop (when run under rocprofv3)")
     ap.add_argument("--only", default=None)
     ap.add_argument("--reps", type=int, default=10)
     args = ap.parse_args()
+    NO_GRAPH = args.no_graph
     dev = "cuda"
     rows = []
 
@@ -144,8 +176,16 @@ def main():
                 add(f"A7_cross_attention {nm}", ms, gb, gf, bound="hbm",
                     note=f"channel-chunked item pipeline, split-bf16 form (v8); bytes = L + R + V + out; "
                          f"{gf / ms / MFMA_F32:.3f} of the f32 MFMA peak on fp32-equivalent algorithmic flops")
-                add(f"A7_cross_attention(disp only) {nm}", timeit(lambda: a2(q1, q2, need_out=False), 20, 3),
-                    (2 * bb * cc * hh * ww * 4 + bb * hh * ww * 4) / 1e9, gf / 2, bound="hbm")
+                with torch.no_grad():
+                    ms_d = timeit_graph(lambda: a2(q1, q2, need_out=False))
+                add(f"A7_cross_attention(disp only) {nm}", ms_d,
+                    (2 * bb * cc * hh * ww * 4 + bb * hh * ww * 4) / 1e9, gf / 2, bound="hbm",
+                    note="attention_chunked16.hip: split-fp16 operands, 16-channel items, one accumulator; timed as a replayed "
+                         "graph of 20 launches; bytes = L + R + disparity")
+                with S._native.test_options(att_kernel=8), torch.no_grad():
+                    add(f"A7_cross_attention(disp only) {nm} [split-bf16 chunked kernel, round 2's, for comparison]",
+                        timeit_graph(lambda: a2(q1, q2, need_out=False)),
+                        (2 * bb * cc * hh * ww * 4 + bb * hh * ww * 4) / 1e9, gf / 2, bound="hbm")
                 with S._native.test_options(att_kernel=4):
                     add(f"A7_cross_attention {nm} [two-pass fp32 kernel v4, for comparison]", timeit(lambda: a2(q1, q2), 20, 3),
                         gb, gf, bound="hbm")

@@ -19,8 +19,8 @@ for v in f32 f16; do
   python3 tools/pmc_summary.py $O/pmc_fetch_$v corr_volume_mfma group_mean lookup cross_attention > $O/fetch_$v.json
   python3 tools/pmc_summary.py $O/pmc_write_$v corr_volume_mfma group_mean lookup cross_attention > $O/write_$v.json
 done
-timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/pmc_mfma -o run --output-format csv -- python3 tools/kernel_bench.py --only A7_ > $O/pmc_mfma_a7.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/pmc_mfma8 -o run --output-format csv -- python3 tools/kernel_bench.py --only A8_ > $O/pmc_mfma_a8.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/pmc_mfma -o run --output-format csv -- python3 tools/kernel_bench.py --no-graph --only A7_ > $O/pmc_mfma_a7.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/pmc_mfma8 -o run --output-format csv -- python3 tools/kernel_bench.py --no-graph --only A8_ > $O/pmc_mfma_a8.log 2>&1
 timeout -k 10 600 python3 tools/kernel_bench.py > $O/kernel_bench.log 2>&1 && cp gpurun_out/kernel_bench.json $P/${R}_kernel_bench.json
 python3 - $O $R <<'PY'
 import json, sys
