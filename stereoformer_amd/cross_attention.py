@@ -57,7 +57,11 @@ class CrossAttentionCostVolume(nn.Module):
 
     forward(left_feature, right_feature[, value]) -> (out [B,Cv,H,W], disp [B,H,W]):
     per row, logits ``<L[:,w], R[:,w-d]> * scale`` for d in [0, max_disp), softmax over d,
-    ``disp = sum_d p_d d`` and ``out[:,w] = sum_d p_d V[:,w-d]`` (V defaults to the right features)."""
+    ``disp = sum_d p_d d`` and ``out[:,w] = sum_d p_d V[:,w-d]`` (V defaults to the right features).
+
+    Inference kernels are fp32-faithful on split fp16 / bf16 matrix-core operands; the default ones assume ``|feature| <
+    65504`` (C <= 32, V = right features) or ``< 4094`` (C > 32, ``need_out=False``, max_disp <= 128) and return inf / NaN
+    beyond that, never a silently wrong number (include/stereo_hip.h, A7)."""
 
     def __init__(self, max_disp, mask="zero", scale="sqrt_c"):
         super().__init__()
