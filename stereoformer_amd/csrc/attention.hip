@@ -724,7 +724,7 @@ extern "C" int stereo_cross_attention_f32(const float *left, const float *right,
             // of <= 128 (0.27 vs 0.38 ms at [8,256,136,240] D=48, 0.15 vs 0.19 ms at [4,256,96,312] D=64, 0.18 vs 0.29 ms
             // at D=128 against the two-pass kernel below); its fp32-MFMA form measured 5-10 % behind the two-pass kernel and
             // is reached through the test hook (6) only.  Hook 4 forces the two-pass kernel, 8 the split form.
-            if (forced == 6 || forced == 8 || forced >= 20 || (forced == 0 && nt <= 5 && C > 32)) {
+            if (forced == 6 || forced == 8 || (forced == 0 && nt <= 5 && C > 32)) {
                 const int rc6 = stereo_cross_attention_chunked<float>(left, right, value, out, disp, B, C, Cv, H, W, D,
                                                                       mask_mode, sc, forced != 6, as_stream(stream));
                 if (rc6 != STEREO_ERR_UNSUPPORTED) return rc6;

@@ -25,6 +25,7 @@
 
 namespace {
 
+// DBG (dev ablations, not instantiated in the library): 1 = no matrix work, 3 = every load through an empty resource.
 template <int NT, int NWV, typename TIN, int DBG = 0>
 __global__ __launch_bounds__(NWV * 64, (NT <= 3 ? 4 : 2)) void cross_attention_disp_chunked16_kernel(
     const TIN *__restrict__ L, const TIN *__restrict__ R, float *__restrict__ disp, int C, int H, int W, int D, int mask_mode,
@@ -345,10 +346,6 @@ int stereo_cross_attention_disp_chunked16(const TIN *L, const TIN *R, float *dis
     (nwv == 8   ? launch_disp_chunked16<NTV, 8, TIN>(L, R, disp, B, C, H, W, D, mask_mode, sc, st)               \
      : nwv == 5 ? launch_disp_chunked16<NTV, 5, TIN>(L, R, disp, B, C, H, W, D, mask_mode, sc, st)               \
                 : launch_disp_chunked16<NTV, 4, TIN>(L, R, disp, B, C, H, W, D, mask_mode, sc, st))
-    if (nt <= 3 && nwv == 5 && sizeof(TIN) == 4 && stereo_opt(OPT_ATT_KERNEL) == 21)   // dev ablations (tools/a7_cfg5_trace.py)
-        return launch_disp_chunked16<3, 5, TIN, 1>(L, R, disp, B, C, H, W, D, mask_mode, sc, st);
-    if (nt <= 3 && nwv == 5 && sizeof(TIN) == 4 && stereo_opt(OPT_ATT_KERNEL) == 23)
-        return launch_disp_chunked16<3, 5, TIN, 3>(L, R, disp, B, C, H, W, D, mask_mode, sc, st);
     return nt <= 3 ? DC(3) : DC(5);
 #undef DC
 }
