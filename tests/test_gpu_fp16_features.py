@@ -183,6 +183,29 @@ def test_cross_attention_disparity_only_chunked16(S, oracle, cfg, waves, half):
         disp_close(d, od, D)
 
 
+def test_cross_attention_disparity_only_chunked16_random_shapes(S, oracle):
+    """48 seeded random shapes of the disparity-only C > 32 route (C 33..300, W 36..900 in steps of 4, D 1..128, 1..3 rows, 1..2
+    pairs, fp32 / fp16 features, both masks, random tiles per workgroup) against the oracle."""
+    rng = np.random.default_rng(2025)
+    for i in range(48):
+        B, C, H = int(rng.integers(1, 3)), int(rng.integers(33, 301)), int(rng.integers(1, 4))
+        W, D = 4 * int(rng.integers(9, 226)), int(rng.integers(1, 129))
+        sr = float(rng.choice([0.05, 1.0, 8.0]))
+        sl = min(float(rng.choice([0.05, 1.0, 8.0])), 2.0 / sr)   # logits of a few hundred make the 1e-3 bar a test of fp32 itself
+        L = rng.standard_normal((B, C, H, W), dtype=np.float32) * sl
+        R = rng.standard_normal((B, C, H, W), dtype=np.float32) * sr
+        mask, scale = ("zero", "neginf")[i & 1], ("sqrt_c", "mean")[(i >> 1) & 1]
+        if i % 3 == 2:
+            (Ld, L), (Rd, R) = h16(L), h16(R)
+        else:
+            Ld, Rd = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+        _, od = oracle.cross_attention(L, R, None, D, mask, scale)
+        with S._native.test_options(tiles_per_wg=int(rng.integers(0, 4)), att_waves=int(rng.choice([0, 0, 4, 5, 8]))):
+            _, d = S.CrossAttentionCostVolume(D, mask, scale)(Ld, Rd, need_out=False)
+        assert torch.isfinite(d).all(), (i, B, C, H, W, D)
+        disp_close(d, od, D)
+
+
 @pytest.mark.parametrize("shape", [(1, 256, 3, 240), (2, 32, 2, 152), (1, 64, 1, 36), (1, 40, 2, 312), (1, 8, 1, 128)])
 def test_allpairs_fp16_features(S, oracle, shape):
     """A8 on fp16 feature maps (what the fnet hands over under autocast; the reference widens with .float()): pyramid == oracle
