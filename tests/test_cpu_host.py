@@ -245,6 +245,33 @@ def test_hbm_place_keeps_the_fastest_candidate_and_frees_the_rest():
     assert best.i == 2 and len(rep["probe_ms"]) == 3          # stopped at the first good-enough candidate
 
 
+def test_hbm_window_search_is_coarse_then_fine():
+    """hbm._search_windows (the window order of place_in_arena / place_in_mapped_arena): every coarse_steps-th window first, then
+    the neighbours of the fastest coarse one; a window within good_enough_ms ends the search; no window is timed twice."""
+    from stereoformer_amd import hbm
+    # the launch time over the window offset as measured on the part: plateaus with smooth flanks (profiles/r03_place_window_probe.txt)
+    curve = [5.4] * 20 + [5.1, 4.9, 4.75, 4.7, 4.65, 4.68, 4.7, 4.78] + [4.8] * 10 + [5.5] * 12
+    seen = []
+
+    def measure(k):
+        assert k not in seen
+        seen.append(k)
+        return curve[k]
+
+    times = hbm._search_windows(len(curve) - 1, 4, measure, None)
+    assert seen[:13] == list(range(0, 50, 4))                       # coarse pass over the whole span
+    assert min(times, key=times.get) == 24 and times[24] == 4.65    # the refinement finds the bottom of the plateau
+    assert set(seen[13:]) == {21, 22, 23, 25, 26, 27}
+    seen.clear()
+    times = hbm._search_windows(len(curve) - 1, 4, measure, 4.72)
+    assert seen == [0, 4, 8, 12, 16, 20, 24]                        # 4.65 <= 4.72: stop at the first good-enough window
+    seen.clear()
+    times = hbm._search_windows(3, 8, measure, None)                # span shorter than one coarse step
+    assert sorted(times) == [0, 1, 2, 3]
+    with pytest.raises(RuntimeError):
+        hbm.MappedArena(1 << 20, 4)                                  # no HIP device here: loud, no CPU stand-in
+
+
 def test_conv_split_is_never_taken_on_cpu_tensors():
     """The update blocks run on CPU tensors in bench.py's cpu_baseline leg (custom ops routed to the oracle there): the HIP
     convolution kernels must not be selected for them, and asking for them directly fails loudly."""
