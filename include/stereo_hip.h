@@ -136,7 +136,8 @@ int stereo_guidance_inputs_nhwc_f32(const float *vol, const float *disp, const f
 /* A8  CorrBlock1D.__init__ + .corr  models/IterativeLocalCostVolume/corr/corr.py:55-76,103-111
  *     fmap1 [B,C,H,W1], fmap2 [B,C,H,W2] -> levels[i] [B*H*W1, W2>>i], i = 0..num_levels
  *     (levels = HOST array of num_levels+1 device pointers; the reference builds
- *     num_levels+1 pyramid entries) */
+ *     num_levels+1 pyramid entries).  fp32-faithful on split fp16 matrix-core operands on the aligned path (W1, W2 % 4 == 0):
+ *     |feature| < 4 094 there (inf / NaN beyond, never silently wrong). */
 int stereo_allpairs_pyramid_f32(const float *fmap1, const float *fmap2, float *const *levels,
                                 int B, int C, int H, int W1, int W2, int num_levels, void *stream);
 

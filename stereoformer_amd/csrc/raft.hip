@@ -86,7 +86,40 @@ struct PyrOut {
 // per output, 32-bit offsets from a workgroup-uniform base, no bounds tests on interior tiles.  (Pooling the pyramid
 // levels in this epilogue with cross-lane adds was bit-identical but slower than one streaming pass over level 0:
 // 0.631 vs 0.583 ms at [8,256,136,240].)
-template <typename TIN>
+// eight fp32 values -> MFMA operand pieces of 16 x (NP = 2: hi, lo unscaled -- two mixed-precision FMAs per value; NP = 1:
+// the values are fp16 numbers already)
+template <int NP>
+__device__ __forceinline__ void ap_split(const float *x, f16x8 *p)
+{
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    if constexpr (NP == 2) {
+        float pre = 16.0f;
+        asm volatile("" : "+v"(pre));
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h[j]) : "v"(x[2 * j]), "v"(pre));
+            asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h[j]) : "v"(x[2 * j + 1]), "v"(pre));
+            asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l[j]) : "v"(x[2 * j]), "v"(pre), "v"(h[j]));
+            asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l[j]) : "v"(x[2 * j + 1]), "v"(pre), "v"(h[j]));
+        }
+        p[0] = __builtin_bit_cast(f16x8, (u32x4v){h[0], h[1], h[2], h[3]});
+        p[1] = __builtin_bit_cast(f16x8, (u32x4v){l[0], l[1], l[2], l[3]});
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[0][j] = (_Float16)x[j];
+    }
+}
+
+// F16P (round 3, default): the matrix phase on the fp16 matrix cores with split operands.  A chunk of 16 channels is ONE
+// k-step of v_mfma_f32_32x32x16_f16: a lane reads its 8 channels of a row / column block from the fp32 image (the same
+// conflict-free ds_read_b32, lanes along w), splits them in registers into two fp16 pieces of 16 x -- hi = fp16(16 x),
+// lo = fp16(16 x - hi), two v_fma_mix per value (attention_chunked16.hip's arithmetic: the low piece is a normal fp16 number
+// for |x| >= 2^-7, below that its absolute error is <= 2^-29) -- and the three leading piece products of each of the four
+// output blocks go to its ONE accumulator: 12 matrix instructions of 32 cycles per chunk instead of 32 of 64 (fp16 features:
+// one piece, exactly, 4 instructions).  The 1 / 256 of the two pre-scales rides on the 1 / sqrt(C) of the epilogue (exact).
+// Range: |feature| < 4 094 (fp32 features), inf / NaN beyond, never silently wrong; test option corr_f16p = 0: f32 MFMA.
+template <typename TIN, bool F16P>
 __global__ __launch_bounds__(256) void allpairs_lds_kernel(const TIN *__restrict__ f1, const TIN *__restrict__ f2,
                                                            float *__restrict__ out, int C, int H, int W1, int W2,
                                                            float sqrt_c, float inv_sqrt_c, int mul_exact)
@@ -145,15 +178,39 @@ __global__ __launch_bounds__(256) void allpairs_lds_kernel(const TIN *__restrict
         const int buf = ck & 1;
         if (ck + 1 < nchunk) commit(buf ^ 1);           // its last readers passed the previous barrier
         if (ck + 2 < nchunk) issue((ck + 2) * AP_KC);   // in flight during this chunk's MFMAs
+        if constexpr (F16P) {
+            constexpr int NP = sizeof(TIN) == 4 ? 2 : 1;
+            f16x8 pa_[2][NP], pb_[2][NP];            // [32-wide block][piece]: element j = channel 8 half + j of the chunk
 #pragma unroll
-        for (int s = 0; s < AP_KC / 2; ++s) {
-            const int c = 2 * s + half;
-            const float a0 = As[buf][c][mw + l31], a1 = As[buf][c][mw + 32 + l31];
-            const float b0 = Bs[buf][c][nw + l31], b1 = Bs[buf][c][nw + 32 + l31];
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+            for (int blk = 0; blk < 2; ++blk) {
+                float xa[8], xb[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    xa[j] = As[buf][8 * half + j][mw + 32 * blk + l31];
+                    xb[j] = Bs[buf][8 * half + j][nw + 32 * blk + l31];
+                }
+                ap_split<NP>(xa, pa_[blk]);
+                ap_split<NP>(xb, pb_[blk]);
+            }
+#pragma unroll
+            for (int p = 0; p < (NP == 2 ? 3 : 1); ++p) {   // hi hi, hi lo, lo hi -- block-interleaved: four independent chains
+                const int ia = p == 2 ? NP - 1 : 0, ib = p == 1 ? NP - 1 : 0;
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa_[0][ia], pb_[0][ib], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa_[0][ia], pb_[1][ib], acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa_[1][ia], pb_[0][ib], acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa_[1][ia], pb_[1][ib], acc11, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < AP_KC / 2; ++s) {
+                const int c = 2 * s + half;
+                const float a0 = As[buf][c][mw + l31], a1 = As[buf][c][mw + 32 + l31];
+                const float b0 = Bs[buf][c][nw + l31], b1 = Bs[buf][c][nw + 32 + l31];
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -464,8 +521,14 @@ static int allpairs_fast(const TIN *fmap1, const TIN *fmap2, float *level0, int 
     int e2 = 0;
     const int mul_exact = frexpf(sq, &e2) == 0.5f ? 1 : 0;  // sqrt(C) a power of two: x * (1/sqrt) == x / sqrt
     dim3 grid((W2 + 127) / 128, (W1 + 127) / 128, (unsigned)(B * H));
-    hipLaunchKernelGGL(allpairs_lds_kernel<TIN>, grid, dim3(256), 0, st, fmap1, fmap2, level0, C, H, W1, W2, sq, 1.0f / sq,
-                       mul_exact);
+    if (stereo_opt(OPT_CORR_F16P)) {   // (the two pre-scales of 16: powers of two, folded into the epilogue's scale exactly)
+        constexpr float U = sizeof(TIN) == 4 ? 256.0f : 1.0f;
+        hipLaunchKernelGGL((allpairs_lds_kernel<TIN, true>), grid, dim3(256), 0, st, fmap1, fmap2, level0, C, H, W1, W2, sq * U,
+                           1.0f / (sq * U), mul_exact);
+    } else {
+        hipLaunchKernelGGL((allpairs_lds_kernel<TIN, false>), grid, dim3(256), 0, st, fmap1, fmap2, level0, C, H, W1, W2, sq,
+                           1.0f / sq, mul_exact);
+    }
     STEREO_LAUNCH_CHECK();
     return STEREO_OK;
 }

@@ -340,14 +340,20 @@ def test_raft_corr_golden(S, golden):
         S.AlternateCorrBlock(f1, f2)
 
 
-@pytest.mark.parametrize("shape", [(1, 256, 3, 240), (2, 31, 2, 150), (1, 64, 1, 33), (1, 40, 2, 312), (1, 7, 1, 128)])
-def test_allpairs_vs_oracle(S, oracle, shape):
+@pytest.mark.parametrize("shape", [(1, 256, 3, 240), (2, 31, 2, 150), (1, 64, 1, 33), (1, 40, 2, 312), (1, 7, 1, 128), (1, 100, 2, 260)])
+@pytest.mark.parametrize("f16p", [1, 0])
+def test_allpairs_vs_oracle(S, oracle, shape, f16p):
+    """A8 with the split-fp16 matrix phase (default) and the f32 MFMA (test option), incl. features of very different magnitude
+    left and right (the low fp16 piece of a small value is subnormal: absolute accuracy)."""
     B, C, H, W = shape
     rng = np.random.default_rng(19)
     f1 = rng.standard_normal(shape, dtype=np.float32)
     f2 = rng.standard_normal(shape, dtype=np.float32)
+    with S._native.test_options(corr_f16p=f16p):
+        blk = S.CorrBlock1D(dev(f1), dev(f2), num_levels=4, radius=4)
+        small = S.CorrBlock1D.corr(dev(f1 * 0.003), dev(f2 * 300)).reshape(B, H, W, W)
     ap = oracle.allpairs_corr(f1, f2)
-    blk = S.CorrBlock1D(dev(f1), dev(f2), num_levels=4, radius=4)
+    close(small, oracle.allpairs_corr((f1 * 0.003).astype(np.float32), (f2 * 300).astype(np.float32)), rtol=1e-5, atol=5e-5)
     pyr = oracle.corr_pyramid(ap, 4)
     for i in range(5):
         close(blk.corr_pyramid[i].reshape(pyr[i].shape), pyr[i], rtol=1e-5, atol=5e-5)
