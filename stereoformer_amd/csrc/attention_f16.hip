@@ -23,7 +23,7 @@
 namespace {
 
 template <int NT, int NWV, typename TIN>
-__global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const TIN *__restrict__ L, const TIN *__restrict__ R,
+__global__ __launch_bounds__(NWV * 64, ((NWV == 8 && NT >= 6) ? 4 : 1)) void cross_attention_split16_kernel(const TIN *__restrict__ L, const TIN *__restrict__ R,
                                                                            float *__restrict__ out, float *__restrict__ disp,
                                                                            int C, int H, int W, int D, int mask_mode,
                                                                            float scale, int tiles_per_wg, int ntiles)
@@ -53,6 +53,22 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
     const unsigned HWu = (unsigned)H * (unsigned)W;  // launcher: 32 * H * W < 2^30 (32-bit byte offsets)
     const int nx = (W + TQW - 1) / TQW;
     const float sc2 = scale * 1.44269504088896340736f;
+    // One-accumulator arithmetic (end of round 3, from attention_chunked16.hip): a feature value is two fp16 pieces of PRE x with
+    // an UNSCALED low piece -- hi = fp16(PRE x), lo = fp16(PRE x - hi), two v_fma_mix per value -- so that hi hi + hi lo + lo hi
+    // accumulate in ONE fp32 accumulator (no second accumulator, no zero accumulator, no combine per tile); lo is a normal fp16
+    // number for |x| >= 2^-7 and rounds on the subnormal grid below (absolute error <= 2^-29 in x).  The probabilities are
+    // split the same way as PP p (PP = 2^10: normal low piece down to p = 2^-17).
+    constexpr float PRE = NP == 2 ? 16.0f : 1.0f, PP = 1024.0f;
+    float pre = PRE;
+    asm volatile("" : "+v"(pre));
+    auto split2 = [&](float x0, float x1, unsigned &h, unsigned &l) {
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(pre));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(pre));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(pre), "v"(h));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(pre), "v"(h));
+    };
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
     const int dl = l31 - 4 * half;
     auto row_off = [](int row) { return row * RSE + 32 * (row & 3) + 4 * (row >> 2); };   // elements
     // transposed K reads: lane 4 q + p of its 16-lane group supplies row (channel) R0 + q, keys K0 + 4 p .. ; R0 = 8 half + 16 s
@@ -68,11 +84,18 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
     // Loads go through buffer resources (common.h): a key outside [0, W) is an out-of-range byte offset and reads 0 -- the zero
     // padding of the band and what ZERO-mask mode wants for the values; channel rows >= C get an empty resource, Q channels
     // >= C fall past the end of theirs.  No per-lane bound selects.
-    typename Quad<TIN>::raw rk[RMAX][NPASS];
+    typename Quad<TIN>::raw rk[RMAX][RING ? 1 : NPASS];   // RING: a tile only ever prefetches its own 256 keys (below)
     TIN qn[16];
     constexpr int ES = (int)sizeof(TIN);
     bool incr = false;   // the prefetched tile continues the current one's row: only its 256 new keys are in `rk`
     int rbase = 0;       // ring column of the current image's first key
+    // RING staging: every tile loads exactly its own 256 keys [w0, w0 + 256) -- one quad per lane and row.  A tile that
+    // continues its predecessor's row (incr) appends them to the ring; any other tile restarts the ring at column 0 with its
+    // Dk halo keys in columns 0 .. Dk - 1 and its own keys behind them.  The halo of a row's FIRST tile lies left of the image
+    // (zeros, written at commit); only the first tile of a workgroup's run can start mid-row, and its halo is loaded and
+    // committed synchronously by `stage_halo` before the loop.  (Until the end of round 3 a restart prefetched all 448 keys:
+    // 16 more registers held for the whole kernel, the difference between one and two workgroups per CU.)
+    bool halo_staged = false;
     auto issue = [&](int tl, bool first) {
         const int x = tl % nx, bh = tl / nx;
         const int hh = bh % H, bb = bh / H;
@@ -81,10 +104,8 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
         const TIN *Lb = L + ((size_t)bb * C * HWu + (size_t)hh * W);
         incr = RING && !first && x > 0;
         int voff[NPASS];
-        if (RING && incr) {
-            voff[0] = (w0 + 4 * lane) * ES;      // keys w0 .. w0 + 255: one quad per lane and row
-#pragma unroll
-            for (int pp = 1; pp < NPASS; ++pp) voff[pp] = -1;
+        if constexpr (RING) {
+            voff[0] = (w0 + 4 * lane) * ES;      // keys w0 .. w0 + 255
         } else {
 #pragma unroll
             for (int pp = 0; pp < NPASS; ++pp) voff[pp] = (lane + 64 * pp < NK / 4) ? (kbase + 4 * (lane + 64 * pp)) * ES : -1;
@@ -94,7 +115,7 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
             const int row = wave + rr * NWV;
             const __amdgpu_buffer_rsrc_t rs = buffer_rsrc(Rb + (size_t)row * HWu, row < C ? (unsigned)W * ES : 0u);
             rk[rr][0] = BufLd<TIN>::quad(rs, voff[0], 0);
-            if (!(RING && incr)) {
+            if constexpr (!RING) {
 #pragma unroll
                 for (int pp = 1; pp < NPASS; ++pp) rk[rr][pp] = BufLd<TIN>::quad(rs, voff[pp], 0);
             }
@@ -107,54 +128,76 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
             vq += (int)((i == 7 ? 9u : 1u) * HWu * ES);
         }
     };
-    auto commit = [&]() {  // registers -> the f16 piece images: one 8-byte store per quad and piece
-        // ring: a continuing tile's 256 keys follow the current window (columns rbase + NK ..., modulo 512) and the window
-        // moves on by 256; a full staging restarts the ring at column 0
-        const bool inc = RING && incr;
-        int c0 = 4 * lane;
-        if constexpr (RING) {
-            if (inc) c0 = (rbase + NK + 4 * lane) & (RCOLS - 1);
-            rbase = inc ? (rbase + 256) & (RCOLS - 1) : 0;
+    auto put_quad = [&](const typename Quad<TIN>::raw &q, int off) {   // one quad -> the piece image(s) at element offset `off`
+        if constexpr (NP == 2) {
+            const f32x4 v = Quad<TIN>::widen(q);
+            unsigned h0, l0, h1, l1;
+            split2(v[0], v[1], h0, l0);
+            split2(v[2], v[3], h1, l1);
+            *reinterpret_cast<u32x2v *>(&Im16[off]) = (u32x2v){h0, h1};
+            *reinterpret_cast<u32x2v *>(&Im16[PSE + off]) = (u32x2v){l0, l1};
+        } else {
+            *reinterpret_cast<typename Quad<TIN>::raw *>(&Im16[off]) = q;
         }
+    };
+    auto commit = [&]() {  // registers -> the f16 piece images: one 8-byte store per quad and piece
+        if constexpr (RING) {
+            // a continuing tile's 256 keys follow the current window (columns rbase + NK ..., modulo 512) and the window moves on
+            // by 256; a restart puts them behind the Dk halo columns and the ring at column 0
+            const int c0 = incr ? (rbase + NK + 4 * lane) & (RCOLS - 1) : Dk + 4 * lane;
+            const bool zero_halo = !incr && !halo_staged && lane < Dk / 4;
+            rbase = incr ? (rbase + 256) & (RCOLS - 1) : 0;
+            halo_staged = false;
 #pragma unroll
-        for (int rr = 0; rr < RMAX; ++rr) {
-            const int row = wave + rr * NWV;
-            if (row < 32) {
-                const int ro = row_off(row);
+            for (int rr = 0; rr < RMAX; ++rr) {
+                const int row = wave + rr * NWV;
+                if (row < 32) {
+                    const int ro = row_off(row);
+                    put_quad(rk[rr][0], ro + c0);
+                    if (zero_halo) {
 #pragma unroll
-                for (int pp = 0; pp < NPASS; ++pp) {
-                    if (lane + 64 * pp < NK / 4 && (pp == 0 || !inc)) {
-                        const int colq = pp == 0 ? c0 : 4 * (lane + 64 * pp);
-                        if constexpr (NP == 2) {
-                            const f32x4 v = Quad<TIN>::widen(rk[rr][pp]);
-                            f16x2 a[2], b[2];
-                            split_pair_f16((f32x2){v[0], v[1]}, a);
-                            split_pair_f16((f32x2){v[2], v[3]}, b);
+                        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2v *>(&Im16[p * PSE + ro + 4 * lane]) = (u32x2v){0u, 0u};
+                    }
+                }
+            }
+        } else {
 #pragma unroll
-                            for (int p = 0; p < 2; ++p)
-                                *reinterpret_cast<f16x4 *>(&Im16[p * PSE + ro + colq]) =
-                                    __builtin_shufflevector(a[p], b[p], 0, 1, 2, 3);
-                        } else {
-                            *reinterpret_cast<typename Quad<TIN>::raw *>(&Im16[ro + colq]) = rk[rr][pp];
-                        }
+            for (int rr = 0; rr < RMAX; ++rr) {
+                const int row = wave + rr * NWV;
+                if (row < 32) {
+                    const int ro = row_off(row);
+#pragma unroll
+                    for (int pp = 0; pp < NPASS; ++pp) {
+                        if (lane + 64 * pp < NK / 4) put_quad(rk[rr][pp], ro + 4 * (lane + 64 * pp));
                     }
                 }
             }
         }
     };
+    auto stage_halo = [&](int tl) {   // RING, first tile of the run, mid-row: keys [w0 - Dk, w0) -> columns 0 .. Dk - 1, synchronously
+        const int x = tl % nx, bh = tl / nx;
+        const int hh = bh % H, bb = bh / H;
+        if (x == 0) return;           // (left of the image: commit writes zeros)
+        const TIN *Rb = R + ((size_t)bb * C * HWu + (size_t)hh * W);
+        const int voff = lane < Dk / 4 ? (x * TQW - Dk + 4 * lane) * ES : -1;
+#pragma unroll
+        for (int rr = 0; rr < RMAX; ++rr) {
+            const int row = wave + rr * NWV;
+            const __amdgpu_buffer_rsrc_t rs = buffer_rsrc(Rb + (size_t)row * HWu, row < C ? (unsigned)W * ES : 0u);
+            rk[rr][0] = BufLd<TIN>::quad(rs, voff, 0);
+        }
+#pragma unroll
+        for (int rr = 0; rr < RMAX; ++rr) {
+            const int row = wave + rr * NWV;
+            if (row < 32 && lane < Dk / 4) put_quad(rk[rr][0], row_off(row) + 4 * lane);
+        }
+        halo_staged = true;
+    };
 
+    if constexpr (RING) stage_halo(tile);
     issue(tile, true);
     commit();
     f16x8 qf[2][NP];
-    // a zero accumulator kept in registers for the whole kernel: the first product of every chain takes it as its C operand
-    // (clearing two fresh accumulators per key tile was 32 v_mov per tile -- a seventh of the loop's vector instructions);
-    // opaque to the compiler, which would otherwise rematerialise the zeros in front of each use
-    // (fp32 features only: with fp16 features the kernel fits 128 registers -- two workgroups per CU -- and 16 more would
-    // cost that; there the single accumulator is cleared per tile)
-    f32x16 zacc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zacc[r] = 0.0f;
-    if constexpr (NP == 2) asm volatile("" : "+v"(zacc));
     for (;;) {
         const int x = tile % nx, bh = tile / nx;
         const int w0 = x * TQW, kbase = w0 - Dk;
@@ -162,10 +205,11 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             if constexpr (NP == 2) {
-                float xq[8];
+                unsigned hq[4], lq[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xq[j] = (float)qn[8 * s + j];
-                split_oct_f16(xq, qf[s]);
+                for (int j = 0; j < 4; ++j) split2((float)qn[8 * s + 2 * j], (float)qn[8 * s + 2 * j + 1], hq[j], lq[j]);
+                qf[s][0] = __builtin_bit_cast(f16x8, (u32x4w){hq[0], hq[1], hq[2], hq[3]});
+                qf[s][1] = __builtin_bit_cast(f16x8, (u32x4w){lq[0], lq[1], lq[2], lq[3]});
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) qf[s][0][j] = (_Float16)qn[8 * s + j];
@@ -178,12 +222,12 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
         if (w0 + 32 * wave < W) {  // wave-uniform
             const bool neg_left = mask_mode == STEREO_MASK_NEGINF && kbase < 0;
             float m = -INFINITY, ssum = 0.0f, esc = 0.0f;
-            f32x16 oh, ol;
+            f32x16 oh;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oh[r] = 0.0f, ol[r] = 0.0f;
+            for (int r = 0; r < 16; ++r) oh[r] = 0.0f;
 #pragma unroll 1
             for (int t = NT - 1; t >= 0; --t) {
-                f32x16 ah, al;
+                f32x16 ah;
                 int ct = 32 * (wave + t);    // column of key tile wave + t of the window (wave-uniform)
                 if constexpr (RING) ct = (ct + rbase) & (RCOLS - 1);
                 // ---- S^T tile = K_t Q^T: A = K through the transposed read, B = Q pieces
@@ -201,22 +245,21 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
                             for (int e = 0; e < 4; ++e) kf[p][4 * tt + e] = __builtin_bit_cast(_Float16, tv[e]);
                         }
                     }
+                    const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[s][0], s == 0 ? z16 : ah, 0, 0, 0);   // (constant 0: an inline operand)
                     if constexpr (NP == 2) {
-                        al = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[s][1], s == 0 ? zacc : al, 0, 0, 0);
-                        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[s][0], s == 0 ? zacc : ah, 0, 0, 0);
-                        al = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qf[s][0], al, 0, 0, 0);
-                    } else {
-                        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[s][0], s == 0 ? zacc : ah, 0, 0, 0);
+                        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[s][1], ah, 0, 0, 0);
+                        ah = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qf[s][0], ah, 0, 0, 0);
                     }
                 }
-                // scores in exp2 units: (acc0 + 2^-11 acc1) x scale x log2 e
+                // scores in exp2 units: acc x scale x log2 e / PRE^2
                 f32x16 a;
-                {   // (packed f32: one v_pk_mul_f32 + one v_pk_fma_f32 per register pair)
-                    const f32x2 sh2 = {sc2, sc2}, sl2 = {sc2 * SPLIT16_LO_UNSCALE, sc2 * SPLIT16_LO_UNSCALE};
+                {   // (packed f32: one v_pk_mul_f32 per register pair)
+                    const float su = sc2 * (1.0f / (PRE * PRE));
+                    const f32x2 sh2 = {su, su};
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        f32x2 v = (f32x2){ah[2 * k], ah[2 * k + 1]} * sh2;
-                        if constexpr (NP == 2) v = __builtin_elementwise_fma((f32x2){al[2 * k], al[2 * k + 1]}, sl2, v);
+                        const f32x2 v = (f32x2){ah[2 * k], ah[2 * k + 1]} * sh2;
                         a[2 * k] = v[0];
                         a[2 * k + 1] = v[1];
                     }
@@ -267,7 +310,7 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
                 if (out) {
                     if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {  // wave-uniform: the running maximum rarely moves after the nearest tiles
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) oh[r] *= alpha, ol[r] *= alpha;
+                        for (int r = 0; r < 16; ++r) oh[r] *= alpha;
                     }
                     // ---- O^T += V_t^T P: A = V^T rows from the image (accumulator key order), B = P as hi + 2^-11 lo'
 #pragma unroll
@@ -281,18 +324,18 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
                         {
                             typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
                             u32x4v hv, lv;
-                            const float c2048 = SPLIT16_LO_SCALE;
+                            float cpp = PP;
+                            asm volatile("" : "+v"(cpp));
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const f16x2 h = __builtin_convertvector((f32x2){a[8 * s + 2 * e], a[8 * s + 2 * e + 1]}, f16x2);
-                                const f16x2 h2 = h * (f16x2){(_Float16)2048.0f, (_Float16)2048.0f};
-                                const unsigned h2u = __builtin_bit_cast(unsigned, h2);
-                                unsigned lu;
-                                asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lu) : "v"(a[8 * s + 2 * e]), "v"(c2048), "v"(h2u));
+                            for (int e = 0; e < 4; ++e) {   // hi = fp16(PP p), lo = fp16(PP p - hi): four mixed-precision FMAs per pair
+                                unsigned hu, lu;
+                                asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hu) : "v"(a[8 * s + 2 * e]), "v"(cpp));
+                                asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hu) : "v"(a[8 * s + 2 * e + 1]), "v"(cpp));
+                                asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lu) : "v"(a[8 * s + 2 * e]), "v"(cpp), "v"(hu));
                                 asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
                                     : "+v"(lu)
-                                    : "v"(a[8 * s + 2 * e + 1]), "v"(c2048), "v"(h2u));
-                                hv[e] = __builtin_bit_cast(unsigned, h);
+                                    : "v"(a[8 * s + 2 * e + 1]), "v"(cpp), "v"(hu));
+                                hv[e] = hu;
                                 lv[e] = lu;
                             }
                             pq[0] = __builtin_bit_cast(f16x8, hv), pq[1] = __builtin_bit_cast(f16x8, lv);
@@ -305,9 +348,9 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
 #pragma unroll
                             for (int e = 0; e < 4; ++e) vf[p][e] = lo[e], vf[p][4 + e] = hi[e];
                         }
-                        ol = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0], pq[1], ol, 0, 0, 0);
                         oh = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0], pq[0], oh, 0, 0, 0);
-                        if constexpr (NP == 2) ol = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1], pq[0], ol, 0, 0, 0);
+                        oh = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0], pq[1], oh, 0, 0, 0);
+                        if constexpr (NP == 2) oh = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1], pq[0], oh, 0, 0, 0);
                     }
                 }
             }
@@ -324,7 +367,7 @@ __global__ __launch_bounds__(NWV * 64) void cross_attention_split16_kernel(const
                     int vo = (int)(((unsigned)(4 * half) * HWu + (unsigned)q) * 4u);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {   // accumulator row r -> channel (r & 3) + 8 (r >> 2) + 4 half; >= C: dropped
-                        const float ov = fmaf(ol[r], SPLIT16_LO_UNSCALE, oh[r]) * inv;
+                        const float ov = oh[r] * (inv * (1.0f / (PRE * PP)));
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ov), ro, vo, 0, 0);
                         vo += (int)(((r & 3) == 3 ? 5u : 1u) * HWu * 4u);
                     }
