@@ -193,8 +193,8 @@ int stereo_resize_bilinear_nhwc_f32(const float *in, float *out, int N, int C, i
  *     models/CrossAttentionCostVolume/cross_attention_cost_volume.py)
  *     left,right [B,C,H,W], value [B,Cv,H,W] -> out [B,Cv,H,W] (or NULL), disp [B,H,W] (or NULL)
  *     Numerics: fp32-faithful (split operands on the fp16 / bf16 matrix cores, fp32 accumulation).  Feature range of the
- *     default kernels: |x| < 65 504 at C <= 32 with value == right, |x| < 4 094 at C > 32 without a value tensor (bands
- *     <= 128), fp32's whole range otherwise; beyond it the result is inf / NaN, never silently wrong. */
+ *     default kernels: |x| < 4 094 (fp32 features; 65 504 for fp16 ones) at C <= 32 with value == right and at C > 32
+ *     without a value tensor (bands <= 128), fp32's whole range otherwise; beyond it inf / NaN, never silently wrong. */
 int stereo_cross_attention_f32(const float *left, const float *right, const float *value,
                                float *out, float *disp, int B, int C, int Cv, int H, int W, int D,
                                int mask_mode, int scale_mode, void *stream);

@@ -59,9 +59,9 @@ class CrossAttentionCostVolume(nn.Module):
     per row, logits ``<L[:,w], R[:,w-d]> * scale`` for d in [0, max_disp), softmax over d,
     ``disp = sum_d p_d d`` and ``out[:,w] = sum_d p_d V[:,w-d]`` (V defaults to the right features).
 
-    Inference kernels are fp32-faithful on split fp16 / bf16 matrix-core operands; the default ones assume ``|feature| <
-    65504`` (C <= 32, V = right features) or ``< 4094`` (C > 32, ``need_out=False``, max_disp <= 128) and return inf / NaN
-    beyond that, never a silently wrong number (include/stereo_hip.h, A7)."""
+    Inference kernels are fp32-faithful on split fp16 / bf16 matrix-core operands; the default ones for C <= 32 with V = right
+    features and for C > 32 with ``need_out=False`` (max_disp <= 128) assume ``|feature| < 4094`` (fp16 features: 65504) and
+    return inf / NaN beyond that, never a silently wrong number (include/stereo_hip.h, A7)."""
 
     def __init__(self, max_disp, mask="zero", scale="sqrt_c"):
         super().__init__()

@@ -1,13 +1,18 @@
 // Epipolar cross-attention (A7), C <= 32, value = right features, on the FP16 matrix cores with SPLIT operands (v9).
 //
 // attention_bf16.hip (v7) splits every fp32 operand into three bf16 pieces and runs six piece products per fp32 product: 22
-// matrix instructions per 32-key tile (12 for Q K^T, 10 for P V).  Here every operand is TWO fp16 pieces, x = hi + 2^-11 lo'
-// (common.h: 22-23 significant bits; exact piece products), the three leading products go to two fp32 accumulators -- hi hi
-// into one, hi lo' + lo' hi into the other, result = acc0 + 2^-11 acc1 -- so a tile costs 6 + 6 v_mfma_f32_32x32x16_f16
-// instead of 22, and the probabilities reach P V with 22 bits instead of v7's 16.  fp16 FEATURES are their own single piece:
-// the score scale moves from the Q operand to the accumulator (so Q stays exactly fp16) and a tile costs 2 + 4.
-// Range: |feature| < 65 504 (fp16); beyond it the result is inf / NaN, never silently wrong -- the fp32 kernels of
-// attention.hip cover fp32's whole range (test hook att_kernel = 5 / 4).
+// matrix instructions per 32-key tile (12 for Q K^T, 10 for P V).  Here every operand is TWO fp16 pieces and the three leading
+// products are kept: 6 + 6 v_mfma_f32_32x32x16_f16 per tile, and the probabilities reach P V with 22 bits instead of v7's 16.
+// Arithmetic (end of round 3; until then the low piece was scaled, x = hi + 2^-11 lo', and the cross terms had an accumulator
+// of their own): a value is split as 16 x = hi + lo with an UNSCALED low piece -- hi = fp16(16 x), lo = fp16(16 x - hi), two
+// v_fma_mix per value -- so hi hi + hi lo + lo hi accumulate in ONE fp32 accumulator (scores = acc / 256): no second
+// accumulator, no zero accumulator, no combine per tile.  lo is a normal fp16 number for |x| >= 2^-7 (22-23 significant bits);
+// below that it rounds on the subnormal grid, an absolute error of <= 2^-29 in x, invisible to the scores.  Probabilities are
+// split the same way as 1024 p.  With the ring prefetching only a tile's own 256 keys the fp32-feature kernel of cfg-3 fits
+// 125 registers: TWO 8-wave workgroups per CU (0.735 -> 0.65 ms).  fp16 FEATURES are their own single piece, exactly: the
+// score scale sits on the accumulator and a tile costs 2 + 4.
+// Range: |feature| < 4 094 (fp32 features: 16 x in fp16), < 65 504 (fp16 features); beyond it the result is inf / NaN, never
+// silently wrong -- the fp32 kernels of attention.hip cover fp32's whole range (test hook att_kernel = 5 / 4).
 //
 // LDS image [piece][channel][key] f16 as in v7 (one image serves V^T row-wise and K through ds_read_b64_tr_b16), but channel
 // row r starts 16 (r & 3) + 2 (r >> 2) dwords into a row slot that is a whole number of 256-B bank rows: the transposed K read

@@ -527,20 +527,22 @@ def test_cross_attention_key_ring_random_runs(S, oracle):
     """The default C <= 32 kernel's key ring (256-query tiles, D > 128: a tile that continues its predecessor's row stages only
     its 256 new keys) under random widths, bands, channel counts and lengths of the persistent workgroups' tile runs."""
     rng = np.random.default_rng(77)
-    for _ in range(8):
+    for it in range(12):
         B, H = int(rng.integers(1, 3)), int(rng.integers(1, 4))
         C = int(rng.integers(1, 33))
         W = 4 * int(rng.integers(130, 340))
         D = int(rng.integers(161, 193))
-        tpw = int(rng.choice([0, 2, 3, 4, 7]))
+        tpw = int(rng.choice([0, 1, 2, 3, 4, 7]))   # 1: every tile restarts the ring (mid-row halo loads); 3, 7: rows end mid-run
         mask = str(rng.choice(["zero", "neginf"]))
         L = rng.standard_normal((B, C, H, W), dtype=np.float32)
         R = rng.standard_normal((B, C, H, W), dtype=np.float32)
+        if it >= 8:   # very different magnitudes left and right: the low fp16 piece of a small value is subnormal (absolute accuracy)
+            L, R = (L * 0.004).astype(np.float32), (R * 250).astype(np.float32)
         oo, od = oracle.cross_attention(L, R, None, D, mask, "sqrt_c")
         with S._native.test_options(att_waves=8, tiles_per_wg=tpw):
             o, d = S.CrossAttentionCostVolume(D, mask, "sqrt_c")(dev(L), dev(R))
             _, d2 = S.CrossAttentionCostVolume(D, mask, "sqrt_c")(dev(L), dev(R), need_out=False)
-        close(o, oo, rtol=1e-4, atol=5e-5)
+        close(o, oo, rtol=1e-4, atol=5e-5 * max(1.0, float(np.abs(R).max()) / 4))   # (absolute part: relative to the values summed)
         close(d, od, rtol=0, atol=1e-3, mean_atol=2.5e-4)
         close(d2, od, rtol=0, atol=1e-3, mean_atol=2.5e-4)
 
