@@ -164,8 +164,11 @@ class MappedArena:
         if self._handle is None or nbytes <= 0 or nbytes % es or first_chunk < lo or \
                 first_chunk * self.chunk_bytes + nbytes > (lo + n) * self.chunk_bytes:
             raise ValueError("MappedArena.window: outside the mapped chunks")
-        return torch.as_tensor(_MappedView(self, self._base + first_chunk * self.chunk_bytes, nbytes // es, dtype),
-                               device=self.device)
+        ptr = self._base + first_chunk * self.chunk_bytes
+        t = torch.as_tensor(_MappedView(self, ptr, nbytes // es, dtype), device=self.device)
+        if t.data_ptr() != ptr:   # (a copy would silently defeat the placement)
+            raise RuntimeError("MappedArena.window: torch copied the mapped memory instead of wrapping it")
+        return t
 
     def keep(self, first_chunk, count):
         """Unmap and release every chunk outside ``[first_chunk, first_chunk + count)`` (device synchronised first).  Windows
