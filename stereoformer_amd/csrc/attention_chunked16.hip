@@ -27,7 +27,7 @@ namespace {
 
 // DBG (dev ablations, not instantiated in the library): 1 = no matrix work, 3 = every load through an empty resource.
 template <int NT, int NWV, typename TIN, int DBG = 0>
-__global__ __launch_bounds__(NWV * 64, (NT <= 3 ? 4 : 2)) void cross_attention_disp_chunked16_kernel(
+__global__ __launch_bounds__(NWV * 64, (NT <= 3 ? 4 : 3)) void cross_attention_disp_chunked16_kernel(
     const TIN *__restrict__ L, const TIN *__restrict__ R, float *__restrict__ disp, int C, int H, int W, int D, int mask_mode,
     float scale, int tiles_per_wg, int ntiles)
 {
