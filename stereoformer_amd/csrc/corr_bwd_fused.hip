@@ -17,16 +17,17 @@
 // is complete and is stored -- no atomics, no partial buffers, a fixed summation order.  R's keys reach 192 columns to the left
 // of the rectangle: they are still in LDS from the rectangles before (ring of 448 keys); L is needed for the rectangle only.
 //
-// Arithmetic.  Split-fp16 on v_mfma_f32_32x32x16_f16 (6 per wave and step): x = hi + lo, products hi hi + hi lo -> acc0,
-// lo' hi -> acc1 with lo' = 2^11 lo on the feature side.  Features are split once per rectangle when they enter LDS (the range
-// contract of the forward's split-fp16 matrix phase: fp32-faithful for 2^-14 <= |x| < 65504).  GRADIENTS have no natural
+// Arithmetic.  Split-fp16 on v_mfma_f32_32x32x16_f16 (6 per wave and step): x = hi + lo, products hi hi + hi lo + lo hi in ONE
+// fp32 accumulator.  Features are split once per rectangle when they enter LDS, as 16 x = hi + lo with an unscaled low piece
+// (a normal fp16 number for |x| >= 2^-7, an absolute error of <= 2^-29 in x below that; |feature| < 4 094 -- until the end
+// of round 3 the low piece carried 2^11 and its products a second accumulator: 1.49 -> 1.38 ms).  GRADIENTS have no natural
 // scale (a mean-reduced loss hands over 1e-9), so each wave scales its 32 x 32 gradient tile per OUTPUT COLUMN by the power of
 // two that puts the column's largest element into [2^14, 2^15) before splitting -- a per-column scale commutes with the
-// product -- runs the six MFMAs from zero accumulators and adds acc0 / sigma + acc1 / (2^11 sigma) to its fp32 totals.  The
+// product -- runs the six MFMAs from a zero accumulator and adds acc / (16 sigma) to its fp32 totals.  The
 // gradient's low piece stays UNSCALED: against a column maximum >= 2^14 its absolute error (fp16's subnormal spacing) is 2^-39
 // of the largest term of the dot product.  Result: as close to fp64 as the f32 matrix cores for gradients from 3e-9 to 2e7
 // (tests/test_gpu_backward.py::test_corr_volume_backward_single_read_kernel).
-// Measured alternatives (cfg-2 size, 8 pairs; this form 1.49 ms): all sixteen v_mfma_f32_32x32x2_f32 per step on the raw values
+// Measured alternatives (cfg-2 size, 8 pairs; against this kernel's 1.49 ms before the one-accumulator form): all sixteen v_mfma_f32_32x32x2_f32 per step on the raw values
 // (no operand preparation at all) 1.81 ms, f32 MFMAs for the dR waves only 1.66 ms -- the f32 matrix pipe at 64 cycles per
 // instruction is the slower resource.  This form runs the vector pipe at ~40 % and the matrix pipe at 9 %: its step time
 // (1.5 us for 16 KB of volume per CU) is the dependent chain LDS read -> column maximum -> split -> MFMA -> totals of two waves
@@ -103,7 +104,7 @@ __device__ __forceinline__ float fb_gradient_tile(const float *__restrict__ Sh, 
     ex = ex < 16 ? 16 : (ex > 254 ? 254 : ex);
     const float sig = __uint_as_float((unsigned)(268 - ex) << 23);  // column max -> [2^14, 2^15)
     // hi = fp16(x sigma), lo = fp16(x sigma - hi) UNSCALED: lo's absolute error is <= 2^-25 (fp16's subnormal spacing) against
-    // a column maximum of >= 2^14, i.e. 2^-39 of the largest term of the dot product -- the features carry the 2^11 instead
+    // a column maximum of >= 2^14, i.e. 2^-39 of the largest term of the dot product
     typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
     u32x4v hv[2], lv[2];
 #pragma unroll
@@ -124,21 +125,44 @@ __device__ __forceinline__ float fb_gradient_tile(const float *__restrict__ Sh, 
     return __uint_as_float((unsigned)(ex - 14) << 23);  // 1 / sigma
 }
 
+constexpr float FB_PRE = 16.0f;   // features are split as 16 x (|feature| < 4 094)
+// eight fp32 values -> hi / unscaled-lo fp16 pieces of FB_PRE x: two mixed-precision FMAs per value
+__device__ __forceinline__ void fb_split_oct(const float *x, f16x8 *p)
+{
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    float pre = FB_PRE;
+    asm volatile("" : "+v"(pre));
+    u32x4v h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned hu, lu;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hu) : "v"(x[2 * j]), "v"(pre));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hu) : "v"(x[2 * j + 1]), "v"(pre));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lu) : "v"(x[2 * j]), "v"(pre), "v"(hu));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lu) : "v"(x[2 * j + 1]), "v"(pre), "v"(hu));
+        h[j] = hu, l[j] = lu;
+    }
+    p[0] = __builtin_bit_cast(f16x8, h), p[1] = __builtin_bit_cast(f16x8, l);
+}
+
 __device__ __forceinline__ void fb_products(const unsigned char *__restrict__ ahi, const unsigned char *__restrict__ alo,
                                             const f16x8 (&bh)[2], const f16x8 (&bl)[2], float inv, f32x16 &tot)
 {
     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const f16x8 ah0 = *reinterpret_cast<const f16x8 *>(ahi), ah1 = *reinterpret_cast<const f16x8 *>(ahi + 32);
     const f16x8 al0 = *reinterpret_cast<const f16x8 *>(alo), al1 = *reinterpret_cast<const f16x8 *>(alo + 32);
+    // ONE accumulator: the feature pieces are 16 x = hi + lo with an UNSCALED low piece (store_features), the gradient's low piece
+    // is unscaled as well, so hi hi + hi lo + lo hi share it (until the end of round 3 the features' low piece carried 2^11 and
+    // the lo hi products an accumulator of their own: 16 more registers and 16 more FMAs per call)
     f32x16 a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[0], z, 0, 0, 0);
-    f32x16 a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[0], z, 0, 0, 0);
     a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh[1], a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh[1], a1, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[0], a0, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh[1], a0, 0, 0, 0);
     a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[0], a0, 0, 0, 0);
     a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl[1], a0, 0, 0, 0);
-    const float inv_lo = inv * SPLIT16_LO_UNSCALE;
+    const float invu = inv * (1.0f / FB_PRE);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tot[r] = fmaf(a1[r], inv_lo, fmaf(a0[r], inv, tot[r]));
+    for (int r = 0; r < 16; ++r) tot[r] = fmaf(a0[r], invu, tot[r]);
 }
 
 __device__ __forceinline__ void fb_store_tile(float *__restrict__ out, int C, unsigned HWu, int col, int W, int half,
@@ -264,13 +288,13 @@ __global__ __launch_bounds__(FB_NTH) void corr_volume_bwd_fused_kernel(const flo
             f16x8 p[2];
 #pragma unroll
             for (int k = 0; k < 8; ++k) x[k] = (ch < C && f_col + 4 * (k >> 2) < W) ? fl[u][k >> 2][k & 3] : 0.0f;
-            split_oct_f16(x, p);
+            fb_split_oct(x, p);
             unsigned char *lp = Lhi + lb * 2 * FB_LPLANE + ch * FB_LB + 2 * fx;
             *reinterpret_cast<f16x8 *>(lp) = p[0];
             *reinterpret_cast<f16x8 *>(lp + FB_LPLANE) = p[1];
 #pragma unroll
             for (int k = 0; k < 8; ++k) x[k] = (ch < C && f_col + 4 * (k >> 2) < W) ? fr[u][k >> 2][k & 3] : 0.0f;
-            split_oct_f16(x, p);
+            fb_split_oct(x, p);
             int pos = rb + fx;
             pos = pos >= FB_RK ? pos - FB_RK : pos;
             *reinterpret_cast<f16x8 *>(Rhi + ch * FB_RB + 2 * pos) = p[0];
