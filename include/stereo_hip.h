@@ -231,7 +231,9 @@ int stereo_soft_argmin_bwd_add_f32(const float *vol, const float *grad_disp, con
                                    int B, int D, int H, int W, int match_similarity, void *stream);
 
 /* backward of A1/A3 (build_cost_volume.py:39-47, GWC_Cost_Volume.py:14-24): grad_vol [B,G,D,H,W] ->
- * grad_left, grad_right [B,C,H,W] (either may be NULL); G = 1 for the correlation volume */
+ * grad_left, grad_right [B,C,H,W] (either may be NULL); G = 1 for the correlation volume.  With both gradients, C / G <= 32,
+ * D <= 192 and W % 4 == 0 the volume's cotangent is read ONCE (split-fp16 matrix cores; gradients of any magnitude, features
+ * |x| < 4 094 -- inf / NaN beyond, never silently wrong); otherwise two launches on the f32 matrix cores / vector units. */
 int stereo_gwc_volume_bwd_f32(const float *left, const float *right, const float *grad_vol,
                               float *grad_left, float *grad_right, int B, int C, int H, int W, int D, int G,
                               void *stream);
