@@ -121,16 +121,15 @@ __global__ __launch_bounds__(NWV * 64, (NT <= 3 ? 4 : 3)) void cross_attention_d
         kp += (size_t)CH * HWu, krows -= CH;
         if (++kj == nck) kj = 0, krows = C, kp = tile_row(R, ++kt, kx);
     };
-    const int vq0 = (int)(((unsigned)(8 * half) * HWu + (unsigned)(32 * wave + l31)) * ES);
+    int vqj[8];                                   // lane-invariant Q offsets (channel 8 half + j, query 32 wave + l31); the tile's
+#pragma unroll                                    // first query goes into the loads' SCALAR offset
+    for (int j = 0; j < 8; ++j) vqj[j] = (int)(((unsigned)(8 * half + j) * HWu + (unsigned)(32 * wave + l31)) * ES);
     auto issue_q = [&](bool live) {               // the Q values of an item are issued one iteration later than its keys (below)
         const int nrow = qrows < CH ? qrows : CH;
         const __amdgpu_buffer_rsrc_t rq = buffer_rsrc(qp, live ? ((unsigned)(nrow - 1) * HWu + (unsigned)W) * ES : 0u);
-        int vq = vq0 + qx * TQW * ES;
+        const int sq = qx * TQW * ES;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {             // B operand: element i -> channel c0 + 8 half + i, query l31 of the wave
-            qn[i] = BufLd<TIN>::one(rq, vq, 0);
-            vq += (int)(HWu * ES);
-        }
+        for (int i = 0; i < 8; ++i) qn[i] = BufLd<TIN>::one(rq, vqj[i], sq);   // B operand: element i -> channel c0 + 8 half + i
         qp += (size_t)CH * HWu, qrows -= CH;
         if (++qj == nck) qj = 0, qrows = C, qp = tile_row(L, ++qt, qx);
     };
@@ -200,14 +199,13 @@ __global__ __launch_bounds__(NWV * 64, (NT <= 3 ? 4 : 3)) void cross_attention_d
             for (int t = 0; t < NT; ++t) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
+                    s16x4 kq[2];
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
                         const _Float16 *src = &cur[p * PSE + k_off + 4 * tt * RSE + 4 * tt + 32 * (wave + t)];
-                        const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)src);
-                        const short tv[4] = {v[0], v[1], v[2], v[3]};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) kf[t][p][4 * tt + e] = __builtin_bit_cast(_Float16, tv[e]);
+                        kq[tt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)src);
                     }
+                    kf[t][p] = __builtin_bit_cast(f16x8, __builtin_shufflevector(kq[0], kq[1], 0, 1, 2, 3, 4, 5, 6, 7));
                 }
             }
 #pragma unroll
