@@ -294,6 +294,12 @@ int stereo_resize_bilinear_bwd_f32(const float *grad_out, float *grad_in_zeroed,
 int stereo_variance_lookup_bwd_f32(const float *vol, const float *disp, const float *grad_out, float *grad_vol_zeroed,
                                    float *grad_disp, int B, int D, int H, int W, float gamma, int S, int consider_valid,
                                    void *stream);
+/* The same in one dense launch: grad_vol need NOT be zero-filled (every element is written once: the variance path makes the
+ * gradient dense in d).  D <= 192, H*W % 4 == 0, sample_points <= 20, 16-byte aligned tensors, else STEREO_ERR_UNSUPPORTED
+ * (the caller zero-fills and takes the entry above). */
+int stereo_variance_lookup_bwd_dense_f32(const float *vol, const float *disp, const float *grad_out, float *grad_vol,
+                                         float *grad_disp, int B, int D, int H, int W, float gamma, int sample_points,
+                                         int consider_valid, void *stream);
 int stereo_diff_volume_bwd_f32(const float *grad_vol, float *grad_left, float *grad_right,
                                int B, int C, int H, int W, int D, void *stream);
 int stereo_concat_volume_bwd_f32(const float *grad_vol, float *grad_left, float *grad_right,

@@ -99,6 +99,7 @@ SIGNATURES = {
     "stereo_local_lookup_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
     "stereo_local_lookup_bwd_dense_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
     "stereo_variance_lookup_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
+    "stereo_variance_lookup_bwd_dense_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp],
     "stereo_diff_volume_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_concat_volume_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "stereo_upsample_convex_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

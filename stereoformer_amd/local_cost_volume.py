@@ -112,11 +112,18 @@ class _VarianceLookupFn(torch.autograd.Function):
         gamma, S, cv = ctx.cfg
         B, D, H, W = vol.shape
         go = N.dev_f32(grad_out, "Variance_Based_Local_Cost_Volume backward: grad")
-        gvol = torch.zeros_like(vol)      # taps and the variance path are accumulated into it
+        gvol = torch.empty_like(vol)
         gdisp = torch.empty_like(disp)
         with torch.cuda.device(vol.device):
-            N.call("stereo_variance_lookup_bwd_f32", N.ptr(vol), N.ptr(disp), N.ptr(go), N.ptr(gvol), N.ptr(gdisp), B, D,
-                   H, W, gamma, S, 1 if cv else 0, N.stream_ptr(vol.device))
+            try:   # one dense launch: every element of grad_vol written once (D <= 192, H*W % 4 == 0, sample_points <= 20)
+                N.call("stereo_variance_lookup_bwd_dense_f32", N.ptr(vol), N.ptr(disp), N.ptr(go), N.ptr(gvol), N.ptr(gdisp), B,
+                       D, H, W, gamma, S, 1 if cv else 0, N.stream_ptr(vol.device))
+            except N.StereoHipError as e:
+                if e.code != N.ERR_UNSUPPORTED:
+                    raise
+                gvol.zero_()           # taps and the variance path are accumulated into it
+                N.call("stereo_variance_lookup_bwd_f32", N.ptr(vol), N.ptr(disp), N.ptr(go), N.ptr(gvol), N.ptr(gdisp), B, D,
+                       H, W, gamma, S, 1 if cv else 0, N.stream_ptr(vol.device))
         return gvol, gdisp, None, None, None
 
 

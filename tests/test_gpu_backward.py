@@ -439,6 +439,41 @@ def test_variance_lookup_backward_g15(S, golden):
             close(gd, g[f"vl_gdisp_g{gm}_S{Sp}_cv{int(cv)}"], rtol=2e-3, atol=5e-4)
 
 
+@pytest.mark.parametrize("shape", [(1, 24, 5, 64), (2, 48, 3, 100), (1, 192, 4, 132), (2, 100, 7, 36), (1, 33, 1, 4), (1, 7, 2, 260)])
+@pytest.mark.parametrize("cv", [False, True])
+def test_variance_lookup_backward_dense_launch(S, shape, cv):
+    """A6 backward in one dense launch (no zero-fill; every element of grad_vol written once) against the accumulate-into-zeros
+    kernel it replaces: same terms, the column statistics reduced in another order -- peaked and flat columns, disparities at
+    both ends of the range, every register-slice size (D 7 .. 192), workgroups with partial pixel blocks."""
+    from stereoformer_amd import _native as N
+    B, D, H, W = shape
+    torch.manual_seed(D * 7 + W)
+    vol = torch.randn(B, D, H, W, device="cuda") * 3
+    vol[:, D // 3, :, : W // 2] += 12.0                          # a sharply peaked half
+    disp = torch.rand(B, 1, H, W, device="cuda") * (D - 1)
+    disp[..., :2] = 0.0
+    disp[..., -2:] = D - 1
+    cot = torch.randn(B, 1, H, W, device="cuda")
+    for (gm, Sp) in ((1.0, 10), (2.0, 20), (0.5, 7)):
+        dense, gd1 = torch.full_like(vol, float("nan")), torch.empty_like(disp)
+        acc, gd0 = torch.zeros_like(vol), torch.empty_like(disp)
+        N.call("stereo_variance_lookup_bwd_dense_f32", N.ptr(vol), N.ptr(disp), N.ptr(cot), N.ptr(dense), N.ptr(gd1), B, D, H, W, gm,
+               Sp, int(cv), N.stream_ptr(vol.device))
+        N.call("stereo_variance_lookup_bwd_f32", N.ptr(vol), N.ptr(disp), N.ptr(cot), N.ptr(acc), N.ptr(gd0), B, D, H, W, gm, Sp,
+               int(cv), N.stream_ptr(vol.device))
+        assert torch.isfinite(dense).all()
+        scale = max(acc.abs().max().item(), 1e-6)
+        # (a sharply peaked column has a tiny sigma, and 1 / (2 sigma) amplifies the rounding of the variance sum: 1e-4-level
+        # differences between two summation orders are fp32 conditioning, not a discrepancy; and where every candidate of a
+        # pixel is the current disparity (invalid pixels) the true tap gradient is 0 and both kernels return rounding noise of
+        # |g| D eps)
+        assert (dense - acc).abs().max().item() <= 2e-4 * scale + 1e-4, (gm, Sp)
+        assert (gd1 - gd0).abs().max().item() <= 5e-4 * max(gd0.abs().max().item(), 1e-6) + 1e-4, (gm, Sp)
+    with pytest.raises(N.StereoHipError):                        # outside the envelope: refused, the host takes the other entry
+        N.call("stereo_variance_lookup_bwd_dense_f32", N.ptr(vol), N.ptr(disp), N.ptr(cot), N.ptr(dense), N.ptr(gd1), B, D, H, W, 1.0,
+               21, int(cv), N.stream_ptr(vol.device))
+
+
 def test_shift_volume_backward_g15(S, golden):
     """A2 'difference' / 'concat' volume gradients against the reference's autograd (G15), D in {1, 7, W, > W}; exact sums of
     the same terms in another order."""

@@ -373,8 +373,10 @@ def main():
             o6 = S.Variance_Based_Local_Cost_Volume(1, 20)(v1, d6, True)
             c6 = torch.randn_like(o6)
             n1 = H * W
-            add("bwd A6 variance-based lookup, 1 pair (incl. zero-fill of grad volume)",
-                timeit(lambda: torch.autograd.grad(o6, (v1, d6), c6, retain_graph=True), 5, 1), (2 * n1 * D * 4 + 4 * n1 * 4) / 1e9)
+            add("bwd A6 variance-based lookup, 1 pair (one dense launch)",
+                timeit(lambda: torch.autograd.grad(o6, (v1, d6), c6, retain_graph=True), 5, 1), (2 * n1 * D * 4 + 4 * n1 * 4) / 1e9,
+                note="round 3 (last day): the gradient is dense in d (variance path), so one launch writes every element once -- "
+                     "0.57 ms as thread-per-pixel accumulation into a zero-filled tensor")
             del v1, d6, o6, c6
             La, Ra = L[:1, :8].detach().requires_grad_(True), R[:1, :8].detach().requires_grad_(True)
             for kind in ("difference", "concat"):
