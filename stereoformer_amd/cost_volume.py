@@ -47,12 +47,16 @@ class _GwcWithDisparityFn(torch.autograd.Function):
     [B,G,D,H,W] gradient even when only the disparity is used.)"""
 
     @staticmethod
-    def forward(ctx, left, right, max_disp, num_groups, match_similarity):
+    def forward(ctx, left, right, max_disp, num_groups, match_similarity, out_vol=None, out_disp=None, out_mean=None):
         B, C, H, W = left.shape
         D, G = int(max_disp), int(num_groups)
-        vol = torch.empty((B, G, D, H, W), device=left.device, dtype=torch.float32)
-        disp = torch.empty((B, H, W), device=left.device, dtype=torch.float32)
-        mean = torch.empty((B, D, H, W), device=left.device, dtype=torch.float32)
+        if out_vol is not None:   # caller-owned (placed) buffers: outputs written in place into history-free aliases
+            vol, disp, mean = out_vol, out_disp, out_mean
+            ctx.mark_dirty(vol, disp, mean)
+        else:
+            vol = torch.empty((B, G, D, H, W), device=left.device, dtype=torch.float32)
+            disp = torch.empty((B, H, W), device=left.device, dtype=torch.float32)
+            mean = torch.empty((B, D, H, W), device=left.device, dtype=torch.float32)
         with torch.cuda.device(left.device):
             N.call("stereo_gwc_volume_soft_argmin_f32", N.ptr(left), N.ptr(right), N.ptr(vol), N.ptr(mean), N.ptr(disp), B, C, H,
                    W, D, G, 1 if match_similarity else 0, N.stream_ptr(left.device))
@@ -105,7 +109,7 @@ class _GwcWithDisparityFn(torch.autograd.Function):
                 a, b = vol_bwd(N.dev_f32(g_vol, "fused volume backward: grad_vol"), G)
                 gl = a if gl is None else (gl + a if a is not None else gl)
                 gr = b if gr is None else (gr + b if b is not None else gr)
-        return gl, gr, None, None, None
+        return gl, gr, None, None, None, None, None, None
 
 
 class _ShiftVolumeFn(torch.autograd.Function):
@@ -271,20 +275,32 @@ def build_gwc_volume_with_disparity(refimg_fea, targetimg_fea, maxdisp, num_grou
     produced: the [B,G,D,H,W] volume is written once and never read back (cfg-2: 25.5 GB of reads saved).
     Differentiable: the backward follows the fused forward (see ``_GwcWithDisparityFn``).
 
-    ``out=(vol, disp, mean)`` (inference only, like torch's ``out=``): caller-owned output tensors that this call overwrites
-    completely -- for buffers that live across many steps and were placed with ``stereoformer_amd.hbm.place_volume_stage_outputs``."""
+    ``out=(vol, disp, mean)`` (like torch's ``out=``): caller-owned output tensors that this call overwrites completely -- for
+    buffers that live across many steps and were placed with ``stereoformer_amd.hbm.place_volume_stage_outputs``.  Under grad
+    the outputs are in-place results on history-free aliases of the buffers (a training loop whose backward runs before the
+    next forward can reuse the same placed buffers every step)."""
     if ops.tracing():
         vol, disp, mean = torch.ops.stereo_hip.gwc_volume_soft_argmin(refimg_fea, targetimg_fea, int(maxdisp), int(num_groups),
                                                                       bool(match_similarity))
         return (vol, disp, mean) if return_mean else (vol, disp)
     if _wants_grad(refimg_fea, targetimg_fea):
-        if out is not None:
-            raise RuntimeError("build_gwc_volume_with_disparity: out= is an inference option (call under torch.no_grad())")
         with torch.no_grad():
             L, R = _pair(refimg_fea, targetimg_fea, "build_gwc_volume_with_disparity")
         assert L.shape[1] % num_groups == 0  # GWC_Cost_Volume.py:7
+        outs = ()
+        if out is not None:
+            # under grad the buffers are written in place through history-free aliases (`detach()`): the returned tensors
+            # carry this call's graph, the caller's buffers stay plain tensors for the next step.  As with any in-place op,
+            # a backward through an EARLIER call's graph after the buffers were overwritten is refused by autograd.
+            B, C, H, W = L.shape
+            D, G = int(maxdisp), int(num_groups)
+            if any(isinstance(t, torch.Tensor) and t.requires_grad for t in out):
+                raise RuntimeError("build_gwc_volume_with_disparity: out= tensors must not require grad")
+            outs = (_check_out(out[0], (B, G, D, H, W), L.device, "[0] (volume)").detach(),
+                    _check_out(out[1], (B, H, W), L.device, "[1] (disparity)").detach(),
+                    _check_out(out[2], (B, D, H, W), L.device, "[2] (mean volume)").detach())
         vol, disp, mean = _GwcWithDisparityFn.apply(refimg_fea.contiguous(), targetimg_fea.contiguous(), int(maxdisp),
-                                                    int(num_groups), bool(match_similarity))
+                                                    int(num_groups), bool(match_similarity), *outs)
         return (vol, disp, mean) if return_mean else (vol, disp)
     L, R = _pair(refimg_fea, targetimg_fea, "build_gwc_volume_with_disparity", feat=True)
     assert L.shape[1] % num_groups == 0  # GWC_Cost_Volume.py:7

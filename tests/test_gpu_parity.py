@@ -821,8 +821,23 @@ def test_out_buffers_and_placement(S, oracle):
         assert a.data_ptr() == b_.data_ptr() and torch.equal(a, w)
     with pytest.raises(ValueError, match="out"):
         S.build_gwc_volume_with_disparity(L, R, D, G, out=(bufs[0], bufs[1], bufs[2][:, :-1]))
-    with pytest.raises(RuntimeError, match="inference option"):
-        S.build_gwc_volume_with_disparity(L.clone().requires_grad_(True), R, D, G, out=bufs)
+    # out= under grad: the same (placed) buffers serve every training step -- in-place results on history-free aliases
+    cot = torch.randn(B, H, W, device="cuda")
+    Lr, Rr = L.clone().requires_grad_(True), R.clone().requires_grad_(True)
+    _, d0, m0 = S.build_gwc_volume_with_disparity(Lr, Rr, D, G, return_mean=True)
+    g0 = torch.autograd.grad((d0 * cot).sum() + m0.square().sum(), (Lr, Rr))
+    for step in range(2):
+        v1, d1, m1 = S.build_gwc_volume_with_disparity(Lr, Rr, D, G, return_mean=True, out=bufs)
+        assert v1.data_ptr() == bufs[0].data_ptr() and d1.data_ptr() == bufs[1].data_ptr() and m1.data_ptr() == bufs[2].data_ptr()
+        assert d1.requires_grad and not bufs[1].requires_grad and bufs[1].grad_fn is None
+        g1 = torch.autograd.grad((d1 * cot).sum() + m1.square().sum(), (Lr, Rr), retain_graph=step == 1)
+        for a, b_ in zip(g1, g0):
+            assert torch.equal(a, b_)
+    S.build_gwc_volume_with_disparity(Lr, Rr, D, G, return_mean=True, out=bufs)      # overwrites the buffers of the retained graph
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        torch.autograd.grad((d1 * cot).sum() + m1.square().sum(), (Lr, Rr))
+    with pytest.raises(RuntimeError, match="must not require grad"):
+        S.build_gwc_volume_with_disparity(Lr, Rr, D, G, out=(bufs[0], bufs[1], bufs[2].clone().requires_grad_(True)))
 
 
 @pytest.mark.parametrize("cfg", [(2, 32, 3, 520, 192), (1, 20, 2, 260, 70), (1, 7, 1, 64, 5), (1, 32, 2, 960, 130), (2, 16, 2, 100, 33)])
