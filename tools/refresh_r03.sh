@@ -39,6 +39,9 @@ print(f"one pass of RAFTStereoLoop (16 iterations, 8 pairs at 1/4 of 544x960, NH
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:20]:
     print("  %8.3f ms %4d launches  %s" % (v[0], v[1], k))
 PY
+bash tools/a7_sq_pmc.sh > $O/a7_sq_pmc.log 2>&1
+cp gpurun_out/a7_sq/pmc_a7_sq.json $P/r03_pmc_a7_sq.json 2>/dev/null
+timeout -k 10 200 python3 tools/place_mapped_probe.py > $P/r03_place_mapped_probe.txt 2>&1
 bash tools/a1bwd_pmc.sh corr_bwd_fused=1 full > $O/a1bwd_pmc.log 2>&1
 cp gpurun_out/a1bwd_pmc/pmc_a1bwd.json $P/r03_pmc_a1bwd.json 2>/dev/null
 (for o in corr_bwd_fused=1 corr_bwd_fused=0 corr_bwd_fused=2 corr_bwd_fused=3 "corr_bwd_fused=1 B=2"; do timeout -k 10 120 python3 tools/a1bwd_ab.py $o 2>&1 | tail -1; done) > $P/r03_a1bwd_ab.txt
