@@ -371,7 +371,9 @@ def small_cin_supported(x, conv) -> bool:
 
 def conv_small_cin(x, conv, relu=False):
     """``conv(x)`` (``relu(conv(x))``) for a KxK convolution over a handful of input channels (``convf1``: 7x7 over the 2-channel
-    flow, update.py:79,87) on the fp32 vector units: NCHW fp32 in, channels-last fp32 out."""
+    flow, update.py:79,87): NCHW fp32 in, channels-last fp32 out.  The 7x7 / 2-channel / 32- or 64-output case (``convf1`` itself)
+    runs as an implicit GEMM on the fp16 matrix cores with split operands (fp32-faithful for ``|x| < 4094``: inf / NaN beyond,
+    never silently wrong); everything else on the fp32 vector units."""
     if not small_cin_supported(x, conv):
         raise ValueError("conv_small_cin: operands outside the kernel's envelope (see conv_split.small_cin_supported)")
     wt = _cached([conv], "tco_small_cin", x.device, lambda: conv.weight.detach().permute(2, 3, 1, 0).contiguous())

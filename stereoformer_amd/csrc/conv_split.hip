@@ -724,6 +724,130 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(const float *__rest
     }
 }
 
+// convf1 proper -- 7x7 over TWO input channels (the flow), 32 or 64 output channels -- as an implicit GEMM on the fp16 matrix
+// cores (end of round 3): K = 49 taps x 2 channels = 98 (padded to 7 k-steps of 16), M = pixels, N = output channels, operands
+// split as 16 x = hi + lo with an unscaled low piece, three products per k-step into ONE accumulator (attention_f16.hip's
+// arithmetic: fp32-faithful for |x| < 4 094).  A workgroup takes 32 x 8 pixels: the fp32 input tile (with halo) sits in LDS as in
+// the vector kernel above, a lane gathers the 8 taps of its k-group for its pixel (tap offsets are compile-time constants
+// selected by the lane's half), splits them in registers; the weights are split ONCE per workgroup into an [N][K] fp16 image
+// whose rows a lane reads as one 16-byte B fragment.  98 x 64 multiply-adds per pixel are 42 matrix instructions per 32 pixels
+// instead of ~2 000 LDS reads and 3 100 packed FMAs per pixel on the vector kernel: 86 -> ~15 us at [8,2,136,240] -> 64.
+template <int NT>
+__global__ __launch_bounds__(256) void conv7_cin2_mfma_kernel(const float *__restrict__ x, const float *__restrict__ wt,
+                                                              const float *__restrict__ bias, float *__restrict__ out, int H, int W,
+                                                              int tiles_x, int tiles_y, int ostride, int relu, int ntiles)
+{
+    constexpr int K = 7, CIN = 2, HC = 32 + K - 1, HR = 8 + K - 1, HALO = K / 2, KK = 112, KROW = KK + 8, COUT = 32 * NT;
+    __shared__ float tile[CIN * HR * HC + 4];
+    __shared__ __attribute__((aligned(16))) _Float16 wB[2][COUT][KROW];   // [piece][out channel][k = tap * 2 + channel]
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    float pre = 16.0f;
+    asm volatile("" : "+v"(pre));
+    auto split2 = [&](float a0, float a1, unsigned &h, unsigned &l) {
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a0), "v"(pre));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(a1), "v"(pre));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a0), "v"(pre), "v"(h));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(a1), "v"(pre), "v"(h));
+    };
+    // weights [tap][channel][COUT] fp32 -> pieces [COUT][k], once per workgroup; k >= 98: zeros (the A operand reads tap 0
+    // there: finite)
+    {   // (all of a thread's weight loads in flight together: COUT * 56 / 256 = 7 NT pairs per thread)
+        constexpr int NW = COUT * (KK / 2) / 256;
+        static_assert(COUT * (KK / 2) % 256 == 0, "weight pairs per thread");
+        float w0[NW], w1[NW];
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int i = tid + 256 * u, n = i % COUT, kp = i / COUT;   // k = 2 kp, 2 kp + 1 (one tap, both channels)
+            w0[u] = 2 * kp < K * K * CIN ? wt[(size_t)(2 * kp) * COUT + n] : 0.0f;
+            w1[u] = 2 * kp + 1 < K * K * CIN ? wt[(size_t)(2 * kp + 1) * COUT + n] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int i = tid + 256 * u, n = i % COUT, kp = i / COUT;
+            unsigned h, l;
+            split2(w0[u], w1[u], h, l);
+            *reinterpret_cast<unsigned *>(&wB[0][n][2 * kp]) = h;
+            *reinterpret_cast<unsigned *>(&wB[1][n][2 * kp]) = l;
+        }
+    }
+  for (int tt = blockIdx.x; tt < ntiles; tt += gridDim.x) {
+    int t = tt;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int x0 = 32 * tx, y0 = 8 * ty;
+    __syncthreads();   // the previous tile's gathers are done
+    for (int i = tid; i < CIN * HR * HC; i += 256) {
+        const int c = i / (HR * HC), r = i - c * (HR * HC);
+        const int hy = r / HC, hx = r - hy * HC;
+        const int yy = y0 - HALO + hy, xx = x0 - HALO + hx;
+        tile[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[(((size_t)b * CIN + c) * H + yy) * W + xx] : 0.0f;
+    }
+    __syncthreads();
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+    const int pbase = (2 * wave) * HC + l31;                         // this lane's pixel of the wave's first row
+#pragma unroll
+    for (int s = 0; s < KK / 16; ++s) {
+        f16x8 ap[2][2];                                              // [row of the wave][piece]
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // k = 16 s + 8 half + j -> tap k / 2 = (ky, kx), channel k & 1: two compile-time offsets, the lane's half picks
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int k0 = 16 * s + j, k1 = 16 * s + 8 + j;
+                const int t0 = k0 < K * K * CIN ? k0 / 2 : 0, t1 = k1 < K * K * CIN ? k1 / 2 : 0;
+                const int o0 = ((k0 & 1) * HR + t0 / K) * HC + t0 % K, o1 = ((k1 & 1) * HR + t1 / K) * HC + t1 % K;
+                a[j] = tile[pbase + mt * HC + (half ? o1 : o0)];
+            }
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split2(a[2 * j], a[2 * j + 1], h[j], l[j]);
+            ap[mt][0] = __builtin_bit_cast(f16x8, (u32x4v){h[0], h[1], h[2], h[3]});
+            ap[mt][1] = __builtin_bit_cast(f16x8, (u32x4v){l[0], l[1], l[2], l[3]});
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f16x8 bh = *reinterpret_cast<const f16x8 *>(&wB[0][32 * nt + l31][16 * s + 8 * half]);
+            const f16x8 bl = *reinterpret_cast<const f16x8 *>(&wB[1][32 * nt + l31][16 * s + 8 * half]);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap[mt][0], bh, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap[mt][0], bl, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap[mt][1], bh, acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+    // accumulator register r of lane (l31, half): pixel column (r & 3) + 8 (r >> 2) + 4 half of the row, output channel l31
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int y = y0 + 2 * wave + mt;
+        if (y < H) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float bv = bias ? bias[32 * nt + l31] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int xo = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = fmaf(acc[mt][nt][r], 1.0f / 256.0f, bv);
+                    if (relu) v = fmaxf(v, 0.0f);
+                    if (xo < W) out[(((size_t)b * H + y) * W + xo) * ostride + 32 * nt + l31] = v;
+                }
+            }
+        }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int stereo_conv_small_cin_nhwc_f32(const float *x, const float *weight_tco, const float *bias, float *out, int B, int Cin,
@@ -740,6 +864,18 @@ extern "C" int stereo_conv_small_cin_nhwc_f32(const float *x, const float *weigh
     const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
     const long long nt = (long long)tiles_x * tiles_y * B;
     if (nt >= (1LL << 31)) return STEREO_ERR_UNSUPPORTED;
+    if (ksize == 7 && Cin == 2 && (Cout == 64 || Cout == 32) && stereo_opt(OPT_CORR_F16P)) {   // convf1: matrix cores (option 0: vector kernel)
+        const unsigned nwg = (unsigned)nt;   // one tile per workgroup: the launch is bound by a workgroup's own latency (persistent runs of
+                                             // two tiles with the weights split once measured slower: 66 vs 57 us at [8,2,136,240])
+        if (Cout == 64)
+            hipLaunchKernelGGL((conv7_cin2_mfma_kernel<2>), dim3(nwg), dim3(256), 0, as_stream(stream), x, weight_tco, bias, out, H, W,
+                               tiles_x, tiles_y, out_stride, relu, (int)nt);
+        else
+            hipLaunchKernelGGL((conv7_cin2_mfma_kernel<1>), dim3(nwg), dim3(256), 0, as_stream(stream), x, weight_tco, bias, out, H, W,
+                               tiles_x, tiles_y, out_stride, relu, (int)nt);
+        STEREO_LAUNCH_CHECK();
+        return STEREO_OK;
+    }
 #define SMALLCIN(KV)                                                                                                          \
     hipLaunchKernelGGL((conv_small_cin_kernel<KV>), dim3((unsigned)nt), dim3(256), 0, as_stream(stream), x, weight_tco, bias, out, \
                        Cin, Cout, H, W, tiles_x, tiles_y, out_stride, relu)
